@@ -1,0 +1,129 @@
+"""ctypes binding of libdruglamp_hip.so (C ABI: include/druglamp_hip.h).
+
+The product path has no CPU fallback: `lib()` raises if the shared object is missing, and every
+wrapper raises RuntimeError with dl_last_error() on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdruglamp_hip.so")
+
+DL_F32, DL_BF16 = 0, 1
+
+c_i64, c_i32, c_f32, c_u64, c_vp, c_sz = C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_void_p, C.c_size_t
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("X", c_vp), ("ldx", c_i64), ("x_kslow", c_i32),
+        ("W", c_vp), ("ldw", c_i64), ("w_kslow", c_i32),
+        ("C", c_vp), ("ldc", c_i64),
+        ("M", c_i64), ("N", c_i64), ("K", c_i64),
+        ("in_dtype", c_i32), ("out_dtype", c_i32),
+        ("bias", c_vp),
+        ("residual", c_vp), ("ldr", c_i64),
+        ("res_row_mod", c_i64),
+        ("res_before_dropout", c_i32),
+        ("act", c_i32),
+        ("pre_out", c_vp), ("ldp", c_i64),
+        ("dact_pre", c_vp), ("lddp", c_i64),
+        ("dropout_p", c_f32), ("dropout_seed", c_u64),
+        ("accumulate", c_i32),
+        ("split_k", c_i32), ("workspace", c_vp), ("workspace_bytes", c_sz),
+    ]
+
+
+class AttnFwdArgs(C.Structure):
+    _fields_ = [
+        ("Q", c_vp), ("K", c_vp), ("V", c_vp), ("O", c_vp), ("LSE", c_vp), ("raw_logits", c_vp),
+        ("q_ps", c_i64), ("q_hs", c_i64), ("q_rs", c_i64),
+        ("k_ps", c_i64), ("k_hs", c_i64), ("k_rs", c_i64),
+        ("v_ps", c_i64), ("v_hs", c_i64), ("v_rs", c_i64),
+        ("o_ps", c_i64), ("o_hs", c_i64), ("o_rs", c_i64), ("o_ss", c_i64),
+        ("n_problems", c_i32), ("n_heads", c_i32), ("n_segments", c_i32), ("partner_shift", c_i32),
+        ("Lq", c_i32), ("Lk", c_i32), ("head_dim", c_i32), ("dtype", c_i32),
+        ("scale", c_f32),
+    ]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [
+        ("Q", c_vp), ("K", c_vp), ("V", c_vp), ("O", c_vp), ("dO", c_vp),
+        ("LSE", c_vp), ("Delta", c_vp),
+        ("dQ", c_vp), ("dK", c_vp), ("dV", c_vp),
+        ("q_ps", c_i64), ("q_hs", c_i64), ("q_rs", c_i64),
+        ("k_ps", c_i64), ("k_hs", c_i64), ("k_rs", c_i64),
+        ("v_ps", c_i64), ("v_hs", c_i64), ("v_rs", c_i64),
+        ("o_ps", c_i64), ("o_hs", c_i64), ("o_rs", c_i64), ("o_ss", c_i64),
+        ("do_ps", c_i64), ("do_hs", c_i64), ("do_rs", c_i64), ("do_ss", c_i64),
+        ("dq_ps", c_i64), ("dq_hs", c_i64), ("dq_rs", c_i64),
+        ("dk_ps", c_i64), ("dk_hs", c_i64), ("dk_rs", c_i64),
+        ("dv_ps", c_i64), ("dv_hs", c_i64), ("dv_rs", c_i64),
+        ("n_problems", c_i32), ("n_heads", c_i32), ("n_segments", c_i32), ("partner_shift", c_i32),
+        ("Lq", c_i32), ("Lk", c_i32), ("head_dim", c_i32), ("dtype", c_i32),
+        ("scale", c_f32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/druglamp_hip.h declares
+SIGNATURES = {
+    "dl_last_error": (C.c_char_p, []),
+    "dl_version": (c_i32, []),
+    "dl_gemm_workspace_bytes": (c_sz, [C.POINTER(GemmArgs)]),
+    "dl_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "dl_colsum": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_sz, c_vp]),
+    "dl_colsum_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "dl_layernorm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_f32, c_i32, c_vp]),
+    "dl_layernorm_bwd_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "dl_layernorm_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
+                                 c_i32, c_i64, c_i64, c_i32, c_vp, c_sz, c_vp]),
+    "dl_attn_fwd": (c_i32, [C.POINTER(AttnFwdArgs), c_vp]),
+    "dl_attn_bwd": (c_i32, [C.POINTER(AttnBwdArgs), c_vp]),
+    "dl_token_gate_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "dl_token_gate_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "dl_add_rowmod_dropout": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_u64, c_i32, c_vp]),
+    "dl_dropout_apply": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_u64, c_i32, c_vp]),
+    "dl_cast": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i64, c_vp]),
+    "dl_rowmod_sum": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
+    "dl_cos_rowloss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "dl_cos_rowloss_bwd": (c_i32, [c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp]),
+    "dl_ntxent_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "dl_ntxent_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "dl_ntxent_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_f32, c_vp, c_vp, c_vp]),
+    "dl_triplet_sigcos_buffer_floats": (c_sz, [c_i64, c_i64]),
+    "dl_triplet_sigcos_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    "dl_triplet_sigcos_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_vp, c_f32, c_vp, c_vp, c_vp]),
+    "dl_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32, c_vp,
+                              c_i32, c_vp]),
+    "dl_prof_enable": (c_i32, [c_i32, c_i32]),
+    "dl_prof_collect": (c_i32, [c_i32, C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built — there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libdruglamp_hip.so is missing (%s). Build it with `python -m druglamp_amd.build`; "
+                "the HIP hot path has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().dl_last_error()
+        raise RuntimeError("druglamp_hip %s failed (status %d): %s" % (what, rc, msg.decode() if msg else "?"))

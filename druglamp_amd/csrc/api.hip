@@ -1,0 +1,82 @@
+// api.hip — error reporting, version, per-kernel-family timing hooks.
+#include <stdarg.h>
+#include <stdio.h>
+#include <mutex>
+#include <vector>
+#include "common.cuh"
+
+namespace {
+thread_local char g_err[512] = "";
+
+struct ProfRec { hipEvent_t a, b; double flops, bytes; };
+struct ProfFamily {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  hipEvent_t pending = nullptr;
+};
+constexpr int NFAM = 8;
+ProfFamily g_prof[NFAM];
+std::mutex g_prof_mu;
+}  // namespace
+
+extern "C" void dl_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* dl_last_error(void) { return g_err; }
+extern "C" int dl_version(void) { return 100; }
+
+void dl_prof_before(int family, hipStream_t s) {
+  if (family < 0 || family >= NFAM || !g_prof[family].on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  g_prof[family].pending = e;
+}
+
+void dl_prof_after(int family, hipStream_t s, double flops, double bytes) {
+  if (family < 0 || family >= NFAM || !g_prof[family].on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfFamily& f = g_prof[family];
+  if (!f.pending) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  f.recs.push_back(ProfRec{f.pending, e, flops, bytes});
+  f.pending = nullptr;
+}
+
+extern "C" int dl_prof_enable(int32_t family, int32_t on) {
+  DL_CHECK_ARG(family >= 0 && family < NFAM, DL_ERR_ARG, "dl_prof_enable: bad family %d", family);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfFamily& f = g_prof[family];
+  for (auto& r : f.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  f.recs.clear();
+  if (f.pending) { (void)hipEventDestroy(f.pending); f.pending = nullptr; }
+  f.on = on != 0;
+  return DL_OK;
+}
+
+extern "C" int dl_prof_collect(int32_t family, int64_t* launches, double* total_ms, double* total_flops,
+                               double* total_bytes) {
+  DL_CHECK_ARG(family >= 0 && family < NFAM, DL_ERR_ARG, "dl_prof_collect: bad family %d", family);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfFamily& f = g_prof[family];
+  double ms = 0, fl = 0, by = 0;
+  int64_t n = 0;
+  for (auto& r : f.recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    ms += t; fl += r.flops; by += r.bytes; ++n;
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (total_bytes) *total_bytes = by;
+  return DL_OK;
+}

@@ -1,0 +1,220 @@
+// common.cuh — shared device/host helpers for libdruglamp_hip (gfx950 only).
+//
+// MFMA conventions used by every matrix kernel in this library
+// -----------------------------------------------------------
+// One "fragment" is a 16-byte packet per lane (u32x4).  For a 16x16 MFMA tile
+//     D[i][j] = sum_k A[i][k] * B[k][j]
+// lane l = (il = l & 15, g = l >> 4) supplies A[il][slots of g] and B[slots of g][il] and
+// receives D[4g + r][il] in accumulator register r (r = 0..3).
+//   bf16: one fragment = 8 bf16 = the 8 contraction slots of lane-group g of ONE
+//         v_mfma_f32_16x16x32_bf16 (KF = 32 contraction indices per fragment).
+//   f32 : one fragment = 4 floats = one slot each of FOUR v_mfma_f32_16x16x4_f32
+//         (KF = 16 contraction indices per fragment); exact fp32 (fmaf chain).
+// The hardware multiplies slot s of group g of A with slot s of group g of B, so any slot ->
+// contraction-index map is legal as long as both operands use the same one.  Two maps occur:
+//   CONTIG: slot (g, s) <-> index g*(KF/4) + s        (operand read with K contiguous)
+//   CTILE : slot (g, s) <-> index 16*(s/4) + 4g + s%4 (operand taken from accumulator tiles,
+//           where lane (il, g) holds rows 4g..4g+3 of each 16-row tile)
+// For f32 the two maps coincide.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/druglamp_hip.h"
+
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define DL_LDS __attribute__((address_space(3)))
+
+extern "C" void dl_set_error(const char* fmt, ...);
+// profiling hooks (api.hip)
+void dl_prof_before(int family, hipStream_t s);
+void dl_prof_after(int family, hipStream_t s, double flops, double bytes);
+
+#define DL_CHECK_ARG(cond, code, ...)                 \
+  do {                                                \
+    if (!(cond)) {                                    \
+      dl_set_error(__VA_ARGS__);                      \
+      return (code);                                  \
+    }                                                 \
+  } while (0)
+
+#define DL_CHECK_LAUNCH(what)                                               \
+  do {                                                                      \
+    hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) {                                                 \
+      dl_set_error("%s: launch failed: %s", what, hipGetErrorString(e_));   \
+      return DL_ERR_LAUNCH;                                                 \
+    }                                                                       \
+  } while (0)
+
+template <typename T> struct DTypeOf;
+template <> struct DTypeOf<float> { static constexpr int value = DL_F32; };
+template <> struct DTypeOf<bf16_t> { static constexpr int value = DL_BF16; };
+
+static inline size_t dl_dtype_size(int dt) { return dt == DL_BF16 ? 2 : 4; }
+
+// ---- scalar conversions ---------------------------------------------------------------
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (bf16_t)lo;
+  v[1] = (bf16_t)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) {
+  return __builtin_bit_cast(float, w & 0xffff0000u);
+}
+
+// 4 consecutive elements of T <-> f32x4 (global memory, vector access)
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) {
+  return *reinterpret_cast<const f32x4*>(p);
+}
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+  u32x2 w = *reinterpret_cast<const u32x2*>(p);
+  f32x4 r = {bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
+  return r;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) {
+  *reinterpret_cast<f32x4*>(p) = v;
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
+  u32x2 w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  *reinterpret_cast<u32x2*>(p) = w;
+}
+
+// ---- MFMA wrappers ----------------------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int KF = 32;  // contraction indices per fragment
+  static constexpr int EPC = 8;  // elements per 16-byte chunk
+  __device__ static __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KF = 16;
+  static constexpr int EPC = 4;
+  __device__ static __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    // NOTE: written out element by element on f32x4 views — indexing the u32x4 inside an unrolled loop
+    // and bit-casting each lane value made hipcc (ROCm 7.2) feed element 0 to all four MFMAs.
+    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], c, 0, 0, 0);
+    return c;
+  }
+};
+
+// Accumulator tiles -> fragment in the CTILE slot map.
+//   bf16: two 16-row tiles (t0: indices 0..15, t1: 16..31) -> 8 bf16
+//   f32 : one 16-row tile -> 4 floats
+__device__ __forceinline__ u32x4 ctile_frag_bf16(f32x4 t0, f32x4 t1) {
+  u32x4 r = {pack_bf16x2(t0[0], t0[1]), pack_bf16x2(t0[2], t0[3]), pack_bf16x2(t1[0], t1[1]),
+             pack_bf16x2(t1[2], t1[3])};
+  return r;
+}
+__device__ __forceinline__ u32x4 ctile_frag_f32(f32x4 t0) { return __builtin_bit_cast(u32x4, t0); }
+
+// ---- LDS access -------------------------------------------------------------------------
+__device__ __forceinline__ u32x4 lds_read16(const char* base, uint32_t byte_off) {
+  return *reinterpret_cast<const u32x4*>(base + byte_off);
+}
+__device__ __forceinline__ void lds_write16(char* base, uint32_t byte_off, u32x4 v) {
+  *reinterpret_cast<u32x4*>(base + byte_off) = v;
+}
+__device__ __forceinline__ float lds_read_f32(const char* base, uint32_t byte_off) {
+  return *reinterpret_cast<const float*>(base + byte_off);
+}
+// ds_read_b64_tr_b16: within each 16-lane group, lane t supplies the address of 4 contiguous
+// bf16 belonging to row (t>>2), column chunk (t&3) of a [4][16] block; lane t receives column t
+// of that block (rows 0..3).  Row placement is free (each lane has its own address).
+__device__ __forceinline__ u32x2 lds_read_tr16(const char* base, uint32_t byte_off) {
+  bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+      (DL_LDS bf16x4*)(base + byte_off));
+  return __builtin_bit_cast(u32x2, v);
+}
+
+// ---- wave reductions (64 lanes) -----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// reduce across the 4 lane groups (lanes il, il+16, il+32, il+48)
+__device__ __forceinline__ float group4_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float group4_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+// ---- math ---------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- dropout RNG: splitmix64 keyed by (seed, group index); one draw serves 4 consecutive
+// elements (16 bits each).  keep[j] = bits16[j] >= thr16 with thr16 = round(p * 65536).
+__device__ __forceinline__ uint64_t dl_splitmix(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint32_t dl_dropout_thr16(float p) {
+  float t = p * 65536.0f + 0.5f;
+  return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)t);
+}
+// element (row, col) of a logical [rows][ncols] tensor, col % 4 == 0: returns 4 keep flags scaled
+__device__ __forceinline__ f32x4 dl_dropout4(f32x4 v, uint64_t seed, uint64_t row, uint64_t col,
+                                             uint64_t ncols, uint32_t thr16, float inv_keep) {
+  const uint64_t bits = dl_splitmix(seed, (row * ncols + col) >> 2);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t b = (uint32_t)(bits >> (16 * j)) & 0xffffu;
+    v[j] = (b >= thr16) ? v[j] * inv_keep : 0.0f;
+  }
+  return v;
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks that are consecutive in the LOGICAL
+// order land on the same XCD (observed placement: physical block b runs on XCD b % 8).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblocks) {
+  const uint32_t nx = 8;
+  if (nblocks < nx) return bid;
+  const uint32_t q = nblocks / nx, r = nblocks % nx;
+  const uint32_t xcd = bid % nx, loc = bid / nx;
+  const uint32_t start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + loc;
+}

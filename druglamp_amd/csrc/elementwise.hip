@@ -1,0 +1,290 @@
+// elementwise.hip — HBM-bound helpers on the path: MHLA token gate, positional add + dropout,
+// dropout re-application, casts, positional-table gradient, fused AdamW.
+#include <math.h>
+#include "common.cuh"
+
+namespace {
+
+// ---------------- MHLA token gate -------------------------------------------------------------
+// gate[b][j][l] = softmax_l(logits[b][l][j]); one wave per (b, j).
+template <typename T>
+__global__ void gate_softmax_kernel(const T* __restrict__ logits, float* __restrict__ gate, int L, int H) {
+  const int bj = blockIdx.x, b = bj / H, j = bj % H, lane = threadIdx.x;
+  const T* src = logits + (int64_t)b * L * H + j;
+  float mx = -INFINITY;
+  for (int l = lane; l < L; l += 64) mx = fmaxf(mx, to_f32(src[(int64_t)l * H]));
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int l = lane; l < L; l += 64) sum += __expf(to_f32(src[(int64_t)l * H]) - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  float* dst = gate + (int64_t)bj * L;
+  for (int l = lane; l < L; l += 64) dst[l] = __expf(to_f32(src[(int64_t)l * H]) - mx) * inv;
+}
+
+// out[b][f] = v[b][f] * (gate_flat[b][f / hd] + res)
+template <typename T>
+__global__ void gate_apply_kernel(const T* __restrict__ v, const float* __restrict__ gate, T* __restrict__ out,
+                                  int64_t n4, int64_t per_sample, int hd, int64_t gate_per_sample, float res) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int64_t e = i * 4;
+  const int64_t b = e / per_sample, f = e % per_sample;
+  const float gv = gate[b * gate_per_sample + f / hd] + res;
+  f32x4 x = load4<T>(v + e);
+  x *= gv;
+  store4<T>(out + e, x);
+}
+
+// one wave per (b, j): dv = dout * (g + res); dgate = sum_c dout*v; dlogits = g * (dgate - sum_l g*dgate)
+template <typename T>
+__global__ void gate_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ v, const float* __restrict__ gate,
+                                T* __restrict__ dv, T* __restrict__ dlogits, int L, int H, int hd, float res) {
+  extern __shared__ float dg_s[];
+  const int bj = blockIdx.x, b = bj / H, j = bj % H, lane = threadIdx.x;
+  const int64_t base = ((int64_t)b * H + j) * L * hd;  // flat offset of this (b, j) slab of L*hd elements
+  const float* g = gate + (int64_t)bj * L;
+  float dot = 0.f;
+  for (int l = lane; l < L; l += 64) {
+    const float gl = g[l];
+    float acc = 0.f;
+    for (int c = 0; c < hd; c += 4) {
+      const int64_t e = base + (int64_t)l * hd + c;
+      const f32x4 d4 = load4<T>(dout + e), v4 = load4<T>(v + e);
+      acc += d4[0] * v4[0] + d4[1] * v4[1] + d4[2] * v4[2] + d4[3] * v4[3];
+      store4<T>(dv + e, d4 * (gl + res));
+    }
+    dg_s[l] = acc;
+    dot += gl * acc;
+  }
+  dot = wave_sum(dot);
+  __syncthreads();
+  T* dst = dlogits + (int64_t)b * L * H + j;
+  for (int l = lane; l < L; l += 64) dst[(int64_t)l * H] = from_f32<T>(g[l] * (dg_s[l] - dot));
+}
+
+// ---------------- positional add + dropout / dropout apply -------------------------------------
+template <typename T>
+__global__ void add_rowmod_dropout_kernel(const T* __restrict__ x, const T* __restrict__ pe, T* __restrict__ y,
+                                          int64_t M, int D, int64_t L, uint32_t thr16, float inv_keep,
+                                          uint64_t seed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n4 = M * (D / 4);
+  if (i >= n4) return;
+  const int64_t row = i / (D / 4);
+  const int col = (int)(i % (D / 4)) * 4;
+  f32x4 v = load4<T>(x + row * D + col);
+  if (pe) v += load4<T>(pe + (row % L) * D + col);
+  if (thr16) v = dl_dropout4(v, seed, (uint64_t)row, (uint64_t)col, (uint64_t)D, thr16, inv_keep);
+  store4<T>(y + row * D + col, v);
+}
+
+template <typename T>
+__global__ void dropout_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int D, int64_t ldx,
+                                     int64_t ldy, uint32_t thr16, float inv_keep, uint64_t seed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n4 = rows * (D / 4);
+  if (i >= n4) return;
+  const int64_t row = i / (D / 4);
+  const int col = (int)(i % (D / 4)) * 4;
+  f32x4 v = load4<T>(x + row * ldx + col);
+  v = dl_dropout4(v, seed, (uint64_t)row, (uint64_t)col, (uint64_t)D, thr16, inv_keep);
+  store4<T>(y + row * ldy + col, v);
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 4 <= n) {
+    store4<TD>(dst + i4, load4<TS>(src + i4));
+  } else {
+    for (int64_t i = i4; i < n; ++i) dst[i] = from_f32<TD>(to_f32(src[i]));
+  }
+}
+
+// out[l][d] (+)= sum_b x[(b*L + l)][d]
+template <typename T>
+__global__ void rowmod_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int D, int64_t L,
+                                  int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n4 = L * (D / 4);
+  if (i >= n4) return;
+  const int64_t l = i / (D / 4);
+  const int col = (int)(i % (D / 4)) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t row = l; row < M; row += L) s += load4<T>(x + row * D + col);
+  float* dst = out + l * D + col;
+  if (accumulate) s += *reinterpret_cast<const f32x4*>(dst);
+  *reinterpret_cast<f32x4*>(dst) = s;
+}
+
+// ---------------- AdamW --------------------------------------------------------------------------
+template <typename TL>
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2_sqrt, float gscale, TL* __restrict__ lowp) {
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const int cnt = (int)min((int64_t)4, n - i4);
+  float pp[4], gg[4], mm[4], vv[4];
+  if (cnt == 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p + i4), b = *reinterpret_cast<const f32x4*>(g + i4);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(m + i4), d = *reinterpret_cast<const f32x4*>(v + i4);
+    for (int j = 0; j < 4; ++j) { pp[j] = a[j]; gg[j] = b[j]; mm[j] = c[j]; vv[j] = d[j]; }
+  } else {
+    for (int j = 0; j < cnt; ++j) { pp[j] = p[i4 + j]; gg[j] = g[i4 + j]; mm[j] = m[i4 + j]; vv[j] = v[i4 + j]; }
+  }
+  for (int j = 0; j < cnt; ++j) {
+    const float grad = gg[j] * gscale;
+    float x = pp[j] * (1.0f - lr * wd);                    // decoupled weight decay
+    mm[j] = b1 * mm[j] + (1.0f - b1) * grad;               // torch: lerp / mul-add
+    vv[j] = b2 * vv[j] + (1.0f - b2) * grad * grad;
+    const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+    x -= (lr / bc1) * (mm[j] / denom);
+    pp[j] = x;
+  }
+  if (cnt == 4) {
+    *reinterpret_cast<f32x4*>(p + i4) = f32x4{pp[0], pp[1], pp[2], pp[3]};
+    *reinterpret_cast<f32x4*>(m + i4) = f32x4{mm[0], mm[1], mm[2], mm[3]};
+    *reinterpret_cast<f32x4*>(v + i4) = f32x4{vv[0], vv[1], vv[2], vv[3]};
+    if (lowp) store4<TL>(lowp + i4, f32x4{pp[0], pp[1], pp[2], pp[3]});
+  } else {
+    for (int j = 0; j < cnt; ++j) {
+      p[i4 + j] = pp[j]; m[i4 + j] = mm[j]; v[i4 + j] = vv[j];
+      if (lowp) lowp[i4 + j] = from_f32<TL>(pp[j]);
+    }
+  }
+}
+
+inline uint32_t nblk(int64_t n, int t = 256) { return (uint32_t)((n + t - 1) / t); }
+}  // namespace
+
+extern "C" int dl_token_gate_fwd(const void* v, const void* logits, void* out, float* gate_out, int64_t B,
+                                 int64_t L, int64_t D, int32_t H, int32_t add_residual, int32_t dtype,
+                                 dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(v && logits && out && gate_out, DL_ERR_ARG, "dl_token_gate_fwd: null pointer");
+  DL_CHECK_ARG(B > 0 && L > 0 && H > 0 && D % H == 0 && (D / H) % 4 == 0, DL_ERR_SHAPE,
+               "dl_token_gate_fwd: need D %% H == 0 and (D/H) %% 4 == 0");
+  const int hd = (int)(D / H);
+  const int64_t n4 = B * L * D / 4;
+  if (dtype == DL_BF16) {
+    hipLaunchKernelGGL((gate_softmax_kernel<bf16_t>), dim3((uint32_t)(B * H)), dim3(64), 0, s,
+                       (const bf16_t*)logits, gate_out, (int)L, (int)H);
+    hipLaunchKernelGGL((gate_apply_kernel<bf16_t>), dim3(nblk(n4)), dim3(256), 0, s, (const bf16_t*)v, gate_out,
+                       (bf16_t*)out, n4, L * D, hd, (int64_t)H * L, add_residual ? 1.0f : 0.0f);
+  } else {
+    hipLaunchKernelGGL((gate_softmax_kernel<float>), dim3((uint32_t)(B * H)), dim3(64), 0, s,
+                       (const float*)logits, gate_out, (int)L, (int)H);
+    hipLaunchKernelGGL((gate_apply_kernel<float>), dim3(nblk(n4)), dim3(256), 0, s, (const float*)v, gate_out,
+                       (float*)out, n4, L * D, hd, (int64_t)H * L, add_residual ? 1.0f : 0.0f);
+  }
+  DL_CHECK_LAUNCH("dl_token_gate_fwd");
+  return DL_OK;
+}
+
+extern "C" int dl_token_gate_bwd(const void* dout, const void* v, const float* gate, void* dv, void* dlogits,
+                                 int64_t B, int64_t L, int64_t D, int32_t H, int32_t add_residual, int32_t dtype,
+                                 dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(dout && v && gate && dv && dlogits, DL_ERR_ARG, "dl_token_gate_bwd: null pointer");
+  DL_CHECK_ARG(B > 0 && L > 0 && H > 0 && D % H == 0 && (D / H) % 4 == 0 && L <= 12288, DL_ERR_SHAPE,
+               "dl_token_gate_bwd: bad shape");
+  const int hd = (int)(D / H);
+  const float res = add_residual ? 1.0f : 0.0f;
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((gate_bwd_kernel<bf16_t>), dim3((uint32_t)(B * H)), dim3(64), (size_t)L * 4, s,
+                       (const bf16_t*)dout, (const bf16_t*)v, gate, (bf16_t*)dv, (bf16_t*)dlogits, (int)L, (int)H,
+                       hd, res);
+  else
+    hipLaunchKernelGGL((gate_bwd_kernel<float>), dim3((uint32_t)(B * H)), dim3(64), (size_t)L * 4, s,
+                       (const float*)dout, (const float*)v, gate, (float*)dv, (float*)dlogits, (int)L, (int)H, hd,
+                       res);
+  DL_CHECK_LAUNCH("dl_token_gate_bwd");
+  return DL_OK;
+}
+
+extern "C" int dl_add_rowmod_dropout(const void* x, const void* pe, void* y, int64_t M, int64_t D, int64_t L,
+                                     float p, uint64_t seed, int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(x && y && M > 0 && D > 0 && D % 4 == 0 && L > 0, DL_ERR_ARG, "dl_add_rowmod_dropout: bad args");
+  DL_CHECK_ARG(p >= 0.f && p < 1.f, DL_ERR_ARG, "dl_add_rowmod_dropout: bad p");
+  const uint32_t thr = p > 0.f ? dl_dropout_thr16(p) : 0u;
+  const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  const int64_t n4 = M * D / 4;
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((add_rowmod_dropout_kernel<bf16_t>), dim3(nblk(n4)), dim3(256), 0, s, (const bf16_t*)x,
+                       (const bf16_t*)pe, (bf16_t*)y, M, (int)D, L, thr, inv, seed);
+  else
+    hipLaunchKernelGGL((add_rowmod_dropout_kernel<float>), dim3(nblk(n4)), dim3(256), 0, s, (const float*)x,
+                       (const float*)pe, (float*)y, M, (int)D, L, thr, inv, seed);
+  DL_CHECK_LAUNCH("dl_add_rowmod_dropout");
+  return DL_OK;
+}
+
+extern "C" int dl_dropout_apply(const void* x, void* y, int64_t n_rows, int64_t D, int64_t ldx, int64_t ldy,
+                                float p, uint64_t seed, int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(x && y && n_rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, DL_ERR_ARG,
+               "dl_dropout_apply: bad args");
+  DL_CHECK_ARG(p > 0.f && p < 1.f, DL_ERR_ARG, "dl_dropout_apply: p must be in (0,1)");
+  const int64_t n4 = n_rows * D / 4;
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((dropout_apply_kernel<bf16_t>), dim3(nblk(n4)), dim3(256), 0, s, (const bf16_t*)x,
+                       (bf16_t*)y, n_rows, (int)D, ldx, ldy, dl_dropout_thr16(p), 1.0f / (1.0f - p), seed);
+  else
+    hipLaunchKernelGGL((dropout_apply_kernel<float>), dim3(nblk(n4)), dim3(256), 0, s, (const float*)x, (float*)y,
+                       n_rows, (int)D, ldx, ldy, dl_dropout_thr16(p), 1.0f / (1.0f - p), seed);
+  DL_CHECK_LAUNCH("dl_dropout_apply");
+  return DL_OK;
+}
+
+extern "C" int dl_cast(const void* src, int32_t sdt, void* dst, int32_t ddt, int64_t n, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(src && dst && n > 0, DL_ERR_ARG, "dl_cast: bad args");
+  const uint32_t blocks = nblk((n + 3) / 4);
+  if (sdt == DL_F32 && ddt == DL_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
+  else if (sdt == DL_BF16 && ddt == DL_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
+  else if (sdt == DL_F32 && ddt == DL_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+  else if (sdt == DL_BF16 && ddt == DL_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+  else { dl_set_error("dl_cast: bad dtypes"); return DL_ERR_ARG; }
+  DL_CHECK_LAUNCH("dl_cast");
+  return DL_OK;
+}
+
+extern "C" int dl_rowmod_sum(const void* x, float* out, int64_t M, int64_t D, int64_t L, int32_t accumulate,
+                             int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(x && out && M > 0 && D > 0 && D % 4 == 0 && L > 0 && M % L == 0, DL_ERR_ARG, "dl_rowmod_sum: bad args");
+  const int64_t n4 = L * D / 4;
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((rowmod_sum_kernel<bf16_t>), dim3(nblk(n4, 64)), dim3(64), 0, s, (const bf16_t*)x, out, M,
+                       (int)D, L, accumulate);
+  else
+    hipLaunchKernelGGL((rowmod_sum_kernel<float>), dim3(nblk(n4, 64)), dim3(64), 0, s, (const float*)x, out, M,
+                       (int)D, L, accumulate);
+  DL_CHECK_LAUNCH("dl_rowmod_sum");
+  return DL_OK;
+}
+
+extern "C" int dl_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                             float grad_scale, void* param_lowp, int32_t lowp_dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, DL_ERR_ARG, "dl_adamw_step: bad args");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  const uint32_t blocks = nblk((n + 3) / 4);
+  if (param_lowp && lowp_dtype == DL_BF16)
+    hipLaunchKernelGGL((adamw_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, (bf16_t*)param_lowp);
+  else
+    hipLaunchKernelGGL((adamw_kernel<float>), dim3(blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, (float*)param_lowp);
+  DL_CHECK_LAUNCH("dl_adamw_step");
+  return DL_OK;
+}

@@ -1,0 +1,459 @@
+// gemm.hip — dl_gemm / dl_colsum: MFMA GEMM with fused epilogues (see include/druglamp_hip.h).
+//
+// Tiling: 128(m) x 128(n) output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
+// 4x4 MFMA 16x16 tiles), contraction consumed 128 BYTES per operand row per step (64 bf16 /
+// 32 f32), two LDS buffers, global->register->LDS staging with the next tile's global loads in
+// flight under the current tile's MFMAs.  Operand tiles in LDS:
+//   K-contiguous operand: [128 rows][128 B], 16-byte chunks XOR-swizzled by (row & 7) so that the
+//     ds_read_b128 fragment reads of 16 consecutive rows spread over 8 slots.
+//   K-slow operand (contraction index is the slow memory dim: dgrad weights, both wgrad
+//     operands): [k rows][128 elems] with a padded pitch, fragments by ds_read_b64_tr_b16
+//     (bf16) or 4 x ds_read_b32 (f32) — the hardware transpose read.
+// The MFMA is issued "swapped" (A = W fragment, B = X fragment) so each lane ends up holding 4
+// CONSECUTIVE output columns of one output row: 8-byte (bf16) / 16-byte (f32) stores.
+#include "common.cuh"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BKB = 128;  // BKB: bytes of contraction per operand row per step
+constexpr int NTHREADS = 256;
+
+template <typename T> struct TileGeom {
+  static constexpr int BKE = BKB / (int)sizeof(T);                 // contraction elems per step
+  static constexpr int PITCH_KSLOW = 128 * (int)sizeof(T) + 32;     // bytes per k-row (padded)
+  static constexpr int TILE_KCONTIG = 128 * BKB;                    // 16384
+  static constexpr int TILE_KSLOW = BKE * PITCH_KSLOW;              // 18432 (bf16) / 17408 (f32)
+  static constexpr int TILE_BYTES = TILE_KSLOW > TILE_KCONTIG ? TILE_KSLOW : TILE_KCONTIG;
+};
+
+struct GemmP {
+  const char* X; const char* W; char* C;
+  int64_t ldx, ldw, ldc;
+  int M, N, K, k_per_split, mt, nt, splits;
+  const float* bias;
+  const char* res; int64_t ldr; int res_row_mod; int res_before_dropout;
+  int act;
+  char* pre_out; int64_t ldp;
+  const char* dact_pre; int64_t lddp;
+  uint32_t drop_thr16; float drop_inv_keep; uint64_t seed;
+  int accumulate;
+  float* slabs;   // split mode: [splits][M][N] f32
+};
+
+// ---- global -> registers (4 chunks of 16 B per thread per operand) ------------------------
+template <typename T, bool KSLOW>
+__device__ __forceinline__ void load_tile(const char* base, int64_t ld, int row0, int nrows, int k0,
+                                          int kend, u32x4 (&r)[4]) {
+  constexpr int EPC = Mma<T>::EPC;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * NTHREADS;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if constexpr (!KSLOW) {
+      const int row = c >> 3, kc = c & 7;
+      const int gr = row0 + row, gk = k0 + kc * EPC;
+      if (gr < nrows && gk < kend)
+        v = *reinterpret_cast<const u32x4*>(base + ((int64_t)gr * ld + gk) * (int64_t)sizeof(T));
+    } else {
+      constexpr int CPR = 128 / EPC;  // chunks per k-row
+      const int krow = c / CPR, cc = c % CPR;
+      const int gk = k0 + krow, gr = row0 + cc * EPC;
+      if (gk < kend && gr < nrows)
+        v = *reinterpret_cast<const u32x4*>(base + ((int64_t)gk * ld + gr) * (int64_t)sizeof(T));
+    }
+    r[i] = v;
+  }
+}
+
+template <typename T, bool KSLOW>
+__device__ __forceinline__ void store_tile(char* lds, const u32x4 (&r)[4]) {
+  constexpr int EPC = Mma<T>::EPC;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * NTHREADS;
+    if constexpr (!KSLOW) {
+      const int row = c >> 3, kc = c & 7;
+      lds_write16(lds, row * BKB + ((kc ^ (row & 7)) << 4), r[i]);
+    } else {
+      constexpr int CPR = 128 / EPC;
+      const int krow = c / CPR, cc = c % CPR;
+      lds_write16(lds, krow * TileGeom<T>::PITCH_KSLOW + cc * 16, r[i]);
+    }
+  }
+}
+
+// fragment for 16 tile rows starting at rb, fragment index kf within the step
+template <typename T, bool KSLOW>
+__device__ __forceinline__ u32x4 read_frag(const char* lds, int rb, int kf, int il, int g) {
+  if constexpr (!KSLOW) {
+    const int row = rb + il;
+    return lds_read16(lds, row * BKB + (((kf * 4 + g) ^ (row & 7)) << 4));
+  } else if constexpr (sizeof(T) == 2) {
+    constexpr int P = TileGeom<T>::PITCH_KSLOW;
+    const int kidx = kf * 32 + g * 8 + (il >> 2);
+    const int col = rb + (il & 3) * 4;
+    const u32x2 a = lds_read_tr16(lds, kidx * P + col * 2);
+    const u32x2 b = lds_read_tr16(lds, (kidx + 4) * P + col * 2);
+    u32x4 r = {a[0], a[1], b[0], b[1]};
+    return r;
+  } else {
+    constexpr int P = TileGeom<T>::PITCH_KSLOW;
+    const int kidx = kf * 16 + g * 4;
+    const int col = rb + il;
+    u32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      r[j] = __builtin_bit_cast(uint32_t, lds_read_f32(lds, (kidx + j) * P + col * 4));
+    return r;
+  }
+}
+
+template <typename T, typename TO, bool XS, bool WS, bool SPLIT>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
+  constexpr int BKE = TileGeom<T>::BKE;
+  constexpr int NFRAG = BKE / Mma<T>::KF;
+  constexpr int TB = TileGeom<T>::TILE_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TB];
+
+  const uint32_t nblocks = (uint32_t)p.mt * p.nt * p.splits;
+  const uint32_t t = xcd_remap(blockIdx.x, nblocks);
+  const int split = t / (p.mt * p.nt);
+  const int tile = t % (p.mt * p.nt);
+  const int m0 = (tile / p.nt) * BM, n0 = (tile % p.nt) * BN;
+  const int kbeg = split * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 rx[4], rw[4];
+  const int nk = (kend - kbeg + BKE - 1) / BKE;
+  if (nk > 0) {
+    load_tile<T, XS>(p.X, p.ldx, m0, p.M, kbeg, kend, rx);
+    load_tile<T, WS>(p.W, p.ldw, n0, p.N, kbeg, kend, rw);
+    store_tile<T, XS>(smem, rx);
+    store_tile<T, WS>(smem + TB, rw);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = smem + (kt & 1) * 2 * TB;
+    char* nxt = smem + ((kt + 1) & 1) * 2 * TB;
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      load_tile<T, XS>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, kend, rx);
+      load_tile<T, WS>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, kend, rw);
+    }
+#pragma unroll
+    for (int kf = 0; kf < NFRAG; ++kf) {
+      u32x4 fx[4], fw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fx[i] = read_frag<T, XS>(cur, wm * 64 + i * 16, kf, il, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fw[j] = read_frag<T, WS>(cur + TB, wn * 64 + j * 16, kf, il, g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(fw[j], fx[i], acc[i][j]);
+    }
+    if (more) {
+      store_tile<T, XS>(nxt, rx);
+      store_tile<T, WS>(nxt + TB, rw);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m = .. + il][n = .. + 4g .. 4g+3] ---------------------------
+  const bool vec_ok = (p.N & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + il;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * g;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if constexpr (SPLIT) {
+        float* dst = p.slabs + ((int64_t)split * p.M + m) * p.N + n;
+        if (vec_ok) *reinterpret_cast<f32x4*>(dst) = v;
+        else
+          for (int r = 0; r < 4 && n + r < p.N; ++r) dst[r] = v[r];
+      } else {
+        const int nvalid = min(4, p.N - n);
+        if (p.bias) {
+          if (nvalid == 4) { const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n); v += b; }
+          else for (int r = 0; r < nvalid; ++r) v[r] += p.bias[n + r];
+        }
+        if (p.pre_out) {
+          T* dst = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
+          if (nvalid == 4 && vec_ok) store4<T>(dst, v);
+          else for (int r = 0; r < nvalid; ++r) dst[r] = from_f32<T>(v[r]);
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        }
+        if (p.dact_pre) {
+          const T* src = reinterpret_cast<const T*>(p.dact_pre) + (int64_t)m * p.lddp + n;
+          f32x4 pre = {0.f, 0.f, 0.f, 0.f};
+          if (nvalid == 4 && vec_ok) pre = load4<T>(src);
+          else for (int r = 0; r < nvalid; ++r) pre[r] = to_f32(src[r]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(pre[r]);
+        }
+        f32x4 resv = {0.f, 0.f, 0.f, 0.f};
+        if (p.res) {
+          const int rr = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+          const T* src = reinterpret_cast<const T*>(p.res) + (int64_t)rr * p.ldr + n;
+          if (nvalid == 4 && vec_ok) resv = load4<T>(src);
+          else for (int r = 0; r < nvalid; ++r) resv[r] = to_f32(src[r]);
+          if (p.res_before_dropout) v += resv;
+        }
+        if (p.drop_thr16)
+          v = dl_dropout4(v, p.seed, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16,
+                          p.drop_inv_keep);
+        if (p.res && !p.res_before_dropout) v += resv;
+        TO* dst = reinterpret_cast<TO*>(p.C) + (int64_t)m * p.ldc + n;
+        if (p.accumulate) {
+          if (nvalid == 4 && vec_ok) { const f32x4 o = load4<TO>(dst); v += o; }
+          else for (int r = 0; r < nvalid; ++r) v[r] += to_f32(dst[r]);
+        }
+        if (nvalid == 4 && vec_ok) store4<TO>(dst, v);
+        else for (int r = 0; r < nvalid; ++r) dst[r] = from_f32<TO>(v[r]);
+      }
+    }
+  }
+}
+
+// out[idx] (+)= sum_z slabs[z][idx]
+template <typename TO>
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, TO* __restrict__ out,
+                                     int64_t mn, int64_t ldc, int N, int splits, int accumulate) {
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= mn) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i4);
+  for (int z = 1; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(slabs + (int64_t)z * mn + i4);
+  const int64_t m = i4 / N, n = i4 % N;
+  TO* dst = out + m * ldc + n;
+  if (accumulate) { const f32x4 o = load4<TO>(dst); s += o; }
+  store4<TO>(dst, s);
+}
+
+int auto_split(int64_t M, int64_t N, int64_t K, int bke) {
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if (tiles >= 192) return 1;
+  int64_t want = (512 + tiles - 1) / tiles;
+  int64_t ksteps = (K + bke - 1) / bke;
+  int64_t maxs = ksteps / 4;  // at least 4 k-steps per split
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want > 256) want = 256;
+  return (int)(want < 1 ? 1 : want);
+}
+
+int resolve_split(const dl_gemm_args* a) {
+  const int bke = BKB / (int)dl_dtype_size(a->in_dtype);
+  if (a->split_k > 0) return a->split_k;
+  if (a->split_k < 0) return 1;
+  // auto: only legal for plain f32 outputs
+  const bool plain = !a->bias && !a->residual && !a->act && !a->pre_out && !a->dact_pre &&
+                     a->dropout_p <= 0.f && a->out_dtype == DL_F32 && (a->N % 4 == 0);
+  return plain ? auto_split(a->M, a->N, a->K, bke) : 1;
+}
+
+template <typename T, typename TO, bool XS, bool WS, bool SPLIT>
+void launch(const GemmP& p, hipStream_t s) {
+  const uint32_t nblocks = (uint32_t)p.mt * p.nt * p.splits;
+  hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT>), dim3(nblocks), dim3(NTHREADS), 0, s, p);
+}
+
+template <typename T, typename TO, bool SPLIT>
+int dispatch_layout(const dl_gemm_args* a, const GemmP& p, hipStream_t s) {
+  if (!a->x_kslow && !a->w_kslow) launch<T, TO, false, false, SPLIT>(p, s);
+  else if (!a->x_kslow && a->w_kslow) launch<T, TO, false, true, SPLIT>(p, s);
+  else if (a->x_kslow && a->w_kslow) launch<T, TO, true, true, SPLIT>(p, s);
+  else {
+    dl_set_error("dl_gemm: layout x_kslow=1,w_kslow=0 is not instantiated");
+    return DL_ERR_UNSUPPORTED;
+  }
+  return DL_OK;
+}
+
+}  // namespace
+
+extern "C" size_t dl_gemm_workspace_bytes(const dl_gemm_args* a) {
+  if (!a) return 0;
+  const int sp = resolve_split(a);
+  return sp > 1 ? (size_t)sp * (size_t)a->M * (size_t)a->N * sizeof(float) : 0;
+}
+
+extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(a && a->X && a->W && a->C, DL_ERR_ARG, "dl_gemm: null operand");
+  DL_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, DL_ERR_SHAPE, "dl_gemm: bad shape M=%ld N=%ld K=%ld",
+               (long)a->M, (long)a->N, (long)a->K);
+  DL_CHECK_ARG(a->M < (1ll << 30) && a->N < (1ll << 30) && a->K < (1ll << 30), DL_ERR_SHAPE,
+               "dl_gemm: dims must fit int32");
+  DL_CHECK_ARG(a->in_dtype == DL_F32 || a->in_dtype == DL_BF16, DL_ERR_ARG, "dl_gemm: bad in_dtype");
+  DL_CHECK_ARG(a->out_dtype == DL_F32 || a->out_dtype == a->in_dtype, DL_ERR_ARG,
+               "dl_gemm: out_dtype must be f32 or in_dtype");
+  const int es = (int)dl_dtype_size(a->in_dtype);
+  const int epc = 16 / es;
+  // 16-byte chunk granularity along the contiguous dim of each operand
+  DL_CHECK_ARG(a->ldx % epc == 0 && a->ldw % epc == 0, DL_ERR_ALIGN,
+               "dl_gemm: ldx/ldw must be multiples of %d elements", epc);
+  DL_CHECK_ARG(((uintptr_t)a->X & 15) == 0 && ((uintptr_t)a->W & 15) == 0, DL_ERR_ALIGN,
+               "dl_gemm: X/W must be 16-byte aligned");
+  if (!a->x_kslow) DL_CHECK_ARG(a->K % epc == 0, DL_ERR_ALIGN, "dl_gemm: K %% %d != 0", epc);
+  else DL_CHECK_ARG(a->M % epc == 0, DL_ERR_ALIGN, "dl_gemm: M %% %d != 0 for k-slow X", epc);
+  if (!a->w_kslow) DL_CHECK_ARG(a->K % epc == 0, DL_ERR_ALIGN, "dl_gemm: K %% %d != 0", epc);
+  else DL_CHECK_ARG(a->N % epc == 0, DL_ERR_ALIGN, "dl_gemm: N %% %d != 0 for k-slow W", epc);
+  const int oes = (int)dl_dtype_size(a->out_dtype);
+  if (a->N % 4 == 0)
+    DL_CHECK_ARG(a->ldc % 4 == 0 && ((uintptr_t)a->C % (4 * oes)) == 0, DL_ERR_ALIGN,
+                 "dl_gemm: C / ldc not aligned for 4-wide stores");
+  DL_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, DL_ERR_ARG, "dl_gemm: dropout_p out of range");
+  DL_CHECK_ARG(a->dropout_p == 0.f || a->N % 4 == 0, DL_ERR_SHAPE, "dl_gemm: dropout needs N %% 4 == 0");
+
+  const int sp = resolve_split(a);
+  if (sp > 1) {
+    DL_CHECK_ARG(!a->bias && !a->residual && !a->act && !a->pre_out && !a->dact_pre &&
+                     a->dropout_p == 0.f && (a->N % 4 == 0),
+                 DL_ERR_UNSUPPORTED, "dl_gemm: split_k supports only the plain epilogue, N %% 4 == 0");
+    const size_t need = (size_t)sp * a->M * a->N * sizeof(float);
+    DL_CHECK_ARG(a->workspace && a->workspace_bytes >= need, DL_ERR_WORKSPACE,
+                 "dl_gemm: split_k=%d needs %zu workspace bytes, got %zu", sp, need, a->workspace_bytes);
+  }
+
+  GemmP p;
+  p.X = (const char*)a->X; p.W = (const char*)a->W; p.C = (char*)a->C;
+  p.ldx = a->ldx; p.ldw = a->ldw; p.ldc = a->ldc;
+  p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
+  p.mt = (int)((a->M + BM - 1) / BM); p.nt = (int)((a->N + BN - 1) / BN); p.splits = sp;
+  const int bke = BKB / es;
+  {
+    const int64_t ksteps = (a->K + bke - 1) / bke;
+    const int64_t per = (ksteps + sp - 1) / sp;
+    p.k_per_split = (int)(per * bke);
+  }
+  p.bias = a->bias;
+  p.res = (const char*)a->residual; p.ldr = a->ldr; p.res_row_mod = (int)a->res_row_mod;
+  p.res_before_dropout = a->res_before_dropout;
+  p.act = a->act;
+  p.pre_out = (char*)a->pre_out; p.ldp = a->ldp;
+  p.dact_pre = (const char*)a->dact_pre; p.lddp = a->lddp;
+  p.drop_thr16 = a->dropout_p > 0.f ? dl_dropout_thr16(a->dropout_p) : 0u;
+  p.drop_inv_keep = a->dropout_p > 0.f ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
+  p.seed = a->dropout_seed;
+  p.accumulate = a->accumulate;
+  p.slabs = (float*)a->workspace;
+
+  dl_prof_before(0, s);
+  int rc = DL_OK;
+  if (a->in_dtype == DL_BF16) {
+    if (sp > 1) rc = dispatch_layout<bf16_t, float, true>(a, p, s);
+    else if (a->out_dtype == DL_F32) rc = dispatch_layout<bf16_t, float, false>(a, p, s);
+    else rc = dispatch_layout<bf16_t, bf16_t, false>(a, p, s);
+  } else {
+    if (sp > 1) rc = dispatch_layout<float, float, true>(a, p, s);
+    else rc = dispatch_layout<float, float, false>(a, p, s);
+  }
+  if (rc != DL_OK) return rc;
+  DL_CHECK_LAUNCH("dl_gemm");
+  if (sp > 1) {
+    const int64_t mn = a->M * a->N;
+    const int threads = 256;
+    const int64_t blocks = (mn / 4 + threads - 1) / threads;
+    if (a->out_dtype == DL_F32)
+      hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((uint32_t)blocks), dim3(threads), 0, s,
+                         (const float*)a->workspace, (float*)a->C, mn, a->ldc, (int)a->N, sp,
+                         a->accumulate);
+    else
+      hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((uint32_t)blocks), dim3(threads), 0, s,
+                         (const float*)a->workspace, (bf16_t*)a->C, mn, a->ldc, (int)a->N, sp,
+                         a->accumulate);
+    DL_CHECK_LAUNCH("dl_gemm(split reduce)");
+  }
+  const double flops = 2.0 * (double)a->M * (double)a->N * (double)a->K;
+  const double bytes = ((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * oes;
+  dl_prof_after(0, s, flops, bytes);
+  return DL_OK;
+}
+
+// ---- column sums ------------------------------------------------------------------------------
+namespace {
+constexpr int CS_ROWS_PER_BLOCK = 512;
+
+// grid: (ceil(N / 256), row_chunks); block 256 threads = 4 waves; lane -> 4 columns, wave -> row phase
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ X, int64_t ldx, int64_t M, int N,
+                                      float* __restrict__ partial) {
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 256 + lane * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS_PER_BLOCK;
+  const int64_t r1 = min(M, r0 + CS_ROWS_PER_BLOCK);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+    if (n + 4 <= N && (N & 3) == 0) {
+      for (int64_t r = r0 + wave; r < r1; r += 4) s += load4<T>(X + r * ldx + n);
+    } else {
+      for (int64_t r = r0 + wave; r < r1; r += 4)
+        for (int j = 0; j < 4 && n + j < N; ++j) s[j] += to_f32(X[r * ldx + n + j]);
+    }
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && n < N) {
+    s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    float* dst = partial + (int64_t)blockIdx.y * N + n;
+    for (int j = 0; j < 4 && n + j < N; ++j) dst[j] = s[j];
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int chunks, int N,
+                                    float* __restrict__ out, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += partial[(int64_t)c * N + n];
+  out[n] = accumulate ? out[n] + s : s;
+}
+}  // namespace
+
+extern "C" size_t dl_colsum_workspace_bytes(int64_t M, int64_t N) {
+  const int64_t chunks = (M + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK;
+  return (size_t)chunks * (size_t)N * sizeof(float);
+}
+
+extern "C" int dl_colsum(const void* X, int64_t ldx, int64_t M, int64_t N, int32_t dtype, float* out,
+                         int32_t accumulate, void* workspace, size_t workspace_bytes, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(X && out && M > 0 && N > 0, DL_ERR_ARG, "dl_colsum: bad args");
+  DL_CHECK_ARG(workspace && workspace_bytes >= dl_colsum_workspace_bytes(M, N), DL_ERR_WORKSPACE,
+               "dl_colsum: workspace too small");
+  if ((N & 3) == 0)
+    DL_CHECK_ARG(ldx % 4 == 0 && ((uintptr_t)X % (4 * dl_dtype_size(dtype))) == 0, DL_ERR_ALIGN,
+                 "dl_colsum: X not aligned for 4-wide loads");
+  const int chunks = (int)((M + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK);
+  dim3 grid((uint32_t)((N + 255) / 256), (uint32_t)chunks);
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)X, ldx, M,
+                       (int)N, (float*)workspace);
+  else
+    hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)X, ldx, M,
+                       (int)N, (float*)workspace);
+  DL_CHECK_LAUNCH("dl_colsum(partial)");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, s,
+                     (const float*)workspace, chunks, (int)N, out, accumulate);
+  DL_CHECK_LAUNCH("dl_colsum(final)");
+  return DL_OK;
+}

@@ -1,0 +1,498 @@
+// losses.hip — loss kernels of the SSL / cross-modality heads (fp32 throughout).
+//   cos_rowloss   : SimSiam 2 - 2 cos(x, y) per row                (self_supervised_learning.py:184-187)
+//   ntxent_stream : NT-Xent over P = [q; k] with a streaming log-sum-exp; the (2n)^2 logit matrix of
+//                   self_supervised_learning.py:168-182 is never materialised (fp32 MFMA tiles).
+//   triplet_sigcos: margin triplet loss with distance 1 - sigmoid(cos) over a label matrix
+//                   (cross_modality.py:15-47, utils.py:571-574).
+#include "tiles.cuh"
+
+namespace {
+using namespace dltile;
+
+// ------------------------------------------------------------------------------------------
+// cosine row loss.  F.normalize semantics: x / max(||x||, 1e-12).
+// ------------------------------------------------------------------------------------------
+constexpr float NORM_EPS = 1e-12f;
+
+__global__ void cos_rowloss_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                       float* __restrict__ row_loss, int64_t n_rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  float dot = 0.f, nx = 0.f, ny = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + row * D + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(y + row * D + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dot += a[e] * b[e]; nx += a[e] * a[e]; ny += b[e] * b[e]; }
+  }
+  dot = wave_sum(dot); nx = wave_sum(nx); ny = wave_sum(ny);
+  if (lane == 0) {
+    const float dx = fmaxf(sqrtf(nx), NORM_EPS), dy = fmaxf(sqrtf(ny), NORM_EPS);
+    row_loss[row] = 2.0f - 2.0f * dot / (dx * dy);
+  }
+}
+
+__global__ void vec_sum_kernel(const float* __restrict__ v, int64_t n, float scale, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    *out = t * scale;
+  }
+}
+
+// dx = gscale * d/dx (2 - 2 cos)
+__global__ void cos_rowloss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, float gscale,
+                                       float* __restrict__ dxo, int64_t n_rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  float dot = 0.f, nx = 0.f, ny = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + row * D + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(y + row * D + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dot += a[e] * b[e]; nx += a[e] * a[e]; ny += b[e] * b[e]; }
+  }
+  dot = wave_sum(dot); nx = wave_sum(nx); ny = wave_sum(ny);
+  const float nxs = sqrtf(nx);
+  const float dx = fmaxf(nxs, NORM_EPS), dy = fmaxf(sqrtf(ny), NORM_EPS);
+  // cos = dot / (dx*dy); d cos / d x = y/(dx*dy) - dot * x / (dx^3 * dy)   (when ||x|| > eps)
+  const float a1 = -2.0f * gscale / (dx * dy);
+  const float a2 = (nxs > NORM_EPS) ? 2.0f * gscale * dot / (dx * dx * dx * dy) : 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + row * D + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(y + row * D + c);
+    *reinterpret_cast<f32x4*>(dxo + row * D + c) = b * a1 + a * a2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// NT-Xent streaming kernels (fp32 MFMA).  Rows of P: i < n -> q[i], else k[i - n].
+// ------------------------------------------------------------------------------------------
+template <int HD>
+__device__ __forceinline__ void stage_p_rows(char* lds, const float* q, const float* k, int64_t n, int64_t n2,
+                                             int64_t j0) {
+  using TL = ATile<float, HD>;
+  for (int c = threadIdx.x; c < 64 * TL::CPR; c += ATT_THREADS) {
+    const int row = c / TL::CPR, ch = c % TL::CPR;
+    const int64_t gr = j0 + row;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (gr < n2) {
+      const float* src = gr < n ? q + gr * HD : k + (gr - n) * HD;
+      v = *reinterpret_cast<const u32x4*>(src + ch * 4);
+    }
+    lds_write16(lds, row * TL::RB + ((ch ^ (row & 7)) << 4), v);
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(ATT_THREADS) void ntxent_fwd_kernel(const float* __restrict__ q,
+                                                                const float* __restrict__ k, int64_t n,
+                                                                float inv_t, float* __restrict__ row_lse,
+                                                                float* __restrict__ row_loss) {
+  using TL = ATile<float, HD>;
+  constexpr int NKF = HD / 16, NKT = 4;
+  __shared__ __attribute__((aligned(16))) char Ps[64 * TL::RB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 15, g = lane >> 4;
+  const int64_t n2 = 2 * n;
+  const int64_t i = (int64_t)blockIdx.x * 64 + wave * 16 + il;
+  const bool iok = i < n2;
+  const float* irow = i < n ? q + i * HD : k + (i - n) * HD;
+  const int64_t pos = i < n ? i + n : i - n;
+  u32x4 qf[NKF];
+#pragma unroll
+  for (int kf = 0; kf < NKF; ++kf) qf[kf] = frag_global<float>(irow, iok, kf, g);
+  const float c = inv_t * LOG2E;
+  float m_run = -INFINITY, l_run = 0.f, pos_logit = 0.f;
+  for (int64_t j0 = 0; j0 < n2; j0 += 64) {
+    stage_p_rows<HD>(Ps, q, k, n, n2, j0);
+    __syncthreads();
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kf = 0; kf < NKF; ++kf) s[kt] = Mma<float>::mma(frag_kc<float, HD>(Ps, kt * 16, kf, il, g), qf[kf], s[kt]);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t j = j0 + kt * 16 + 4 * g + r;
+        if (j == pos) pos_logit = s[kt][r] * inv_t;
+        if (j == i || j >= n2) s[kt][r] = -INFINITY;
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    mx = group4_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    if (m_new > -INFINITY) {
+      const float alpha = exp2f((m_run - m_new) * c);
+      float rs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rs += exp2f((s[kt][r] - m_new) * c);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+    }
+    __syncthreads();
+  }
+  const float l = group4_sum(l_run);
+  const float pl = group4_sum(pos_logit);
+  if (iok && g == 0) {
+    const float lse = m_run * inv_t + logf(l);
+    row_lse[i] = lse;
+    row_loss[i] = lse - pl;
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(ATT_THREADS) void ntxent_bwd_kernel(const float* __restrict__ q,
+                                                                const float* __restrict__ k, int64_t n,
+                                                                float inv_t, const float* __restrict__ row_lse,
+                                                                float gscale, float* __restrict__ dq,
+                                                                float* __restrict__ dk) {
+  using TL = ATile<float, HD>;
+  constexpr int NKF = HD / 16, NKT = 4, NDT = HD / 16;
+  __shared__ __attribute__((aligned(16))) char smem[64 * TL::RB + 64 * sizeof(float)];
+  char* Ps = smem;
+  float* lse_s = reinterpret_cast<float*>(smem + 64 * TL::RB);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 15, g = lane >> 4;
+  const int64_t n2 = 2 * n;
+  const int64_t i = (int64_t)blockIdx.x * 64 + wave * 16 + il;
+  const bool iok = i < n2;
+  const float* irow = i < n ? q + i * HD : k + (i - n) * HD;
+  const int64_t pos = i < n ? i + n : i - n;
+  u32x4 qf[NKF];
+#pragma unroll
+  for (int kf = 0; kf < NKF; ++kf) qf[kf] = frag_global<float>(irow, iok, kf, g);
+  const float c = inv_t * LOG2E;
+  const float lse_i = iok ? row_lse[i] * LOG2E : INFINITY;
+  f32x4 acc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int64_t j0 = 0; j0 < n2; j0 += 64) {
+    stage_p_rows<HD>(Ps, q, k, n, n2, j0);
+    if (threadIdx.x < 64) lse_s[threadIdx.x] = (j0 + threadIdx.x < n2) ? row_lse[j0 + threadIdx.x] * LOG2E : INFINITY;
+    __syncthreads();
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kf = 0; kf < NKF; ++kf) s[kt] = Mma<float>::mma(frag_kc<float, HD>(Ps, kt * 16, kf, il, g), qf[kf], s[kt]);
+      const f32x4 lj = *reinterpret_cast<const f32x4*>(lse_s + kt * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t j = j0 + kt * 16 + 4 * g + r;
+        const float x = s[kt][r] * c;
+        float cij = exp2f(x - lse_i) + exp2f(x - lj[r]);
+        if (j == pos) cij -= 2.0f;
+        if (j == i || j >= n2 || !iok) cij = 0.f;
+        s[kt][r] = cij;
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const u32x4 cb = ctile_frag_f32(s[kt]);
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) acc[d] = Mma<float>::mma(frag_tr<float, HD>(Ps, kt * 16, d * 16, il, g), cb, acc[d]);
+    }
+    __syncthreads();
+  }
+  if (iok) {
+    float* drow = i < n ? dq + i * HD : dk + (i - n) * HD;
+    const float sc = gscale * inv_t;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) *reinterpret_cast<f32x4*>(drow + d * 16 + 4 * g) = acc[d] * sc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// triplet loss with D = 1 - sigmoid(cos).  nn.CosineSimilarity eps = 1e-8 (clamps each norm).
+// ------------------------------------------------------------------------------------------
+constexpr float COS_EPS = 1e-8f;
+
+// row norms (clamped at eps): one wave per row
+__global__ void row_norm_kernel(const float* __restrict__ X, int n, int dim, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = lane; c < dim; c += 64) { const float a = X[(int64_t)i * dim + c]; s += a * a; }
+  s = wave_sum(s);
+  if (lane == 0) out[i] = fmaxf(sqrtf(s), COS_EPS);
+}
+
+// block = 4 waves, wave handles one anchor i and loops over j
+__global__ void sigcos_dist_kernel(const float* __restrict__ P, const float* __restrict__ Dm,
+                                   const float* __restrict__ pn, const float* __restrict__ dn, int n_p, int n_d,
+                                   int dim, float* __restrict__ dist, float* __restrict__ selfd,
+                                   float* __restrict__ cosout) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_p) return;
+  const float np = pn[i];
+  float np2 = 0.f;
+  for (int c = lane; c < dim; c += 64) { const float a = P[(int64_t)i * dim + c]; np2 += a * a; }
+  np2 = wave_sum(np2);
+  for (int j = 0; j < n_d; ++j) {
+    float dot = 0.f;
+    for (int c = lane; c < dim; c += 64) dot += P[(int64_t)i * dim + c] * Dm[(int64_t)j * dim + c];
+    dot = wave_sum(dot);
+    if (lane == 0) {
+      const float cs = dot / (np * dn[j]);
+      cosout[(int64_t)i * n_d + j] = cs;
+      dist[(int64_t)i * n_d + j] = 1.0f - 1.0f / (1.0f + __expf(-cs));
+    }
+  }
+  if (lane == 0) {  // anchor-as-positive distance
+    const float cs = np2 / (np * np);
+    selfd[i] = 1.0f - 1.0f / (1.0f + __expf(-cs));
+  }
+}
+
+// one block per anchor i.  partial[i] = sum of hinges, cnt[i] = number of triplets.
+// When `gcoef` != nullptr also writes dL/dDist[i][j] (unnormalised: +count for positives, -count for negatives).
+__global__ void triplet_reduce_kernel(const float* __restrict__ dist, const float* __restrict__ selfd,
+                                      const int8_t* __restrict__ gt, int n_p, int n_d, float margin,
+                                      float* __restrict__ partial, float* __restrict__ cnt,
+                                      float* __restrict__ gcoef) {
+  extern __shared__ int lists[];  // pos list then neg list (n_d ints each)
+  __shared__ int npos_s, nneg_s;
+  __shared__ float red[8];
+  const int i = blockIdx.x;
+  int* pos = lists; int* neg = lists + n_d;
+  if (threadIdx.x == 0) {
+    int a = 0, b = 0;
+    for (int j = 0; j < n_d; ++j) {
+      const int8_t v = gt[(int64_t)i * n_d + j];
+      if (v == 1) pos[a++] = j; else if (v == 0) neg[b++] = j;
+    }
+    npos_s = a; nneg_s = b;
+  }
+  __syncthreads();
+  const int np_ = npos_s, nn_ = nneg_s;
+  const float* drow = dist + (int64_t)i * n_d;
+  float s = 0.f;
+  if (gcoef) for (int j = threadIdx.x; j < n_d; j += blockDim.x) gcoef[(int64_t)i * n_d + j] = 0.f;
+  __syncthreads();
+  float count = 0.f;
+  if (np_ > 0 && nn_ > 0) {
+    count = (float)np_ * (float)nn_;
+    for (int t = threadIdx.x; t < np_ * nn_; t += blockDim.x) {
+      const int pj = pos[t / nn_], nj = neg[t % nn_];
+      const float hv = drow[pj] - drow[nj] + margin;
+      if (hv > 0.f) {
+        s += hv;
+        if (gcoef) { atomicAdd(&gcoef[(int64_t)i * n_d + pj], 1.0f); atomicAdd(&gcoef[(int64_t)i * n_d + nj], -1.0f); }
+      }
+    }
+  } else if (nn_ > 0) {
+    count = (float)nn_;
+    const float dself = selfd[i];
+    for (int t = threadIdx.x; t < nn_; t += blockDim.x) {
+      const int nj = neg[t];
+      const float hv = dself - drow[nj] + margin;
+      if (hv > 0.f) { s += hv; if (gcoef) atomicAdd(&gcoef[(int64_t)i * n_d + nj], -1.0f); }
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    partial[i] = t; cnt[i] = count;
+  }
+}
+
+__global__ void triplet_final_kernel(const float* __restrict__ partial, const float* __restrict__ cnt, int n_p,
+                                     float* __restrict__ loss, float* __restrict__ n_tri) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f, c = 0.f;
+    for (int i = 0; i < n_p; ++i) { s += partial[i]; c += cnt[i]; }
+    if (c == 0.f) c = 1.f;
+    *loss = s / c; *n_tri = c;
+  }
+}
+
+// dp_i = sum_j G_ij * (d_j/(|p_i||d_j|) - cos_ij p_i/|p_i|^2); G_ij = -sig'(cos) * coef_ij * gscale / n_tri
+__global__ void triplet_bwd_p_kernel(const float* __restrict__ P, const float* __restrict__ Dm,
+                                     const float* __restrict__ pn, const float* __restrict__ dn,
+                                     const float* __restrict__ cosm, const float* __restrict__ gcoef, int n_p,
+                                     int n_d, int dim, float gscale, const float* __restrict__ n_tri,
+                                     float* __restrict__ dp) {
+  const int i = blockIdx.x;
+  const float gs = gscale / n_tri[0];
+  const float np = pn[i];
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+    float acc = 0.f;
+    const float pc = P[(int64_t)i * dim + c];
+    for (int j = 0; j < n_d; ++j) {
+      const float gc = gcoef[(int64_t)i * n_d + j];
+      if (gc == 0.f) continue;
+      const float cs = cosm[(int64_t)i * n_d + j];
+      const float sg = 1.0f / (1.0f + __expf(-cs));
+      const float G = -sg * (1.0f - sg) * gc * gs;
+      acc += G * (Dm[(int64_t)j * dim + c] / (np * dn[j]) - cs * pc / (np * np));
+    }
+    dp[(int64_t)i * dim + c] = acc;
+  }
+}
+__global__ void triplet_bwd_d_kernel(const float* __restrict__ P, const float* __restrict__ Dm,
+                                     const float* __restrict__ pn, const float* __restrict__ dn,
+                                     const float* __restrict__ cosm, const float* __restrict__ gcoef, int n_p,
+                                     int n_d, int dim, float gscale, const float* __restrict__ n_tri,
+                                     float* __restrict__ dd) {
+  const int j = blockIdx.x;
+  const float gs = gscale / n_tri[0];
+  const float nd = dn[j];
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+    float acc = 0.f;
+    const float dc = Dm[(int64_t)j * dim + c];
+    for (int i = 0; i < n_p; ++i) {
+      const float gc = gcoef[(int64_t)i * n_d + j];
+      if (gc == 0.f) continue;
+      const float cs = cosm[(int64_t)i * n_d + j];
+      const float sg = 1.0f / (1.0f + __expf(-cs));
+      const float G = -sg * (1.0f - sg) * gc * gs;
+      acc += G * (P[(int64_t)i * dim + c] / (pn[i] * nd) - cs * dc / (nd * nd));
+    }
+    dd[(int64_t)j * dim + c] = acc;
+  }
+}
+
+struct TripletBuf {
+  float *dist, *selfd, *partial, *cnt, *cosm, *gcoef, *pn, *dn;
+  TripletBuf(float* base, int64_t n_p, int64_t n_d) {
+    dist = base; selfd = dist + n_p * n_d; partial = selfd + n_p; cnt = partial + n_p;
+    cosm = cnt + n_p; gcoef = cosm + n_p * n_d; pn = gcoef + n_p * n_d; dn = pn + n_p;
+  }
+};
+}  // namespace
+
+extern "C" int dl_cos_rowloss_fwd(const float* x, const float* y, float* row_loss, float* loss_sum, int64_t n_rows,
+                                  int64_t D, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(x && y && row_loss && n_rows > 0 && D > 0 && D % 4 == 0, DL_ERR_ARG, "dl_cos_rowloss_fwd: bad args");
+  hipLaunchKernelGGL(cos_rowloss_fwd_kernel, dim3((uint32_t)((n_rows + 3) / 4)), dim3(256), 0, s, x, y, row_loss,
+                     n_rows, (int)D);
+  DL_CHECK_LAUNCH("dl_cos_rowloss_fwd");
+  if (loss_sum) {
+    hipLaunchKernelGGL(vec_sum_kernel, dim3(1), dim3(1024), 0, s, (const float*)row_loss, n_rows, 1.0f, loss_sum);
+    DL_CHECK_LAUNCH("dl_cos_rowloss_fwd(sum)");
+  }
+  return DL_OK;
+}
+
+extern "C" int dl_cos_rowloss_bwd(const float* x, const float* y, float grad_scale, float* dx, int64_t n_rows,
+                                  int64_t D, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(x && y && dx && n_rows > 0 && D > 0 && D % 4 == 0, DL_ERR_ARG, "dl_cos_rowloss_bwd: bad args");
+  hipLaunchKernelGGL(cos_rowloss_bwd_kernel, dim3((uint32_t)((n_rows + 3) / 4)), dim3(256), 0, s, x, y, grad_scale,
+                     dx, n_rows, (int)D);
+  DL_CHECK_LAUNCH("dl_cos_rowloss_bwd");
+  return DL_OK;
+}
+
+extern "C" size_t dl_ntxent_workspace_bytes(int64_t n, int64_t d) { (void)d; return (size_t)(2 * n) * sizeof(float); }
+
+extern "C" int dl_ntxent_fwd(const float* q, const float* k, int64_t n, int64_t d, float temperature, float* loss,
+                             float* row_lse, void* workspace, size_t workspace_bytes, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(q && k && loss && row_lse && n > 0, DL_ERR_ARG, "dl_ntxent_fwd: bad args");
+  DL_CHECK_ARG(d == 64 || d == 128, DL_ERR_UNSUPPORTED, "dl_ntxent_fwd: d must be 64 or 128 (got %ld)", (long)d);
+  DL_CHECK_ARG(temperature > 0.f, DL_ERR_ARG, "dl_ntxent_fwd: temperature must be > 0");
+  DL_CHECK_ARG(workspace && workspace_bytes >= dl_ntxent_workspace_bytes(n, d), DL_ERR_WORKSPACE,
+               "dl_ntxent_fwd: workspace too small");
+  const uint32_t blocks = (uint32_t)((2 * n + 63) / 64);
+  float* row_loss = (float*)workspace;
+  if (d == 64)
+    hipLaunchKernelGGL((ntxent_fwd_kernel<64>), dim3(blocks), dim3(ATT_THREADS), 0, s, q, k, n, 1.0f / temperature,
+                       row_lse, row_loss);
+  else
+    hipLaunchKernelGGL((ntxent_fwd_kernel<128>), dim3(blocks), dim3(ATT_THREADS), 0, s, q, k, n, 1.0f / temperature,
+                       row_lse, row_loss);
+  DL_CHECK_LAUNCH("dl_ntxent_fwd");
+  hipLaunchKernelGGL(vec_sum_kernel, dim3(1), dim3(1024), 0, s, (const float*)row_loss, 2 * n,
+                     1.0f / (float)(2 * n), loss);
+  DL_CHECK_LAUNCH("dl_ntxent_fwd(sum)");
+  return DL_OK;
+}
+
+extern "C" int dl_ntxent_bwd(const float* q, const float* k, int64_t n, int64_t d, float temperature,
+                             const float* row_lse, float grad_out, float* dq, float* dk, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(q && k && row_lse && dq && dk && n > 0, DL_ERR_ARG, "dl_ntxent_bwd: bad args");
+  DL_CHECK_ARG(d == 64 || d == 128, DL_ERR_UNSUPPORTED, "dl_ntxent_bwd: d must be 64 or 128");
+  const uint32_t blocks = (uint32_t)((2 * n + 63) / 64);
+  const float gscale = grad_out / (float)(2 * n);
+  if (d == 64)
+    hipLaunchKernelGGL((ntxent_bwd_kernel<64>), dim3(blocks), dim3(ATT_THREADS), 0, s, q, k, n, 1.0f / temperature,
+                       row_lse, gscale, dq, dk);
+  else
+    hipLaunchKernelGGL((ntxent_bwd_kernel<128>), dim3(blocks), dim3(ATT_THREADS), 0, s, q, k, n, 1.0f / temperature,
+                       row_lse, gscale, dq, dk);
+  DL_CHECK_LAUNCH("dl_ntxent_bwd");
+  return DL_OK;
+}
+
+extern "C" size_t dl_triplet_sigcos_buffer_floats(int64_t n_p, int64_t n_d) {
+  return (size_t)(3 * n_p * n_d + 4 * n_p + n_d);
+}
+
+// `dist` must hold dl_triplet_sigcos_buffer_floats(n_p, n_d) floats: the distance matrix first, then
+// scratch (anchor-as-positive distances, per-anchor partials, cosines, gradient coefficients, norms)
+// that the backward call reuses.
+extern "C" int dl_triplet_sigcos_fwd(const float* p_lats, const float* d_lats, const int8_t* gt, int64_t n_p,
+                                     int64_t n_d, int64_t dim, float margin, float* dist, float* loss, float* n_tri,
+                                     dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(p_lats && d_lats && gt && dist && loss && n_tri && n_p > 0 && n_d > 0 && dim > 0, DL_ERR_ARG,
+               "dl_triplet_sigcos_fwd: bad args");
+  DL_CHECK_ARG(n_d <= 8192, DL_ERR_SHAPE, "dl_triplet_sigcos_fwd: n_d too large for the LDS index lists");
+  TripletBuf b(dist, n_p, n_d);
+  hipLaunchKernelGGL(row_norm_kernel, dim3((uint32_t)((n_p + 3) / 4)), dim3(256), 0, s, p_lats, (int)n_p, (int)dim, b.pn);
+  hipLaunchKernelGGL(row_norm_kernel, dim3((uint32_t)((n_d + 3) / 4)), dim3(256), 0, s, d_lats, (int)n_d, (int)dim, b.dn);
+  hipLaunchKernelGGL(sigcos_dist_kernel, dim3((uint32_t)((n_p + 3) / 4)), dim3(256), 0, s, p_lats, d_lats,
+                     (const float*)b.pn, (const float*)b.dn, (int)n_p, (int)n_d, (int)dim, b.dist, b.selfd, b.cosm);
+  DL_CHECK_LAUNCH("dl_triplet_sigcos_fwd(dist)");
+  hipLaunchKernelGGL(triplet_reduce_kernel, dim3((uint32_t)n_p), dim3(256), (size_t)n_d * 2 * sizeof(int), s,
+                     (const float*)b.dist, (const float*)b.selfd, gt, (int)n_p, (int)n_d, margin, b.partial, b.cnt,
+                     (float*)nullptr);
+  DL_CHECK_LAUNCH("dl_triplet_sigcos_fwd(reduce)");
+  hipLaunchKernelGGL(triplet_final_kernel, dim3(1), dim3(64), 0, s, (const float*)b.partial, (const float*)b.cnt,
+                     (int)n_p, loss, n_tri);
+  DL_CHECK_LAUNCH("dl_triplet_sigcos_fwd(final)");
+  return DL_OK;
+}
+
+extern "C" int dl_triplet_sigcos_bwd(const float* p_lats, const float* d_lats, const int8_t* gt, const float* dist,
+                                     int64_t n_p, int64_t n_d, int64_t dim, float margin, const float* n_tri,
+                                     float grad_out, float* dp, float* dd, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(p_lats && d_lats && gt && dist && n_tri && dp && dd && n_p > 0 && n_d > 0 && dim > 0, DL_ERR_ARG,
+               "dl_triplet_sigcos_bwd: bad args");
+  TripletBuf b(const_cast<float*>(dist), n_p, n_d);
+  hipLaunchKernelGGL(triplet_reduce_kernel, dim3((uint32_t)n_p), dim3(256), (size_t)n_d * 2 * sizeof(int), s,
+                     (const float*)b.dist, (const float*)b.selfd, gt, (int)n_p, (int)n_d, margin, b.partial, b.cnt,
+                     b.gcoef);
+  DL_CHECK_LAUNCH("dl_triplet_sigcos_bwd(coef)");
+  hipLaunchKernelGGL(triplet_bwd_p_kernel, dim3((uint32_t)n_p), dim3(256), 0, s, p_lats, d_lats, (const float*)b.pn,
+                     (const float*)b.dn, (const float*)b.cosm, (const float*)b.gcoef, (int)n_p, (int)n_d, (int)dim,
+                     grad_out, n_tri, dp);
+  hipLaunchKernelGGL(triplet_bwd_d_kernel, dim3((uint32_t)n_d), dim3(256), 0, s, p_lats, d_lats, (const float*)b.pn,
+                     (const float*)b.dn, (const float*)b.cosm, (const float*)b.gcoef, (int)n_p, (int)n_d, (int)dim,
+                     grad_out, n_tri, dd);
+  DL_CHECK_LAUNCH("dl_triplet_sigcos_bwd");
+  return DL_OK;
+}

@@ -1,0 +1,207 @@
+// norm.hip — LayerNorm forward / backward (HBM-bound: one pass over x, 16-byte/8-byte vector loads,
+// one wave per row, statistics in fp32).
+#include "common.cuh"
+
+namespace {
+constexpr int LN_MAXV = 8;            // up to 8 x (64 lanes x 4 elems) = 2048 columns
+constexpr int LN_BWD_ROWS = 64;       // rows per workgroup in backward (16 per wave)
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     int64_t ldy, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int64_t M, int D,
+                                                     float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const int nv = D >> 2;  // vec4 chunks per row
+  f32x4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nv) {
+      v[j] = load4<T>(x + row * ldx + c * 4);
+      s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q += d * d; }
+    }
+  }
+  const float var = wave_sum(q) / (float)D;
+  const float rstd = rsqrtf(var + eps);
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nv) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c * 4);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gm[e] + bt[e];
+      store4<T>(y + row * ldy + c * 4, o);
+    }
+  }
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+}
+
+// partial layout: [nblocks][2][D]  (0: dgamma, 1: dbeta)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int64_t lddy,
+                                                     const T* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma,
+                                                     const T* __restrict__ dres, int64_t lddres,
+                                                     T* __restrict__ dx, int64_t lddx,
+                                                     float* __restrict__ partial, int64_t M, int D) {
+  extern __shared__ __attribute__((aligned(16))) char ln_smem[];  // [4 waves][2][D] floats
+  float* sm = reinterpret_cast<float*>(ln_smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = D >> 2;
+  f32x4 gm[LN_MAXV], dg[LN_MAXV], db[LN_MAXV];
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int c = lane + 64 * j;
+    dg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gm[j] = (c < nv) ? *reinterpret_cast<const f32x4*>(gamma + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * LN_BWD_ROWS;
+  for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
+    const int64_t row = r0 + rr;
+    if (row >= M) break;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[LN_MAXV], g[LN_MAXV];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nv) {
+        const f32x4 xv = load4<T>(x + row * ldx + c * 4);
+        const f32x4 dv = load4<T>(dy + row * lddy + c * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[j][e] = (xv[e] - mu) * rs;
+          g[j][e] = dv[e] * gm[j][e];
+          c1 += g[j][e];
+          c2 += g[j][e] * xh[j][e];
+          dg[j][e] += dv[e] * xh[j][e];
+          db[j][e] += dv[e];
+        }
+      }
+    }
+    c1 = wave_sum(c1) / (float)D;
+    c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nv) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - c1 - xh[j][e] * c2);
+        if (dres) o += load4<T>(dres + row * lddres + c * 4);
+        store4<T>(dx + row * lddx + c * 4, o);
+      }
+    }
+  }
+  // cross-wave reduction of dgamma/dbeta through LDS
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nv) {
+      *reinterpret_cast<f32x4*>(sm + (wave * 2 + 0) * D + c * 4) = dg[j];
+      *reinterpret_cast<f32x4*>(sm + (wave * 2 + 1) * D + c * 4) = db[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    const int which = i / D, col = i % D;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += sm[(w * 2 + which) * D + col];
+    partial[((int64_t)blockIdx.x * 2 + which) * D + col] = s;
+  }
+}
+
+__global__ void ln_bwd_final_kernel(const float* __restrict__ partial, int nblocks, int D,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                    int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * D) return;
+  const int which = i / D, col = i % D;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[((int64_t)b * 2 + which) * D + col];
+  float* dst = which == 0 ? dgamma : dbeta;
+  if (!dst) return;
+  dst[col] = accumulate ? dst[col] + s : s;
+}
+}  // namespace
+
+extern "C" int dl_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta,
+                                void* y, int64_t ldy, float* mean, float* rstd, int64_t M, int64_t D,
+                                float eps, int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(x && y && gamma && beta, DL_ERR_ARG, "dl_layernorm_fwd: null pointer");
+  DL_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, DL_ERR_SHAPE,
+               "dl_layernorm_fwd: D=%ld must be a multiple of 4 and <= %d", (long)D, 256 * LN_MAXV);
+  DL_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0, DL_ERR_ALIGN, "dl_layernorm_fwd: ld must be multiple of 4");
+  const uint32_t blocks = (uint32_t)((M + 3) / 4);
+  dl_prof_before(3, s);
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, ldx,
+                       gamma, beta, (bf16_t*)y, ldy, mean, rstd, M, (int)D, eps);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)x, ldx,
+                       gamma, beta, (float*)y, ldy, mean, rstd, M, (int)D, eps);
+  DL_CHECK_LAUNCH("dl_layernorm_fwd");
+  dl_prof_after(3, s, 8.0 * M * D, 2.0 * M * D * dl_dtype_size(dtype));
+  return DL_OK;
+}
+
+extern "C" size_t dl_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
+  const int64_t nb = (M + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
+  return (size_t)nb * 2 * (size_t)D * sizeof(float);
+}
+
+extern "C" int dl_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx,
+                                const float* mean, const float* rstd, const float* gamma,
+                                const void* dres, int64_t lddres, void* dx, int64_t lddx, float* dgamma,
+                                float* dbeta, int32_t accumulate, int64_t M, int64_t D, int32_t dtype,
+                                void* workspace, size_t workspace_bytes, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(dy && x && mean && rstd && gamma && dx, DL_ERR_ARG, "dl_layernorm_bwd: null pointer");
+  DL_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, DL_ERR_SHAPE,
+               "dl_layernorm_bwd: D=%ld must be a multiple of 4 and <= %d", (long)D, 256 * LN_MAXV);
+  DL_CHECK_ARG(workspace && workspace_bytes >= dl_layernorm_bwd_workspace_bytes(M, D),
+               DL_ERR_WORKSPACE, "dl_layernorm_bwd: workspace too small");
+  const int nb = (int)((M + LN_BWD_ROWS - 1) / LN_BWD_ROWS);
+  const size_t smem = 4 * 2 * (size_t)D * sizeof(float);
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(nb), dim3(256), smem, s, (const bf16_t*)dy, lddy,
+                       (const bf16_t*)x, ldx, mean, rstd, gamma, (const bf16_t*)dres, lddres,
+                       (bf16_t*)dx, lddx, (float*)workspace, M, (int)D);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(nb), dim3(256), smem, s, (const float*)dy, lddy,
+                       (const float*)x, ldx, mean, rstd, gamma, (const float*)dres, lddres, (float*)dx,
+                       lddx, (float*)workspace, M, (int)D);
+  DL_CHECK_LAUNCH("dl_layernorm_bwd");
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((uint32_t)((2 * D + 255) / 256)), dim3(256), 0, s,
+                       (const float*)workspace, nb, (int)D, dgamma, dbeta, accumulate);
+    DL_CHECK_LAUNCH("dl_layernorm_bwd(final)");
+  }
+  return DL_OK;
+}

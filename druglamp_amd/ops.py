@@ -1,0 +1,322 @@
+"""Tensor-level wrappers over the C ABI (druglamp_amd/_lib.py) and the autograd Functions built on
+them.  torch is used for device memory, streams and autograd plumbing only: every arithmetic op on
+the hot path below is a libdruglamp_hip entry point.  There is no CPU path here — tensors must live
+on a HIP device and the shared library must be present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import DL_BF16, DL_F32, AttnBwdArgs, AttnFwdArgs, GemmArgs, check
+
+_DT = {torch.float32: DL_F32, torch.bfloat16: DL_BF16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError("druglamp_amd: unsupported dtype %s (float32 / bfloat16 only)" % t.dtype)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("druglamp_amd: the HIP hot path needs device tensors (got a %s tensor); "
+                               "there is no CPU fallback" % t.device)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class _Workspace:
+    """One growing scratch buffer per device; all launches that use it are stream-ordered."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        key = (device.type, device.index)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
+
+
+_ws = _Workspace()
+_ws2 = _Workspace()  # second buffer so that two scratch users can be live inside one op
+
+
+# ------------------------------------------------------------------------------------------------
+# raw ops
+# ------------------------------------------------------------------------------------------------
+def gemm(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_kslow=False, w_kslow=False,
+         ldx: Optional[int] = None, ldw: Optional[int] = None, bias=None, residual=None, res_row_mod=0,
+         res_before_dropout=False, act=0, pre_out=None, dact_pre=None, dropout_p=0.0, seed=0, out=None,
+         out_dtype=None, accumulate=False, split_k=-1) -> torch.Tensor:
+    """C[M,N] = epilogue(sum_k X[m,k] W[n,k]); see include/druglamp_hip.h (dl_gemm)."""
+    _need_gpu(x, w)
+    L = _lib.lib()
+    out_dtype = out_dtype or x.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+    a = GemmArgs()
+    a.X, a.W, a.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    a.ldx = ldx if ldx is not None else (M if x_kslow else K)
+    a.ldw = ldw if ldw is not None else (N if w_kslow else K)
+    a.ldc = out.stride(0) if out.dim() == 2 else N
+    a.x_kslow, a.w_kslow = int(x_kslow), int(w_kslow)
+    a.M, a.N, a.K = M, N, K
+    a.in_dtype, a.out_dtype = _dt(x), _dt(out)
+    a.bias = _ptr(bias)
+    a.residual = _ptr(residual)
+    a.ldr = N if residual is None else residual.stride(-2)
+    a.res_row_mod = res_row_mod
+    a.res_before_dropout = int(res_before_dropout)
+    a.act = act
+    a.pre_out = _ptr(pre_out)
+    a.ldp = N
+    a.dact_pre = _ptr(dact_pre)
+    a.lddp = N
+    a.dropout_p = float(dropout_p)
+    a.dropout_seed = int(seed)
+    a.accumulate = int(accumulate)
+    a.split_k = split_k
+    nbytes = L.dl_gemm_workspace_bytes(C.byref(a))
+    if nbytes:
+        ws = _ws.get(nbytes, x.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    check(L.dl_gemm(C.byref(a), _stream()), "dl_gemm")
+    return out
+
+
+def colsum(x2d: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate=False) -> torch.Tensor:
+    _need_gpu(x2d)
+    L = _lib.lib()
+    M, N = x2d.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x2d.device)
+    ws = _ws2.get(L.dl_colsum_workspace_bytes(M, N), x2d.device)
+    check(L.dl_colsum(x2d.data_ptr(), x2d.stride(0), M, N, _dt(x2d), out.data_ptr(), int(accumulate),
+                      ws.data_ptr(), ws.numel(), _stream()), "dl_colsum")
+    return out
+
+
+def layernorm_fwd(x2d, gamma, beta, eps):
+    _need_gpu(x2d, gamma, beta)
+    L = _lib.lib()
+    M, D = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    check(L.dl_layernorm_fwd(x2d.data_ptr(), x2d.stride(0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                             y.stride(0), mean.data_ptr(), rstd.data_ptr(), M, D, float(eps), _dt(x2d), _stream()),
+          "dl_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dres=None, need_param_grads=True):
+    L = _lib.lib()
+    M, D = x2d.shape
+    dx = torch.empty_like(x2d)
+    dgamma = torch.empty(D, dtype=torch.float32, device=x2d.device) if need_param_grads else None
+    dbeta = torch.empty(D, dtype=torch.float32, device=x2d.device) if need_param_grads else None
+    ws = _ws.get(L.dl_layernorm_bwd_workspace_bytes(M, D), x2d.device)
+    check(L.dl_layernorm_bwd(dy2d.data_ptr(), dy2d.stride(0), x2d.data_ptr(), x2d.stride(0), mean.data_ptr(),
+                             rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), 0 if dres is None else dres.stride(0),
+                             dx.data_ptr(), dx.stride(0), _ptr(dgamma), _ptr(dbeta), 0, M, D, _dt(x2d),
+                             ws.data_ptr(), ws.numel(), _stream()), "dl_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if src.dtype == dtype:
+        return src
+    _need_gpu(src)
+    src = src.contiguous()
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(_lib.lib().dl_cast(src.data_ptr(), _dt(src), dst.data_ptr(), _DT[dtype], src.numel(), _stream()), "dl_cast")
+    return dst
+
+
+def attn_fwd(q, k, v, *, n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, scale,
+             q_strides, k_strides, v_strides, out, o_strides, o_ss, need_lse=True, raw_logits=None):
+    """Strides are (problem, head, row) in elements.  Returns the LSE tensor (or None)."""
+    _need_gpu(q, k, v, out)
+    a = AttnFwdArgs()
+    a.Q, a.K, a.V, a.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    lse = None
+    if need_lse:
+        lse = torch.empty((n_segments, n_problems, n_heads, Lq), dtype=torch.float32, device=q.device)
+    a.LSE = _ptr(lse)
+    a.raw_logits = _ptr(raw_logits)
+    a.q_ps, a.q_hs, a.q_rs = q_strides
+    a.k_ps, a.k_hs, a.k_rs = k_strides
+    a.v_ps, a.v_hs, a.v_rs = v_strides
+    a.o_ps, a.o_hs, a.o_rs = o_strides
+    a.o_ss = o_ss
+    a.n_problems, a.n_heads, a.n_segments, a.partner_shift = n_problems, n_heads, n_segments, partner_shift
+    a.Lq, a.Lk, a.head_dim, a.dtype = Lq, Lk, head_dim, _dt(q)
+    a.scale = float(scale)
+    check(_lib.lib().dl_attn_fwd(C.byref(a), _stream()), "dl_attn_fwd")
+    return lse
+
+
+def attn_bwd(q, k, v, o, do, lse, *, n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, scale,
+             q_strides, k_strides, v_strides, o_strides, o_ss, do_strides, do_ss, dq, dq_strides, dk, dk_strides,
+             dv, dv_strides):
+    _need_gpu(q, k, v, o, do)
+    a = AttnBwdArgs()
+    delta = torch.empty_like(lse)
+    a.Q, a.K, a.V, a.O, a.dO = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr()
+    a.LSE, a.Delta = lse.data_ptr(), delta.data_ptr()
+    a.dQ, a.dK, a.dV = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    a.q_ps, a.q_hs, a.q_rs = q_strides
+    a.k_ps, a.k_hs, a.k_rs = k_strides
+    a.v_ps, a.v_hs, a.v_rs = v_strides
+    a.o_ps, a.o_hs, a.o_rs = o_strides
+    a.o_ss = o_ss
+    a.do_ps, a.do_hs, a.do_rs = do_strides
+    a.do_ss = do_ss
+    a.dq_ps, a.dq_hs, a.dq_rs = dq_strides
+    a.dk_ps, a.dk_hs, a.dk_rs = dk_strides
+    a.dv_ps, a.dv_hs, a.dv_rs = dv_strides
+    a.n_problems, a.n_heads, a.n_segments, a.partner_shift = n_problems, n_heads, n_segments, partner_shift
+    a.Lq, a.Lk, a.head_dim, a.dtype = Lq, Lk, head_dim, _dt(q)
+    a.scale = float(scale)
+    check(_lib.lib().dl_attn_bwd(C.byref(a), _stream()), "dl_attn_bwd")
+
+
+def dropout_apply(x2d: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    y = torch.empty_like(x2d)
+    rows, D = x2d.shape
+    check(_lib.lib().dl_dropout_apply(x2d.data_ptr(), y.data_ptr(), rows, D, x2d.stride(0), y.stride(0), float(p),
+                                      int(seed), _dt(x2d), _stream()), "dl_dropout_apply")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# dropout seeds: one generator per process; each dropout site draws a fresh 63-bit seed per forward
+# ------------------------------------------------------------------------------------------------
+_seed_gen = torch.Generator(device="cpu")
+_seed_gen.manual_seed(0x5EED)
+
+
+def manual_seed(seed: int) -> None:
+    _seed_gen.manual_seed(int(seed))
+
+
+def next_seed() -> int:
+    return int(torch.randint(0, 2 ** 62, (1,), generator=_seed_gen).item())
+
+
+def rowmod_sum(x2d: torch.Tensor, L: int) -> torch.Tensor:
+    M, D = x2d.shape
+    out = torch.empty((L, D), dtype=torch.float32, device=x2d.device)
+    check(_lib.lib().dl_rowmod_sum(x2d.data_ptr(), out.data_ptr(), M, D, L, 0, _dt(x2d), _stream()), "dl_rowmod_sum")
+    return out
+
+
+def add_rowmod_dropout(x2d: torch.Tensor, pe2d: Optional[torch.Tensor], p: float, seed: int) -> torch.Tensor:
+    M, D = x2d.shape
+    y = torch.empty_like(x2d)
+    Lr = pe2d.shape[0] if pe2d is not None else 1
+    check(_lib.lib().dl_add_rowmod_dropout(x2d.data_ptr(), _ptr(pe2d), y.data_ptr(), M, D, Lr, float(p), int(seed),
+                                           _dt(x2d), _stream()), "dl_add_rowmod_dropout")
+    return y
+
+
+def token_gate_fwd(v: torch.Tensor, logits: torch.Tensor, H: int, add_residual: bool):
+    B, L, D = v.shape
+    out = torch.empty_like(v)
+    gate = torch.empty((B, H, L), dtype=torch.float32, device=v.device)
+    check(_lib.lib().dl_token_gate_fwd(v.data_ptr(), logits.data_ptr(), out.data_ptr(), gate.data_ptr(), B, L, D, H,
+                                       int(add_residual), _dt(v), _stream()), "dl_token_gate_fwd")
+    return out, gate
+
+
+def token_gate_bwd(dout, v, gate, H: int, add_residual: bool):
+    B, L, D = v.shape
+    dv = torch.empty_like(v)
+    dlogits = torch.empty((B, L, H), dtype=v.dtype, device=v.device)
+    check(_lib.lib().dl_token_gate_bwd(dout.data_ptr(), v.data_ptr(), gate.data_ptr(), dv.data_ptr(),
+                                       dlogits.data_ptr(), B, L, D, H, int(add_residual), _dt(v), _stream()),
+          "dl_token_gate_bwd")
+    return dv, dlogits
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, step,
+               grad_scale=1.0, lowp=None):
+    n = param.numel()
+    check(_lib.lib().dl_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
+                                   float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                   float(grad_scale), _ptr(lowp), _DT[lowp.dtype] if lowp is not None else 0,
+                                   _stream()), "dl_adamw_step")
+
+
+def cos_rowloss_fwd(x, y):
+    n, D = x.shape
+    row = torch.empty(n, dtype=torch.float32, device=x.device)
+    check(_lib.lib().dl_cos_rowloss_fwd(x.data_ptr(), y.data_ptr(), row.data_ptr(), None, n, D, _stream()),
+          "dl_cos_rowloss_fwd")
+    return row
+
+
+def cos_rowloss_bwd(x, y, grad_scale: float):
+    n, D = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.lib().dl_cos_rowloss_bwd(x.data_ptr(), y.data_ptr(), float(grad_scale), dx.data_ptr(), n, D, _stream()),
+          "dl_cos_rowloss_bwd")
+    return dx
+
+
+def ntxent_fwd(q, k, temperature: float):
+    n, d = q.shape
+    L = _lib.lib()
+    loss = torch.empty(1, dtype=torch.float32, device=q.device)
+    lse = torch.empty(2 * n, dtype=torch.float32, device=q.device)
+    ws = _ws.get(L.dl_ntxent_workspace_bytes(n, d), q.device)
+    check(L.dl_ntxent_fwd(q.data_ptr(), k.data_ptr(), n, d, float(temperature), loss.data_ptr(), lse.data_ptr(),
+                          ws.data_ptr(), ws.numel(), _stream()), "dl_ntxent_fwd")
+    return loss, lse
+
+
+def ntxent_bwd(q, k, temperature: float, lse, grad_out: float):
+    n, d = q.shape
+    dq, dk = torch.empty_like(q), torch.empty_like(k)
+    check(_lib.lib().dl_ntxent_bwd(q.data_ptr(), k.data_ptr(), n, d, float(temperature), lse.data_ptr(),
+                                   float(grad_out), dq.data_ptr(), dk.data_ptr(), _stream()), "dl_ntxent_bwd")
+    return dq, dk
+
+
+def triplet_sigcos_fwd(p_lats, d_lats, gt_i8, margin: float):
+    n_p, dim = p_lats.shape
+    n_d = d_lats.shape[0]
+    L = _lib.lib()
+    buf = torch.empty(L.dl_triplet_sigcos_buffer_floats(n_p, n_d), dtype=torch.float32, device=p_lats.device)
+    loss = torch.empty(1, dtype=torch.float32, device=p_lats.device)
+    ntri = torch.empty(1, dtype=torch.float32, device=p_lats.device)
+    check(L.dl_triplet_sigcos_fwd(p_lats.data_ptr(), d_lats.data_ptr(), gt_i8.data_ptr(), n_p, n_d, dim, float(margin),
+                                  buf.data_ptr(), loss.data_ptr(), ntri.data_ptr(), _stream()), "dl_triplet_sigcos_fwd")
+    return loss, ntri, buf
+
+
+def triplet_sigcos_bwd(p_lats, d_lats, gt_i8, margin: float, buf, ntri, grad_out: float):
+    n_p, dim = p_lats.shape
+    n_d = d_lats.shape[0]
+    dp, dd = torch.empty_like(p_lats), torch.empty_like(d_lats)
+    check(_lib.lib().dl_triplet_sigcos_bwd(p_lats.data_ptr(), d_lats.data_ptr(), gt_i8.data_ptr(), buf.data_ptr(), n_p,
+                                           n_d, dim, float(margin), ntri.data_ptr(), float(grad_out), dp.data_ptr(),
+                                           dd.data_ptr(), _stream()), "dl_triplet_sigcos_bwd")
+    return dp, dd

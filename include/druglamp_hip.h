@@ -1,0 +1,239 @@
+/*
+ * druglamp_hip.h — C ABI of libdruglamp_hip.so (gfx950 / MI355X).
+ *
+ * The reference (Lzcstan/DrugLAMP) has NO native / FFI layer: its hot path is Python nn.Module
+ * composition over stock PyTorch ops.  Every entry point below therefore replaces a *sequence of
+ * eager torch ops* inside one reference function; the reference file:line each one stands in for
+ * is cited next to it.  The Python host side (druglamp_amd/model/…) keeps the reference's module
+ * names, forward signatures and state_dict keys and calls these entry points through ctypes
+ * (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers unless a
+ *     parameter says "host".
+ *   - the library owns nothing: the caller allocates inputs, outputs and workspaces
+ *     (dl_*_workspace_bytes tells how much); no hipMalloc on any path below.
+ *   - every launch goes to the hipStream_t passed in (void* here so that C callers need no HIP
+ *     headers); nothing synchronises the device.
+ *   - return value: 0 on success, negative dl_status otherwise; dl_last_error() gives a
+ *     thread-local message.  Nothing aborts.
+ *   - dtype: activations/weights are DL_F32 (exact-fp32 MFMA path, parity mode) or DL_BF16
+ *     (bf16 MFMA, fp32 accumulate); statistics, biases, norm affine params, losses and all
+ *     parameter gradients are fp32.
+ */
+#ifndef DRUGLAMP_HIP_H
+#define DRUGLAMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { DL_OK = 0, DL_ERR_ARG = -1, DL_ERR_SHAPE = -2, DL_ERR_ALIGN = -3,
+               DL_ERR_WORKSPACE = -4, DL_ERR_LAUNCH = -5, DL_ERR_UNSUPPORTED = -6 } dl_status;
+
+typedef enum { DL_F32 = 0, DL_BF16 = 1 } dl_dtype;
+
+typedef void* dl_stream;   /* hipStream_t */
+
+const char* dl_last_error(void);
+int dl_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * dl_gemm — C[m,n] = epilogue( sum_k X[m,k] * W[n,k] )
+ *
+ * Replaces torch.nn.Linear forward and its two autograd products wherever the hot path uses
+ * them: Attention.forward query/key/value/out/fc (model/PMMA/attention.py:90-99,81-83,120),
+ * Mlp.forward fc1/fc2 (model/PMMA/mlp.py:44-50), Embeddings.mol_embeddings
+ * (model/PMMA/embed.py:40-42), PGCA in/out projections
+ * (model/PGCA/guided_cross_attention_model.py:146-161,212,314), MHLA lin1/lin2
+ * (model/PMMA/encoder.py:128-129).
+ *
+ * Operand storage: x_kslow == 0 -> X stored [M][K] (K contiguous, row pitch ldx elements);
+ *                  x_kslow == 1 -> X stored [K][M] (M contiguous, pitch ldx).  Same for W/N.
+ *   forward  y = x W^T      : X=x  (kslow 0), W=weight (kslow 0)
+ *   dgrad    dx = dy W      : X=dy (kslow 0), W=weight viewed [contraction=N_out][K_in] (kslow 1)
+ *   wgrad    dW = dy^T x    : X=dy (kslow 1, rows = N_out), W=x (kslow 1, rows = K_in)
+ * Epilogue order: v = acc (+bias[n]); save pre_out; act; * gelu'(dact_pre); (+res if
+ * res_before_dropout); dropout; (+res otherwise); store (or C += v when accumulate, f32 out).
+ * split_k > 1: the contraction is cut into split_k slabs reduced by a second kernel; only the
+ * plain epilogue (optionally accumulate) is allowed and out_dtype must be DL_F32.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* X; int64_t ldx; int32_t x_kslow;
+  const void* W; int64_t ldw; int32_t w_kslow;
+  void* C; int64_t ldc;
+  int64_t M, N, K;
+  int32_t in_dtype, out_dtype;
+  const float* bias;                 /* [N] or NULL */
+  const void* residual; int64_t ldr; /* in_dtype, [M or res_row_mod][N] or NULL */
+  int64_t res_row_mod;               /* >0: residual row = m % res_row_mod (positional table) */
+  int32_t res_before_dropout;
+  int32_t act;                       /* 0 none, 1 exact-erf GELU */
+  void* pre_out; int64_t ldp;        /* in_dtype, pre-activation copy or NULL */
+  const void* dact_pre; int64_t lddp;/* in_dtype, multiply by gelu'(dact_pre[m,n]) or NULL */
+  float dropout_p; uint64_t dropout_seed;
+  int32_t accumulate;
+  int32_t split_k; void* workspace; size_t workspace_bytes;
+} dl_gemm_args;
+
+size_t dl_gemm_workspace_bytes(const dl_gemm_args* a);
+int dl_gemm(const dl_gemm_args* a, dl_stream s);
+
+/* column sums: out[n] (+)= sum_m X[m,n] — bias gradients of every Linear above. */
+int dl_colsum(const void* X, int64_t ldx, int64_t M, int64_t N, int32_t dtype, float* out,
+              int32_t accumulate, void* workspace, size_t workspace_bytes, dl_stream s);
+size_t dl_colsum_workspace_bytes(int64_t M, int64_t N);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (eps 1e-6 inside PMMA: model/PMMA/block.py:23-27,
+ * model/PMMA/encoder.py:31; eps 1e-5 for v/x_gca_norm: model/basic_model.py:115,118).
+ * fwd: y = (x - mean) * rstd * gamma + beta ; mean/rstd [M] f32 saved for bwd (may be NULL).
+ * bwd: dx = LN'(dy) (+ dres if given); dgamma/dbeta [D] f32 (+)= column reductions.
+ * ------------------------------------------------------------------------------------------ */
+int dl_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
+                     int64_t ldy, float* mean, float* rstd, int64_t M, int64_t D, float eps,
+                     int32_t dtype, dl_stream s);
+size_t dl_layernorm_bwd_workspace_bytes(int64_t M, int64_t D);
+int dl_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean,
+                     const float* rstd, const float* gamma, const void* dres, int64_t lddres,
+                     void* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
+                     int64_t M, int64_t D, int32_t dtype, void* workspace, size_t workspace_bytes,
+                     dl_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused attention: O = softmax(scale * Q K^T) V, no mask, no dropout
+ * (attention_dropout_rate = 0, configs/default_config.py:81; PGCA dropout = 0).
+ *
+ * One launch covers `n_problems` independent (K,V) sets ("problems" = batch x streams), each
+ * with n_heads heads.  Every problem has 1 or 2 query SEGMENTS of Lq rows each that attend to
+ * the SAME K/V — this is Attention.paired_attention (model/PMMA/attention.py:44-88): segment 0
+ * is the stream's own q, segment 1 the other stream's q ("guided" attention), and the two
+ * outputs land side by side ([attn | attn_p], the torch.cat at attention.py:81).
+ * n_segments == 1 gives plain self attention (attention.py:109-122, head dim 128) and PGCA's
+ * cross attention (guided_cross_attention_model.py:290-311; Lq=256, Lk=512, 1 head).
+ *
+ * Addressing (element strides, all tensors dtype `dtype`, head dim contiguous):
+ *   own q   (p, h, r, :)   = Q + p*q_ps + h*q_hs + r*q_rs
+ *   segment 0 of problem p queries with Q(p); segment 1 with Q(partner(p)),
+ *       partner(p) = (p + partner_shift) % n_problems      (paired streams: [stream][batch]
+ *       ordering, partner_shift = batch)
+ *   k/v     (p, h, r, :)   = K + p*k_ps + h*k_hs + r*k_rs  (same for V with v_*)
+ *   o  (seg, p, h, r, :)   = O + seg*o_ss + p*o_ps + h*o_hs + r*o_rs
+ *   lse(seg, p, h, r)      = LSE + ((seg*n_problems + p)*n_heads + h)*Lq + r  (f32, natural log)
+ * raw_logits (optional, f32): scale*QK^T before softmax, [p][h][Lq][Lk] for segment 0 —
+ * what GuidedCrossAttention returns as its 2nd output (guided_cross_attention_model.py:307,316-320).
+ * head_dim in {64, 128}; strides multiples of 16 bytes; Lq, Lk arbitrary (tails are masked).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* Q; const void* K; const void* V; void* O; float* LSE; float* raw_logits;
+  int64_t q_ps, q_hs, q_rs, k_ps, k_hs, k_rs, v_ps, v_hs, v_rs, o_ps, o_hs, o_rs, o_ss;
+  int32_t n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, dtype;
+  float scale;
+} dl_attn_fwd_args;
+int dl_attn_fwd(const dl_attn_fwd_args* a, dl_stream s);
+
+/* Backward.  dO is addressed like O (do_* strides); Delta has the shape of LSE and is scratch
+ * filled by the call (rowsum(dO*O)).  dQ(p) receives BOTH contributions of q tensor p (its own
+ * attention's segment 0 and its partner attention's segment 1) from one workgroup — nothing is
+ * accumulated across launches and the result is deterministic.  dK/dV(p) sum over the segments
+ * of attention p.  All three are overwritten. */
+typedef struct {
+  const void* Q; const void* K; const void* V; const void* O; const void* dO;
+  const float* LSE; float* Delta;
+  void* dQ; void* dK; void* dV;
+  int64_t q_ps, q_hs, q_rs, k_ps, k_hs, k_rs, v_ps, v_hs, v_rs, o_ps, o_hs, o_rs, o_ss;
+  int64_t do_ps, do_hs, do_rs, do_ss, dq_ps, dq_hs, dq_rs, dk_ps, dk_hs, dk_rs, dv_ps, dv_hs, dv_rs;
+  int32_t n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, dtype;
+  float scale;
+} dl_attn_bwd_args;
+int dl_attn_bwd(const dl_attn_bwd_args* a, dl_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * MHLA token gate (MultiHeadLinearAttention.forward, model/PMMA/encoder.py:127-140):
+ * logits [B][L][H] -> g = softmax over L (per b, per h); out = flat-reinterpreted product:
+ * within sample b, flat index f = (j*L + l)*hd + c (j<H, hd = D/H) of the contiguous [L][D]
+ * buffer is scaled by g[b][l][j].  (NOT a head split — the reference does a .view on the
+ * contiguous (B,L,D) tensor.)  out = v * gate (+ v if add_residual, the caller's `mv + hv`).
+ * bwd: dv, dlogits.
+ * ------------------------------------------------------------------------------------------ */
+int dl_token_gate_fwd(const void* v, const void* logits, void* out, float* gate_out, int64_t B,
+                      int64_t L, int64_t D, int32_t H, int32_t add_residual, int32_t dtype,
+                      dl_stream s);
+int dl_token_gate_bwd(const void* dout, const void* v, const float* gate, void* dv, void* dlogits,
+                      int64_t B, int64_t L, int64_t D, int32_t H, int32_t add_residual,
+                      int32_t dtype, dl_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise helpers on the path.
+ * ------------------------------------------------------------------------------------------ */
+/* y = dropout(x + pe[row % L]) — Embeddings.forward prot branch (model/PMMA/embed.py:51-52). */
+int dl_add_rowmod_dropout(const void* x, const void* pe, void* y, int64_t M, int64_t D,
+                          int64_t L, float p, uint64_t seed, int32_t dtype, dl_stream s);
+/* y = dropout_mask(seed)(x) / (1-p) — regenerates a forward mask for the backward pass. */
+int dl_dropout_apply(const void* x, void* y, int64_t n_rows, int64_t D, int64_t ldx, int64_t ldy,
+                     float p, uint64_t seed, int32_t dtype, dl_stream s);
+/* dst(bf16|f32) = src(f32|bf16) elementwise cast (weight casts, master fp32 -> compute dtype). */
+int dl_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n,
+            dl_stream s);
+/* out[d] (+)= sum over rows r of x[r][d] where rows are grouped by (r % L): pe gradients. */
+int dl_rowmod_sum(const void* x, float* out, int64_t M, int64_t D, int64_t L, int32_t accumulate,
+                  int32_t dtype, dl_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss kernels.
+ * cos_rowloss: SimSiam loss_fn (model/self_supervised_learning.py:184-187):
+ *   per row r: 2 - 2*cos(x_r, y_r); out_sum (+)= sum_r.  bwd gives dx (y is a detached target).
+ * ntxent_stream: nt_xent_loss (self_supervised_learning.py:168-182): P = [q;k] (2n x d),
+ *   logits = P P^T / T with the diagonal removed, positive of i is i+n (mod 2n), loss = sum CE / 2n,
+ *   computed by streaming tiles with an online log-sum-exp; never materialises (2n)^2.
+ * triplet_sigcos: ccpp_p_tri_loss (model/cross_modality.py:15-47) with distance
+ *   1 - sigmoid(cos) (utils.py:571-574): all-pairs sigmoid(cos) matrix once, then the masked
+ *   triplet reduction over the label matrix gt[n_p][n_d] (1 positive, 0 negative, -1 ignore).
+ * ------------------------------------------------------------------------------------------ */
+int dl_cos_rowloss_fwd(const float* x, const float* y, float* row_loss, float* loss_sum,
+                       int64_t n_rows, int64_t D, dl_stream s);
+int dl_cos_rowloss_bwd(const float* x, const float* y, float grad_scale, float* dx, int64_t n_rows,
+                       int64_t D, dl_stream s);
+size_t dl_ntxent_workspace_bytes(int64_t n, int64_t d);
+int dl_ntxent_fwd(const float* q, const float* k, int64_t n, int64_t d, float temperature,
+                  float* loss, float* row_lse, void* workspace, size_t workspace_bytes,
+                  dl_stream s);
+int dl_ntxent_bwd(const float* q, const float* k, int64_t n, int64_t d, float temperature,
+                  const float* row_lse, float grad_out, float* dq, float* dk, dl_stream s);
+/* `dist` must hold dl_triplet_sigcos_buffer_floats(n_p, n_d) floats: the (n_p x n_d) distance matrix
+ * first, then scratch that dl_triplet_sigcos_bwd reuses (pass the same buffer). */
+size_t dl_triplet_sigcos_buffer_floats(int64_t n_p, int64_t n_d);
+int dl_triplet_sigcos_fwd(const float* p_lats, const float* d_lats, const int8_t* gt, int64_t n_p,
+                          int64_t n_d, int64_t dim, float margin, float* dist, float* loss,
+                          float* n_tri, dl_stream s);
+int dl_triplet_sigcos_bwd(const float* p_lats, const float* d_lats, const int8_t* gt,
+                          const float* dist, int64_t n_p, int64_t n_d, int64_t dim, float margin,
+                          const float* n_tri, float grad_out, float* dp, float* dd, dl_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused AdamW over a flat fp32 parameter arena (torch.optim.AdamW semantics, decoupled weight
+ * decay, bias correction; trainer.py:225-229 steps up to three of these per batch).
+ * step is the 1-based step count AFTER increment.  Optionally emits a compute-dtype copy.
+ * ------------------------------------------------------------------------------------------ */
+int dl_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                  float grad_scale, void* param_lowp, int32_t lowp_dtype, dl_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel timing hooks used by bench.py for the roofline object: when enabled for a kernel
+ * family, each launch is bracketed by hipEventRecord on its own stream.
+ * family: 0 gemm, 1 attn_fwd, 2 attn_bwd, 3 layernorm.
+ * dl_prof_collect synchronises the recorded events and returns launches / total ms / total
+ * algorithmic flops / total algorithmic bytes since dl_prof_enable.
+ * ------------------------------------------------------------------------------------------ */
+int dl_prof_enable(int32_t family, int32_t on);
+int dl_prof_collect(int32_t family, int64_t* launches, double* total_ms, double* total_flops,
+                    double* total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRUGLAMP_HIP_H */
