@@ -1,0 +1,37 @@
+"""Synthetic DrugLAMP inputs (test infrastructure): numpy only, deterministic.
+
+`model_inputs` mimics what the reference's collate hands the model (utils.py:304-334): post-GCN drug
+node features zero-padded to 512 nodes, ChemBERTa token embeddings zero-padded to 512, the ESM-2
+block of an (Lp+2)-token protein tiled to 2304 positions (repeat_pad) with zero tail, and the integer
+residue codes tiled with the same period (stored as float64, as the reference does).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import detgen
+
+
+def model_inputs(tag: str, B: int, salt: int = 0):
+    """Synthetic pre-extracted inputs with the padding structure of the real collate (utils.py:326-334)."""
+    rs = np.random.RandomState(1234 + salt)
+    vd = detgen.normalish(tag + ".vd", (B, 512, 128), salt).copy()
+    xd = detgen.normalish(tag + ".xd", (B, 512, 384), salt).copy()
+    xp = np.zeros((B, 2304, 640), dtype=np.float32)
+    vp = np.zeros((B, 2304), dtype=np.float64)
+    for b in range(B):
+        n_atom = int(rs.randint(10, 80))
+        vd[b, n_atom:] = 0
+        n_tok = int(rs.randint(12, 128))
+        xd[b, n_tok:] = 0
+        Lp = int(rs.randint(100, 600))
+        seq = rs.randint(1, 26, size=Lp).astype(np.float64)
+        blk = detgen.normalish("%s.xp%d" % (tag, b), (Lp + 2, 640), salt)
+        reps = 2304 // (Lp + 2)
+        for r in range(reps):
+            xp[b, r * (Lp + 2):(r + 1) * (Lp + 2)] = blk
+            vp[b, r * (Lp + 2) + 1: r * (Lp + 2) + 1 + Lp] = seq
+    y = (detgen.uniform(tag + ".y", (B,), salt=salt) > 0).astype(np.float32)
+    return vd, vp, xd, xp, y
+
+

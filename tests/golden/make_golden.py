@@ -1,0 +1,352 @@
+"""Generate the committed golden fixtures by running the REAL reference in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Weights and inputs come from oracle/detgen.py (regenerated bit-identically by the tests), so the
+.npz files hold only the reference's OUTPUTS (full tensors where small, sub-samples + row norms
+where large).  Nothing from /root/reference is copied: the fixtures are data.
+"""
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import ref_harness  # noqa: E402
+from oracle import detgen, synth  # noqa: E402
+
+ref_harness.import_reference()
+torch.set_num_threads(8)
+
+
+def fill_module(mod: torch.nn.Module, salt: int = 0):
+    sd = mod.state_dict()
+    vals = detgen.fill_state_dict([(k, tuple(v.shape), str(v.dtype)) for k, v in sd.items()], salt)
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+    return mod
+
+
+def T(name, shape, scale=1.0, salt=0):
+    return torch.from_numpy(detgen.normalish(name, shape, salt) * np.float32(scale))
+
+
+def sub(x: torch.Tensor):
+    """sub-sample of a big (B, L, D) tensor: first/last 4 rows, per-row norms, checksum."""
+    x = x.detach().double()
+    return {"head": x[:, :4].float().numpy(), "tail": x[:, -4:].float().numpy(),
+            "rownorm": x.norm(dim=-1).float().numpy(), "sum": np.float64(x.sum().item())}
+
+
+def sd_spec(mod):
+    import json
+    return np.asarray(json.dumps([(k, list(v.shape), str(v.dtype).replace("torch.", "")) for k, v in mod.state_dict().items()]))
+
+
+def save(name, **arrs):
+    flat = {}
+    for k, v in arrs.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat["%s/%s" % (k, kk)] = np.asarray(vv)
+        else:
+            flat[k] = v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def pmma_config(L):
+    from configs import get_model_defaults
+    cfg = get_model_defaults(128)
+    cfg.feat_len = L
+    cfg.mol_len = L
+    cfg.transformer.dropout_rate = 0.0
+    return cfg
+
+
+def grad_norms(mod):
+    return {k: np.float64(p.grad.double().norm().item()) for k, p in mod.named_parameters() if p.grad is not None}
+
+
+def gen_pmma():
+    from model.PMMA import PairedMultimodelAttention
+    for tag, L in (("pmma_mid", 64), ("pmma_full", 256)):
+        m = fill_module(PairedMultimodelAttention(pmma_config(L), vis=True)).eval()
+        prot = T(tag + ".prot", (2, L, 256)).requires_grad_(True)
+        mol = T(tag + ".mol", (2, L, 256)).requires_grad_(True)
+        enc, w, gw = m(prot, mol)
+        G = T(tag + ".G", tuple(enc.shape))
+        (enc * G).sum().backward()
+        gn = grad_norms(m)
+        out = dict(sd=sd_spec(m), gradnorm=gn, w0=w[0][:, :, :4, :8], gw0=gw[0][:, :, :4, :8], w3=w[3][:, :, :4, :8])
+        if L == 64:
+            out.update(encoded=enc, dprot=prot.grad, dmol=mol.grad,
+                       dW_l0_query=m.encoder.layer_with_mol[0].attn.query.weight.grad[:8, :16],
+                       dW_l3_fc2=m.encoder.layer_with_mol[3].ffn.fc2.weight.grad[:8, :16],
+                       db_l1_fc_mol=m.encoder.layer_with_mol[1].attn.fc_mol.bias.grad,
+                       dpe_mol=m.embeddings.pe_mol.grad[0, :4, :16])
+        else:
+            out.update(encoded=sub(enc), dprot=sub(prot.grad), dmol=sub(mol.grad))
+        save(tag, **out)
+
+
+def gen_pgca():
+    from model.PGCA.guided_cross_attention_model import GuidedCrossAttention
+    m = fill_module(GuidedCrossAttention(embed_dim=128, num_heads=1)).eval()
+    for tag, (Lq, Lk, B) in (("pgca_small", (48, 80, 3)), ("pgca_full", (256, 512, 2))):
+        q = T(tag + ".q", (Lq, B, 128)).requires_grad_(True)
+        kv = T(tag + ".kv", (Lk, B, 128)).requires_grad_(True)
+        m.zero_grad()
+        out, raw = m(q, kv, kv)
+        G = T(tag + ".G", tuple(out.shape))
+        (out * G).sum().backward()
+        save(tag, sd=sd_spec(m), out=out, raw=raw[:, :, :8, :16], rawnorm=raw.double().norm(dim=-1).float(), dq=q.grad, dkv=kv.grad,
+             gradnorm=grad_norms(m))
+
+
+def gen_mhla():
+    from model.PMMA import MultiHeadLinearAttention
+    for tag, (d, dd, B, L) in (("mhla_toy", (32, 64, 2, 5)), ("mhla_full", (256, 1024, 2, 256))):
+        m = fill_module(MultiHeadLinearAttention(d_model=d, d_diff=dd, nhead=8, dropout=0, activation="gelu")).eval()
+        v = T(tag + ".v", (B, L, d)).requires_grad_(True)
+        out = m(v)
+        G = T(tag + ".G", tuple(out.shape))
+        (out * G).sum().backward()
+        save(tag, sd=sd_spec(m), out=out, dv=v.grad, gradnorm=grad_norms(m))
+
+
+def gen_losses():
+    import model.self_supervised_learning as S
+    import model.cross_modality as CMm
+    from utils import sigmoid_cosine_distance_p
+    out = {}
+    for tag, (n, d) in (("ntx_small", (24, 64)), ("ntx_big", (512, 128))):
+        q = T(tag + ".q", (n, d), 0.3).requires_grad_(True)
+        k = T(tag + ".k", (n, d), 0.3).requires_grad_(True)
+        loss = S.nt_xent_loss(q, k, temperature=0.1)
+        loss.backward()
+        out[tag + "/loss"] = loss
+        out[tag + "/dq"] = q.grad[:8]
+        out[tag + "/dk"] = k.grad[:8]
+    x = T("cos.x", (300, 128)).requires_grad_(True)
+    y = T("cos.y", (300, 128))
+    l = S.loss_fn(x, y)
+    l.mean().backward()
+    out["cos/rows"] = l
+    out["cos/dx"] = x.grad
+    # triplet loss over an explicit label dict (ccpp_p_tri_loss with the margin-scheduled distance loss)
+    n_p, n_d = 12, 17
+    pl = torch.nn.functional.normalize(T("tri.p", (n_p, 256)), dim=-1).requires_grad_(True)
+    dl = torch.nn.functional.normalize(T("tri.d", (n_d, 256)), dim=-1).requires_grad_(True)
+    gtm = (detgen.uniform("tri.gt", (n_p, n_d)) > 0.3).astype(np.int8)
+    gtm[0] = 0
+    gtm[1] = 1
+    pid2t = {"p%d" % i: i for i in range(n_p)}
+    did2t = {"d%d" % j: j for j in range(n_d)}
+    gt = {"p%d" % i: {"d%d" % j: int(gtm[i, j]) for j in range(n_d)} for i in range(n_p)}
+    lf = torch.nn.TripletMarginWithDistanceLoss(distance_function=sigmoid_cosine_distance_p, margin=0.3, reduction="sum")
+    tl = CMm.ccpp_p_tri_loss(lf, gt, pid2t, did2t, pl, dl)
+    tl.backward()
+    out.update({"tri/loss": tl, "tri/dp": pl.grad, "tri/dd": dl.grad, "tri/gt": gtm})
+    # margin schedule
+    sch = CMm.MarginScheduledLossFunction(CMm.ccpp_p_tri_loss, m_ori=0.5, n_re=100)
+    margins = [sch.margin]
+    for _ in range(205):
+        sch.step()
+        margins.append(sch.margin)
+    out["margins"] = np.asarray(margins, dtype=np.float64)
+    save("losses", **out)
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole models
+# ---------------------------------------------------------------------------------------------------
+class _PassThrough(torch.nn.Module):
+    def forward(self, x):
+        return x
+
+
+def model_inputs(tag, B, salt=0):
+    return tuple(torch.from_numpy(a) for a in synth.model_inputs(tag, B, salt))
+
+
+def build_model(kind):
+    import importlib
+    cfg = ref_harness.default_cfg()
+    Model = getattr(importlib.import_module("model." + kind), kind)
+    m = Model(n_drug_feature=384, n_prot_feature=640, n_hidden=128, **cfg)
+    m.drug_extractor = _PassThrough()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m
+
+
+def gen_models():
+    for kind in ("DrugLAMP", "DrugLAMP2C2P", "DrugLAMPwoLLM"):
+        torch.manual_seed(0)
+        m = build_model(kind)
+        vd, vp, xd, xp, y = model_inputs("model." + kind, 2)
+        fill_module(m)
+        m.eval()
+        with torch.no_grad():
+            vd_o, vp_o, ssl, cm, score = m(vd, vp, xd, xp)
+        out = dict(sd=sd_spec(m), score=score, vp=sub(vp_o), A_v=m.A_v_gca[:, :, :4, :8])
+        if kind != "DrugLAMPwoLLM":
+            out["A_x"] = m.A_x_gca[:, :, :4, :8]
+        if cm is not None:
+            out["cm_aug_prot"] = sub(cm["aug_prot"])
+            out["cm_aug_drug"] = sub(cm["aug_drug"])
+        # train-mode BN forward + cls-loss backward (dropout 0); B=8 so that the classifier's BatchNorm
+        # batch statistics are well conditioned
+        vd, vp, xd, xp, y = model_inputs("modeltrain." + kind, 8)
+        m.train()
+        m.zero_grad()
+        vd_o, vp_o, ssl, cm, score_t = m(vd, vp, xd, xp)
+        from model.basic_model import binary_cross_entropy
+        n, loss = binary_cross_entropy(score_t, y)
+        loss.backward()
+        out.update(score_train=score_t, cls_loss=loss, gradnorm=grad_norms(m))
+        save("model_" + kind, **out)
+
+
+def gen_ssl_cm():
+    """SSL (prot MLM with captured masks + SimSiam) and CM losses on a DrugLAMP2C2P instance."""
+    import model.self_supervised_learning as S
+    torch.manual_seed(0)
+    m = build_model("DrugLAMP2C2P")
+    B = 6
+    vd, vp, xd, xp, y = model_inputs("sslcm", B)
+    m.train()
+    vd_o, vp_o, ssl, cm, score = m(vd, vp, xd, xp)
+    m.ssl_model(**ssl)                      # creates the lazy SimSiam projectors
+    fill_module(m)
+    # capture the random draws of prot_mlm
+    cap = {}
+    real_subset, real_like = S.get_mask_subset_with_prob, S.prob_mask_like
+
+    def subset(mask, prob):
+        cap["mask"] = real_subset(mask, prob)
+        return cap["mask"]
+
+    def like(t, prob):
+        cap["replace"] = real_like(t, prob)
+        return cap["replace"]
+
+    S.get_mask_subset_with_prob, S.prob_mask_like = subset, like
+    torch.manual_seed(7)
+    m.zero_grad()
+    vd_o, vp_o, ssl, cm, score = m(vd, vp, xd, xp)
+    d = m.ssl_model(**ssl)
+    S.get_mask_subset_with_prob, S.prob_mask_like = real_subset, real_like
+    ((d["prot_ssl"] + d["drug_ssl"]) * 0.1).backward(retain_graph=True)
+    gn_ssl = grad_norms(m)
+    meta = []
+    pid = [0, 1, 0, 2, 3, 1]
+    did = [5, 5, 6, 7, 5, 8]
+    for t in range(B):
+        meta.append({"Prot_ID": pid[t], "Drug_ID": did[t], "Y": float(y[t])})
+    m.zero_grad()
+    cm_loss = m.cm_model(**cm, meta=meta)
+    cm_loss.backward()
+    gn_cm = grad_norms(m)
+    n_tok = int((vp != 0).sum())
+    save("ssl_cm", sd=sd_spec(m), prot_ssl=d["prot_ssl"], drug_ssl=d["drug_ssl"], cm_loss=cm_loss,
+         mask=np.packbits(cap["mask"].numpy()), replace=np.packbits(cap["replace"].numpy()),
+         n_masked=np.int64(cap["mask"].sum().item()), n_tok=np.int64(n_tok),
+         meta_pid=np.asarray(pid), meta_did=np.asarray(did), gradnorm_ssl=gn_ssl, gradnorm_cm=gn_cm)
+
+
+def gen_train_steps():
+    """trainer.py:179-231 driven by hand (Lightning is absent) with the reference model and three
+    torch.optim.AdamW over the SAME parameter list (main.py:158-160)."""
+    import model.self_supervised_learning as S
+    from model.basic_model import binary_cross_entropy
+    torch.manual_seed(0)
+    m = build_model("DrugLAMP2C2P")
+    B = 8
+    vd, vp, xd, xp, y = model_inputs("train", B)
+    m.train()
+    _, _, ssl, cm, _ = m(vd, vp, xd, xp)
+    m.ssl_model(**ssl)
+    fill_module(m)
+    params = list(m.parameters())               # NOTE: taken before... the lazy projectors are excluded
+    # reference: optimisers are built in main.py BEFORE the first SSL forward, so the lazily created
+    # projectors are in no optimiser.  Reproduce by filtering them out.
+    lazy = {id(p) for n, p in m.named_parameters() if ".projector." in n}
+    params = [p for p in params if id(p) not in lazy]
+    opt = torch.optim.AdamW(params, lr=1e-4)
+    opt_ssl = torch.optim.AdamW(params, lr=3e-5)
+    opt_cm = torch.optim.AdamW(params, lr=3e-5)
+    meta = [{"Prot_ID": [0, 1, 0, 2, 3, 1, 4, 0][t], "Drug_ID": [5, 5, 6, 7, 5, 8, 9, 7][t], "Y": float(y[t])} for t in range(B)]
+    masks = {"mask": [], "replace": []}
+    real_subset, real_like = S.get_mask_subset_with_prob, S.prob_mask_like
+
+    def subset(mask, prob):
+        r = real_subset(mask, prob)
+        masks["mask"].append(np.packbits(r.numpy()))
+        return r
+
+    def like(t, prob):
+        r = real_like(t, prob)
+        masks["replace"].append(np.packbits(r.numpy()))
+        return r
+
+    S.get_mask_subset_with_prob, S.prob_mask_like = subset, like
+    torch.manual_seed(11)
+    rec = {"cls": [], "ssl": [], "cm": [], "cm_weight": [], "delta": [], "pnorm": []}
+    cm_weight = 1.0
+    names = [n for n, p in m.named_parameters()]
+    for step, cur_epoch in enumerate([1, 5, 5, 6]):
+        compute_ssl = cur_epoch % 5 == 0
+        compute_cm = cur_epoch >= 5
+        before = torch.cat([p.detach().flatten() for p in params]).double()
+        _, _, ssl, cm, score = m(vd, vp, xd, xp)
+        opt.zero_grad()
+        _, cls_loss = binary_cross_entropy(score, y)
+        cls_loss.backward(retain_graph=compute_ssl or compute_cm)
+        ssl_v, cm_v = 0.0, 0.0
+        if compute_ssl:
+            opt_ssl.zero_grad()
+            d = m.ssl_model(**ssl)
+            ssl_loss = (d["prot_ssl"] + d["drug_ssl"]) * 0.1
+            ssl_loss.backward(retain_graph=compute_cm)
+            ssl_v = ssl_loss.item()
+        if compute_cm:
+            opt_cm.zero_grad()
+            cm_loss = m.cm_model(**cm, meta=meta)
+            if cur_epoch == 5 and cm_loss.item() > 0:
+                while cm_loss.item() * cm_weight / 10 > cls_loss.item():
+                    cm_weight /= 10
+                while cm_loss.item() * cm_weight * 10 < cls_loss.item():
+                    cm_weight *= 10
+            cm_loss = cm_loss * cm_weight
+            cm_loss.backward()
+            cm_v = cm_loss.item()
+        opt.step()
+        if compute_ssl:
+            opt_ssl.step()
+        if compute_cm:
+            opt_cm.step()
+        after = torch.cat([p.detach().flatten() for p in params]).double()
+        rec["cls"].append(cls_loss.item()); rec["ssl"].append(ssl_v); rec["cm"].append(cm_v)
+        rec["cm_weight"].append(cm_weight)
+        rec["delta"].append((after - before).norm().item()); rec["pnorm"].append(after.norm().item())
+    S.get_mask_subset_with_prob, S.prob_mask_like = real_subset, real_like
+    save("train_steps", sd=sd_spec(m), cls=np.asarray(rec["cls"]), ssl=np.asarray(rec["ssl"]), cm=np.asarray(rec["cm"]),
+         cm_weight=np.asarray(rec["cm_weight"]), delta=np.asarray(rec["delta"]), pnorm=np.asarray(rec["pnorm"]),
+         masks=np.stack(masks["mask"]), replaces=np.stack(masks["replace"]))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["pmma", "pgca", "mhla", "losses", "models", "sslcm", "train"]
+    table = dict(pmma=gen_pmma, pgca=gen_pgca, mhla=gen_mhla, losses=gen_losses, models=gen_models, sslcm=gen_ssl_cm,
+                 train=gen_train_steps)
+    for w in which:
+        table[w]()
