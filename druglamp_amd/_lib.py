@@ -123,7 +123,15 @@ def lib():
     return _lib
 
 
+_DEBUG_SYNC = bool(os.environ.get("DL_DEBUG_SYNC"))
+
+
 def check(rc: int, what: str = "") -> None:
+    if _DEBUG_SYNC:           # debugging aid: surface asynchronous faults at the launch that caused them
+        import sys
+        import torch
+        print("[dl] %s" % what, file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
     if rc != 0:
         msg = lib().dl_last_error()
         raise RuntimeError("druglamp_hip %s failed (status %d): %s" % (what, rc, msg.decode() if msg else "?"))

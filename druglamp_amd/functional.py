@@ -1,0 +1,460 @@
+"""Block-level autograd Functions of the hot path with hand-written backward passes.
+
+Each Function is a fixed sequence of libdruglamp_hip launches (druglamp_amd/ops.py) — forward and
+backward — so autograd sees ONE node per transformer block / attention module instead of ~20 eager
+ops, nothing is re-derived by a tracing compiler, and what is saved for backward is chosen by hand.
+
+Reference semantics restated here (see oracle/druglamp_oracle.py for the plain-torch version):
+  PMMABlock.forward          model/PMMA/block.py:33-62
+  Attention.forward          model/PMMA/attention.py:90-127 (+ paired_attention 44-88)
+  Mlp.forward                model/PMMA/mlp.py:44-50
+  Embeddings.forward         model/PMMA/embed.py:38-54
+  GuidedCrossAttention       model/PGCA/guided_cross_attention_model.py:15-329
+  MultiHeadLinearAttention   model/PMMA/encoder.py:127-140
+"""
+from __future__ import annotations
+
+import math
+import weakref
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+# ------------------------------------------------------------------------------------------------
+# compute-dtype copies of fp32 master parameters, cached per optimiser epoch
+# ------------------------------------------------------------------------------------------------
+_param_epoch = 0
+_lowp_cache = {}
+
+
+def bump_param_epoch() -> None:
+    """Call after parameters were modified through raw pointers (the fused AdamW kernel)."""
+    global _param_epoch
+    _param_epoch += 1
+    _lowp_cache.clear()
+
+
+def lowp(params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+    """Compute-dtype tensor holding cat(params, dim=0) (a single param is returned as is in fp32).
+
+    Cached per (parameter objects, their versions, optimiser epoch).  Entries hold WEAK references and
+    are validated by identity: a Python id can be reused by a new tensor once the old model is gone."""
+    key = (tuple(id(p) for p in params), dtype)
+    ver = (_param_epoch,) + tuple(p._version for p in params)
+    hit = _lowp_cache.get(key)
+    if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
+        return hit[1]
+    with torch.no_grad():
+        w = params[0].detach() if len(params) == 1 else torch.cat([p.detach() for p in params], dim=0)
+        if w.dtype != dtype:
+            w = ops.cast(w, dtype)
+        elif not w.is_contiguous():
+            w = w.contiguous()
+    if len(_lowp_cache) > 4096:
+        _lowp_cache.clear()
+    _lowp_cache[key] = (ver, w, tuple(weakref.ref(p) for p in params))
+    return w
+
+
+def _f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.detach()
+
+
+# ------------------------------------------------------------------------------------------------
+# transformer block (paired: two streams + guided attention; self: one stream)
+# ------------------------------------------------------------------------------------------------
+# parameter order per stream (18 tensors paired / 16 self):
+#   ln1.w ln1.b  q.w q.b k.w k.b v.w v.b  [fc.w fc.b]  out.w out.b  ln2.w ln2.b  fc1.w fc1.b fc2.w fc2.b
+def _n_params(paired: bool) -> int:
+    return 18 if paired else 16
+
+
+class _Stream:
+    """Unpacked per-stream parameter views for one block call."""
+
+    def __init__(self, ps: Sequence[torch.Tensor], paired: bool, cdt: torch.dtype):
+        it = iter(ps)
+        self.ln1w, self.ln1b = next(it), next(it)
+        qw, qb, kw, kb, vw, vb = (next(it) for _ in range(6))
+        self.qkv_w = lowp((qw, kw, vw), cdt)
+        self.qkv_b = lowp((qb, kb, vb), torch.float32)
+        if paired:
+            fw, fb = next(it), next(it)
+            self.fc_w, self.fc_b = lowp((fw,), cdt), _f32(fb)
+        ow, ob = next(it), next(it)
+        self.out_w, self.out_b = lowp((ow,), cdt), _f32(ob)
+        self.ln2w, self.ln2b = next(it), next(it)
+        w1, b1, w2, b2 = (next(it) for _ in range(4))
+        self.w1, self.b1 = lowp((w1,), cdt), _f32(b1)
+        self.w2, self.b2 = lowp((w2,), cdt), _f32(b2)
+
+
+class TransformerBlockFn(torch.autograd.Function):
+    """x: [S, B, L, d] (S = 2 stacked streams when paired, else 1).  Returns the same shape."""
+
+    @staticmethod
+    def forward(ctx, x, paired, H, p_drop, training, eps, *params):
+        S, B, L, d = x.shape
+        assert S == (2 if paired else 1)
+        cdt = x.dtype
+        M = B * L
+        npar = _n_params(paired)
+        streams = [_Stream(params[s * npar:(s + 1) * npar], paired, cdt) for s in range(S)]
+        x = x.contiguous()
+        xs = [x[s].reshape(M, d) for s in range(S)]
+        nseg = 2 if paired else 1
+        hd = d // H
+        p_eff = float(p_drop) if (training and p_drop > 0) else 0.0
+
+        qkv = torch.empty((S, M, 3 * d), dtype=cdt, device=x.device)
+        xn, stats1 = [], []
+        for s, st in enumerate(streams):
+            y, mean, rstd = ops.layernorm_fwd(xs[s], st.ln1w.detach(), st.ln1b.detach(), eps)
+            xn.append(y)
+            stats1.append((mean, rstd))
+            ops.gemm(y, st.qkv_w, M=M, N=3 * d, K=d, bias=st.qkv_b, out=qkv[s])
+        a = torch.empty((S, M, nseg * d), dtype=cdt, device=x.device)
+        qs = (L * 3 * d, hd, 3 * d)
+        os_ = (L * nseg * d, hd, nseg * d)
+        lse = ops.attn_fwd(qkv, qkv[..., d:], qkv[..., 2 * d:], n_problems=S * B, n_heads=H, n_segments=nseg,
+                           partner_shift=B if paired else 0, Lq=L, Lk=L, head_dim=hd, scale=1.0 / math.sqrt(hd),
+                           q_strides=qs, k_strides=qs, v_strides=qs, out=a, o_strides=os_, o_ss=d)
+        out = torch.empty_like(x)
+        saved: List[torch.Tensor] = [x, qkv, a, lse]
+        seeds = []
+        for s, st in enumerate(streams):
+            if paired:
+                f = ops.gemm(a[s], st.fc_w, M=M, N=d, K=2 * d, bias=st.fc_b)
+            else:
+                f = a[s]
+            x1 = ops.gemm(f, st.out_w, M=M, N=d, K=d, bias=st.out_b, residual=xs[s])
+            hn, mean2, rstd2 = ops.layernorm_fwd(x1, st.ln2w.detach(), st.ln2b.detach(), eps)
+            pre = torch.empty((M, 4 * d), dtype=cdt, device=x.device)
+            s1 = ops.next_seed() if p_eff > 0 else 0
+            s2 = ops.next_seed() if p_eff > 0 else 0
+            act = ops.gemm(hn, st.w1, M=M, N=4 * d, K=d, bias=st.b1, act=1, pre_out=pre, dropout_p=p_eff, seed=s1)
+            ops.gemm(act, st.w2, M=M, N=d, K=4 * d, bias=st.b2, dropout_p=p_eff, seed=s2, residual=x1,
+                     out=out[s].reshape(M, d))
+            seeds.append((s1, s2))
+            saved += [xn[s], stats1[s][0], stats1[s][1], f if paired else a[s], x1, hn, mean2, rstd2, pre, act,
+                      st.qkv_w, st.out_w, st.w1, st.w2, st.fc_w if paired else st.out_w,
+                      st.ln1w.detach(), st.ln2w.detach()]
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (paired, H, p_eff, S, B, L, d, seeds)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        paired, H, p_eff, S, B, L, d, seeds = ctx.cfg
+        sv = ctx.saved_tensors
+        x, qkv, a, lse = sv[:4]
+        per = 17
+        M = B * L
+        nseg = 2 if paired else 1
+        hd = d // H
+        cdt = x.dtype
+        dout = dout.contiguous()
+        da = torch.empty_like(a)
+        dx1_all = []
+        grads_tail = []     # per stream: param grads produced after attention (fc/out/ln2/mlp)
+        for s in range(S):
+            (xn, mean1, rstd1, f, x1, hn, mean2, rstd2, pre, act, qkv_w, out_w, w1, w2, fc_w, ln1w, ln2w) = \
+                sv[4 + s * per: 4 + (s + 1) * per]
+            dy = dout[s].reshape(M, d)
+            s1, s2 = seeds[s]
+            g2 = ops.dropout_apply(dy, p_eff, s2) if p_eff > 0 else dy
+            dw2 = ops.gemm(g2, act, M=d, N=4 * d, K=M, x_kslow=True, w_kslow=True, ldx=d, ldw=4 * d,
+                           out_dtype=torch.float32, split_k=0)
+            db2 = ops.colsum(g2)
+            g1 = ops.gemm(g2, w2, M=M, N=4 * d, K=d, w_kslow=True, ldw=4 * d, dact_pre=pre, dropout_p=p_eff, seed=s1)
+            dw1 = ops.gemm(g1, hn, M=4 * d, N=d, K=M, x_kslow=True, w_kslow=True, ldx=4 * d, ldw=d,
+                           out_dtype=torch.float32, split_k=0)
+            db1 = ops.colsum(g1)
+            dhn = ops.gemm(g1, w1, M=M, N=d, K=4 * d, w_kslow=True, ldw=d)
+            dx1, dg2, dbt2 = ops.layernorm_bwd(dhn, x1, mean2, rstd2, ln2w, dres=dy)
+            dwo = ops.gemm(dx1, f, M=d, N=d, K=M, x_kslow=True, w_kslow=True, ldx=d, ldw=d, out_dtype=torch.float32,
+                           split_k=0)
+            dbo = ops.colsum(dx1)
+            if paired:
+                df = ops.gemm(dx1, out_w, M=M, N=d, K=d, w_kslow=True, ldw=d)
+                dwf = ops.gemm(df, a[s], M=d, N=2 * d, K=M, x_kslow=True, w_kslow=True, ldx=d, ldw=2 * d,
+                               out_dtype=torch.float32, split_k=0)
+                dbf = ops.colsum(df)
+                ops.gemm(df, fc_w, M=M, N=2 * d, K=d, w_kslow=True, ldw=2 * d, out=da[s])
+                grads_tail.append((dwf, dbf, dwo, dbo, dg2, dbt2, dw1, db1, dw2, db2))
+            else:
+                ops.gemm(dx1, out_w, M=M, N=d, K=d, w_kslow=True, ldw=d, out=da[s])
+                grads_tail.append((dwo, dbo, dg2, dbt2, dw1, db1, dw2, db2))
+            dx1_all.append(dx1)
+        # attention backward: dqkv [S, M, 3d]
+        dqkv = torch.empty_like(qkv)
+        qs = (L * 3 * d, hd, 3 * d)
+        os_ = (L * nseg * d, hd, nseg * d)
+        ops.attn_bwd(qkv, qkv[..., d:], qkv[..., 2 * d:], a, da, lse, n_problems=S * B, n_heads=H, n_segments=nseg,
+                     partner_shift=B if paired else 0, Lq=L, Lk=L, head_dim=hd, scale=1.0 / math.sqrt(hd),
+                     q_strides=qs, k_strides=qs, v_strides=qs, o_strides=os_, o_ss=d, do_strides=os_, do_ss=d,
+                     dq=dqkv, dq_strides=qs, dk=dqkv[..., d:], dk_strides=qs, dv=dqkv[..., 2 * d:], dv_strides=qs)
+        dx = torch.empty_like(x)
+        out_grads: List[Optional[torch.Tensor]] = []
+        for s in range(S):
+            (xn, mean1, rstd1, f, x1, hn, mean2, rstd2, pre, act, qkv_w, out_w, w1, w2, fc_w, ln1w, ln2w) = \
+                sv[4 + s * per: 4 + (s + 1) * per]
+            g = dqkv[s]
+            dwqkv = ops.gemm(g, xn, M=3 * d, N=d, K=M, x_kslow=True, w_kslow=True, ldx=3 * d, ldw=d,
+                             out_dtype=torch.float32, split_k=0)
+            dbqkv = ops.colsum(g)
+            dxn = ops.gemm(g, qkv_w, M=M, N=d, K=3 * d, w_kslow=True, ldw=d)
+            dxs, dg1, dbt1 = ops.layernorm_bwd(dxn, x[s].reshape(M, d), mean1, rstd1, ln1w, dres=dx1_all[s])
+            dx[s].reshape(M, d).copy_(dxs)
+            out_grads += [dg1, dbt1, dwqkv[0:d], dbqkv[0:d], dwqkv[d:2 * d], dbqkv[d:2 * d], dwqkv[2 * d:],
+                          dbqkv[2 * d:]]
+            out_grads += list(grads_tail[s])
+        return (dx, None, None, None, None, None) + tuple(out_grads)
+
+
+def transformer_block(x, paired: bool, H: int, p_drop: float, training: bool, eps: float, params):
+    return TransformerBlockFn.apply(x, paired, H, p_drop, training, eps, *params)
+
+
+# ------------------------------------------------------------------------------------------------
+# plain Linear (+ optional row-mod positional add and dropout), LayerNorm
+# ------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b                                     (mode 'plain')
+       y = dropout(x W^T + b + pe[row % L])               (mode 'pe_drop', Embeddings.mol_embeddings)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pe, p_drop, training):
+        cdt = x.dtype
+        K, N = x.shape[-1], weight.shape[0]
+        x2 = x.reshape(-1, K).contiguous()
+        M = x2.shape[0]
+        w = lowp((weight,), cdt)
+        p_eff = float(p_drop) if (training and p_drop > 0) else 0.0
+        seed = ops.next_seed() if p_eff > 0 else 0
+        if pe is None:
+            y = ops.gemm(x2, w, M=M, N=N, K=K, bias=_f32(bias))
+        else:
+            pe2 = lowp((pe,), cdt).reshape(-1, N)
+            y = ops.gemm(x2, w, M=M, N=N, K=K, bias=_f32(bias), residual=pe2, res_row_mod=pe2.shape[0],
+                         res_before_dropout=True, dropout_p=p_eff, seed=seed)
+        ctx.save_for_backward(x2, w)
+        ctx.cfg = (x.shape, M, N, K, p_eff, seed, bias is not None, None if pe is None else tuple(pe.shape))
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        xshape, M, N, K, p_eff, seed, has_bias, pe_shape = ctx.cfg
+        g = dy.reshape(M, N).contiguous()
+        if p_eff > 0:
+            g = ops.dropout_apply(g, p_eff, seed)
+        dx = ops.gemm(g, w, M=M, N=K, K=N, w_kslow=True, ldw=K).reshape(xshape) if ctx.needs_input_grad[0] else None
+        dw = ops.gemm(g, x2, M=N, N=K, K=M, x_kslow=True, w_kslow=True, ldx=N, ldw=K, out_dtype=torch.float32,
+                      split_k=0) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(g) if (has_bias and ctx.needs_input_grad[2]) else None
+        dpe = None
+        if pe_shape is not None and ctx.needs_input_grad[3]:
+            dpe = ops.rowmod_sum(g, pe_shape[-2]).reshape(pe_shape)
+        return dx, dw, db, dpe, None, None
+
+
+def linear(x, weight, bias=None):
+    return LinearFn.apply(x, weight, bias, None, 0.0, False)
+
+
+class AddPeDropoutFn(torch.autograd.Function):
+    """y = dropout(x + pe[row % L])  — Embeddings.forward prot branch (embed.py:51-52)."""
+
+    @staticmethod
+    def forward(ctx, x, pe, p_drop, training):
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D).contiguous()
+        p_eff = float(p_drop) if (training and p_drop > 0) else 0.0
+        seed = ops.next_seed() if p_eff > 0 else 0
+        y = ops.add_rowmod_dropout(x2, lowp((pe,), x.dtype).reshape(-1, D), p_eff, seed)
+        ctx.cfg = (x.shape, tuple(pe.shape), p_eff, seed)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xshape, pe_shape, p_eff, seed = ctx.cfg
+        D = xshape[-1]
+        g = dy.reshape(-1, D).contiguous()
+        if p_eff > 0:
+            g = ops.dropout_apply(g, p_eff, seed)
+        dpe = ops.rowmod_sum(g, pe_shape[-2]).reshape(pe_shape) if ctx.needs_input_grad[1] else None
+        return g.reshape(xshape), dpe, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        D = x.shape[-1]
+        x2 = x.reshape(-1, D).contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x2, weight.detach(), bias.detach(), eps)
+        ctx.save_for_backward(x2, mean, rstd, weight.detach())
+        ctx.shape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, w = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(dy.reshape(x2.shape).contiguous(), x2, mean, rstd, w)
+        return dx.reshape(ctx.shape), dg, db, None
+
+
+def layer_norm(x, weight, bias, eps):
+    return LayerNormFn.apply(x, weight, bias, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# PGCA: single launch set for in-proj (q from query, k|v from key), attention, out-proj
+# ------------------------------------------------------------------------------------------------
+class GuidedCrossAttentionFn(torch.autograd.Function):
+    """query (Lq, B, E), key == value (Lk, B, E), seq-first as the reference passes them.
+    Returns (out (Lq, B, E), raw logits (B, H, Lq, Lk) fp32 or None)."""
+
+    @staticmethod
+    def forward(ctx, query, key, in_w, in_b, out_w, out_b, H, need_raw):
+        Lq, B, E = query.shape
+        Lk = key.shape[0]
+        cdt = query.dtype
+        hd = E // H
+        q2 = query.reshape(Lq * B, E).contiguous()
+        k2 = key.reshape(Lk * B, E).contiguous()
+        w = lowp((in_w,), cdt)
+        b = _f32(in_b)
+        # rows of q/k/v are (l, b) pairs: problem stride = row width, row stride = B * row width
+        qp = ops.gemm(q2, w[:E], M=Lq * B, N=E, K=E, bias=None if b is None else b[:E])
+        kv = ops.gemm(k2, w[E:], M=Lk * B, N=2 * E, K=E, bias=None if b is None else b[E:])
+        o = torch.empty((Lq * B, E), dtype=cdt, device=query.device)
+        raw = torch.empty((B, H, Lq, Lk), dtype=torch.float32, device=query.device) if need_raw else None
+        scale = float(hd) ** -0.5
+        lse = ops.attn_fwd(qp, kv, kv[:, E:], n_problems=B, n_heads=H, n_segments=1, partner_shift=0, Lq=Lq, Lk=Lk,
+                           head_dim=hd, scale=scale, q_strides=(E, hd, B * E), k_strides=(2 * E, hd, B * 2 * E),
+                           v_strides=(2 * E, hd, B * 2 * E), out=o, o_strides=(E, hd, B * E), o_ss=0, raw_logits=raw)
+        ow = lowp((out_w,), cdt)
+        y = ops.gemm(o, ow, M=Lq * B, N=E, K=E, bias=_f32(out_b))
+        ctx.save_for_backward(q2, k2, w, qp, kv, o, lse, ow)
+        ctx.cfg = (Lq, Lk, B, E, H, scale, in_b is not None, out_b is not None)
+        ctx.mark_non_differentiable(*([raw] if raw is not None else []))
+        return y.reshape(Lq, B, E), raw
+
+    @staticmethod
+    def backward(ctx, dy, _draw):
+        q2, k2, w, qp, kv, o, lse, ow = ctx.saved_tensors
+        Lq, Lk, B, E, H, scale, has_inb, has_outb = ctx.cfg
+        hd = E // H
+        g = dy.reshape(Lq * B, E).contiguous()
+        dwo = ops.gemm(g, o, M=E, N=E, K=Lq * B, x_kslow=True, w_kslow=True, ldx=E, ldw=E, out_dtype=torch.float32,
+                       split_k=0)
+        dbo = ops.colsum(g) if has_outb else None
+        do = ops.gemm(g, ow, M=Lq * B, N=E, K=E, w_kslow=True, ldw=E)
+        dqp = torch.empty_like(qp)
+        dkv = torch.empty_like(kv)
+        ops.attn_bwd(qp, kv, kv[:, E:], o, do, lse, n_problems=B, n_heads=H, n_segments=1, partner_shift=0, Lq=Lq,
+                     Lk=Lk, head_dim=hd, scale=scale, q_strides=(E, hd, B * E), k_strides=(2 * E, hd, B * 2 * E),
+                     v_strides=(2 * E, hd, B * 2 * E), o_strides=(E, hd, B * E), o_ss=0, do_strides=(E, hd, B * E),
+                     do_ss=0, dq=dqp, dq_strides=(E, hd, B * E), dk=dkv, dk_strides=(2 * E, hd, B * 2 * E),
+                     dv=dkv[:, E:], dv_strides=(2 * E, hd, B * 2 * E))
+        dwq = ops.gemm(dqp, q2, M=E, N=E, K=Lq * B, x_kslow=True, w_kslow=True, ldx=E, ldw=E, out_dtype=torch.float32,
+                       split_k=0)
+        dwkv = ops.gemm(dkv, k2, M=2 * E, N=E, K=Lk * B, x_kslow=True, w_kslow=True, ldx=2 * E, ldw=E,
+                        out_dtype=torch.float32, split_k=0)
+        din_w = torch.cat((dwq, dwkv), dim=0)
+        din_b = torch.cat((ops.colsum(dqp), ops.colsum(dkv))) if has_inb else None
+        dquery = ops.gemm(dqp, w[:E], M=Lq * B, N=E, K=E, w_kslow=True, ldw=E).reshape(Lq, B, E)
+        dkey = ops.gemm(dkv, w[E:], M=Lk * B, N=E, K=2 * E, w_kslow=True, ldw=E).reshape(Lk, B, E)
+        return dquery, dkey, din_w, din_b, dwo, dbo, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# MHLA token gate: lin1 -> GELU -> lin2 -> softmax over L -> flat-reinterpreted scaling (+ residual)
+# ------------------------------------------------------------------------------------------------
+class TokenGateFn(torch.autograd.Function):
+    """out = MHLA(v) (+ v when add_residual) — encoder.py:127-140 and the caller's `mv + hv`."""
+
+    @staticmethod
+    def forward(ctx, v, w1, b1, w2, b2, H, add_residual):
+        B, L, D = v.shape
+        cdt = v.dtype
+        M = B * L
+        dd = w1.shape[0]
+        v2 = v.reshape(M, D).contiguous()
+        lw1, lw2 = lowp((w1,), cdt), lowp((w2,), cdt)
+        pre = torch.empty((M, dd), dtype=cdt, device=v.device)
+        hid = ops.gemm(v2, lw1, M=M, N=dd, K=D, bias=_f32(b1), act=1, pre_out=pre)
+        logits = ops.gemm(hid, lw2, M=M, N=H, K=dd, bias=_f32(b2))
+        out, gate = ops.token_gate_fwd(v2.reshape(B, L, D), logits.reshape(B, L, H), H, add_residual)
+        ctx.save_for_backward(v2, lw1, lw2, pre, hid, gate)
+        ctx.cfg = (B, L, D, H, dd, add_residual)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        v2, lw1, lw2, pre, hid, gate = ctx.saved_tensors
+        B, L, D, H, dd, add_residual = ctx.cfg
+        M = B * L
+        dv_gate, dlogits = ops.token_gate_bwd(dout.contiguous(), v2.reshape(B, L, D), gate, H, add_residual)
+        dl2 = dlogits.reshape(M, H)
+        dw2 = ops.gemm(dl2, hid, M=H, N=dd, K=M, x_kslow=True, w_kslow=True, ldx=H, ldw=dd, out_dtype=torch.float32,
+                       split_k=0)
+        db2 = ops.colsum(dl2)
+        dpre = ops.gemm(dl2, lw2, M=M, N=dd, K=H, w_kslow=True, ldw=dd, dact_pre=pre)
+        dw1 = ops.gemm(dpre, v2, M=dd, N=D, K=M, x_kslow=True, w_kslow=True, ldx=dd, ldw=D, out_dtype=torch.float32,
+                       split_k=0)
+        db1 = ops.colsum(dpre)
+        dv = ops.gemm(dpre, lw1, M=M, N=D, K=dd, w_kslow=True, ldw=D, residual=dv_gate.reshape(M, D))
+        return dv.reshape(B, L, D), dw1, db1, dw2, db2, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# dtype cast as an autograd node; attention maps for vis=True
+# ------------------------------------------------------------------------------------------------
+class CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return ops.cast(x.contiguous(), dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.cast(dy.contiguous(), ctx.src), None
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    return x if x.dtype == dtype else CastFn.apply(x, dtype)
+
+
+@torch.no_grad()
+def attention_maps(x, blk, H: int, paired: bool):
+    """softmax(QK^T/sqrt(hd)) maps for visualisation (reference `vis=True`); not differentiable, not on
+    the training path.  Projections run through dl_gemm / dl_layernorm; the (B,H,L,L) probabilities
+    themselves are produced with the attention kernel's raw-logit output + a torch softmax."""
+    S, B, L, d = x.shape
+    hd = d // H
+    M = B * L
+    maps = []
+    qkvs = []
+    for s in range(S):
+        ps = blk.stream_params(s)
+        xn, _, _ = ops.layernorm_fwd(x[s].reshape(M, d).contiguous(), ps[0].detach(), ps[1].detach(), 1e-6)
+        w = lowp((ps[2], ps[4], ps[6]), x.dtype)
+        b = lowp((ps[3], ps[5], ps[7]), torch.float32)
+        qkvs.append(ops.gemm(xn, w, M=M, N=3 * d, K=d, bias=b))
+    qs = (L * 3 * d, hd, 3 * d)
+
+    def raw_of(qbuf, kbuf):
+        raw = torch.empty((B, H, L, L), dtype=torch.float32, device=x.device)
+        scratch = torch.empty((M, d), dtype=x.dtype, device=x.device)
+        ops.attn_fwd(qbuf, kbuf[:, d:], kbuf[:, 2 * d:], n_problems=B, n_heads=H, n_segments=1, partner_shift=0, Lq=L,
+                     Lk=L, head_dim=hd, scale=1.0 / math.sqrt(hd), q_strides=qs, k_strides=qs, v_strides=qs,
+                     out=scratch, o_strides=(L * d, hd, d), o_ss=0, need_lse=False, raw_logits=raw)
+        return torch.softmax(raw, dim=-1)
+
+    w = raw_of(qkvs[0], qkvs[0])
+    gw = raw_of(qkvs[1], qkvs[0]) if paired else None
+    return w, gw

@@ -1,0 +1,149 @@
+"""GPU parity: the HIP hot path (through the C ABI, via the reference-shaped modules) against the
+golden fixtures of the real reference and against the CPU oracle.  fp32 mode must hold the
+north-star tolerance (1e-4); bf16 mode is checked at 3e-2 (bf16 has 8 mantissa bits)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import T, check_sub, det_state_dict, gradnorms, load, relerr
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-4
+BF16_TOL = 3e-2
+
+
+def check_gradnorms(named_params, g, tol):
+    """Per-parameter gradient norms against the reference's.  Key-projection biases and the MHLA gate
+    bias have an analytically ZERO gradient (softmax shift invariance): there both sides hold only
+    rounding noise, which must merely be small next to the real gradients."""
+    ref = gradnorms(g)
+    sd = dict(named_params)
+    scale = max(ref.values())
+    for k, n_ref in ref.items():
+        got = float(sd[k].grad.double().norm())
+        if k.endswith(("key.bias", "key_mol.bias", "lin2.bias")) or (k == "in_proj_bias"):
+            assert abs(got - n_ref) <= tol * 10 * scale, (k, got, n_ref)
+        else:
+            assert abs(got - n_ref) <= tol * 10 * max(n_ref, 1e-4), (k, got, n_ref)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def pmma_config(L, dropout=0.0):
+    return _Cfg(hidden_size=256, mol_len=L, feat_len=L,
+                transformer=_Cfg(num_heads=4, num_p_plus_s_layers=4, attention_dropout_rate=0, dropout_rate=dropout))
+
+
+def build_pmma(g, L, dtype, vis=False):
+    from druglamp_amd.model.PMMA import PairedMultimodelAttention
+    m = PairedMultimodelAttention(pmma_config(L), vis=vis)
+    sd = det_state_dict(g)
+    missing = m.load_state_dict(sd, strict=True)
+    m = m.to(_dev()).eval()
+    m.compute_dtype = dtype
+    return m
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+def test_pmma_mid_forward_backward(dtype, tol):
+    g = load("pmma_mid")
+    m = build_pmma(g, 64, dtype)
+    prot = T("pmma_mid.prot", (2, 64, 256)).to(_dev()).requires_grad_(True)
+    mol = T("pmma_mid.mol", (2, 64, 256)).to(_dev()).requires_grad_(True)
+    enc, w, gw = m(prot, mol)
+    assert w == [] and gw == []
+    assert relerr(enc, g["encoded"]) <= tol
+    (enc * T("pmma_mid.G", tuple(enc.shape)).to(_dev())).sum().backward()
+    assert relerr(prot.grad, g["dprot"]) <= tol * 3
+    assert relerr(mol.grad, g["dmol"]) <= tol * 3
+    sd = dict(m.named_parameters())
+    assert relerr(sd["encoder.layer_with_mol.0.attn.query.weight"].grad[:8, :16], g["dW_l0_query"]) <= tol * 3
+    assert relerr(sd["encoder.layer_with_mol.3.ffn.fc2.weight"].grad[:8, :16], g["dW_l3_fc2"]) <= tol * 3
+    assert relerr(sd["encoder.layer_with_mol.1.attn.fc_mol.bias"].grad, g["db_l1_fc_mol"]) <= tol * 3
+    assert relerr(sd["embeddings.pe_mol"].grad[0, :4, :16], g["dpe_mol"]) <= tol * 3
+    check_gradnorms(m.named_parameters(), g, tol)
+    assert sd["embeddings.embedding.weight"].grad is None     # dead Linear, as in the reference
+
+
+def test_pmma_vis_maps():
+    g = load("pmma_mid")
+    m = build_pmma(g, 64, torch.float32, vis=True)
+    prot = T("pmma_mid.prot", (2, 64, 256)).to(_dev())
+    mol = T("pmma_mid.mol", (2, 64, 256)).to(_dev())
+    with torch.no_grad():
+        enc, w, gw = m(prot, mol)
+    assert relerr(w[0][:, :, :4, :8], g["w0"]) <= F32_TOL
+    assert relerr(gw[0][:, :, :4, :8], g["gw0"]) <= F32_TOL
+    assert relerr(w[3][:, :, :4, :8], g["w3"]) <= F32_TOL
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+def test_pmma_full_forward(dtype, tol):
+    g = load("pmma_full")
+    m = build_pmma(g, 256, dtype)
+    prot = T("pmma_full.prot", (2, 256, 256)).to(_dev()).requires_grad_(True)
+    mol = T("pmma_full.mol", (2, 256, 256)).to(_dev()).requires_grad_(True)
+    enc, _, _ = m(prot, mol)
+    check_sub(enc, g, "encoded", tol)
+    (enc * T("pmma_full.G", tuple(enc.shape)).to(_dev())).sum().backward()
+    check_sub(prot.grad, g, "dprot", tol * 3)
+    check_sub(mol.grad, g, "dmol", tol * 3)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("tag,shape", [("pgca_small", (48, 80, 3)), ("pgca_full", (256, 512, 2))])
+def test_pgca(tag, shape, dtype, tol):
+    from druglamp_amd.model.PGCA import GuidedCrossAttention
+    Lq, Lk, B = shape
+    g = load(tag)
+    m = GuidedCrossAttention(embed_dim=128, num_heads=1)
+    m.load_state_dict(det_state_dict(g), strict=True)
+    m = m.to(_dev()).eval()
+    m.compute_dtype = dtype
+    q = T(tag + ".q", (Lq, B, 128)).to(_dev()).requires_grad_(True)
+    kv = T(tag + ".kv", (Lk, B, 128)).to(_dev()).requires_grad_(True)
+    out, raw = m(q, kv, kv)
+    assert tuple(raw.shape) == (B, 1, Lq, Lk)
+    assert relerr(out, g["out"]) <= tol
+    assert relerr(raw[:, :, :8, :16], g["raw"]) <= tol
+    assert relerr(raw.double().norm(dim=-1), g["rawnorm"]) <= tol
+    (out * T(tag + ".G", tuple(out.shape)).to(_dev())).sum().backward()
+    assert relerr(q.grad, g["dq"]) <= tol * 3
+    assert relerr(kv.grad, g["dkv"]) <= tol * 3
+    check_gradnorms(m.named_parameters(), g, tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+@pytest.mark.parametrize("tag,shape", [("mhla_toy", (32, 64, 2, 5)), ("mhla_full", (256, 1024, 2, 256))])
+def test_mhla(tag, shape, dtype, tol):
+    from druglamp_amd.model.PMMA import MultiHeadLinearAttention
+    d, dd, B, L = shape
+    g = load(tag)
+    m = MultiHeadLinearAttention(d_model=d, d_diff=dd, nhead=8, dropout=0, activation="gelu")
+    m.load_state_dict(det_state_dict(g), strict=True)
+    m = m.to(_dev()).eval()
+    m.compute_dtype = dtype
+    v = T(tag + ".v", (B, L, d)).to(_dev()).requires_grad_(True)
+    out = m(v)
+    assert relerr(out, g["out"]) <= tol
+    (out * T(tag + ".G", tuple(out.shape)).to(_dev())).sum().backward()
+    assert relerr(v.grad, g["dv"]) <= tol * 3
+    check_gradnorms(m.named_parameters(), g, tol)
+
+
+def test_no_cpu_fallback():
+    """The product path must refuse CPU tensors instead of silently computing somewhere else."""
+    g = load("pmma_mid")
+    from druglamp_amd.model.PMMA import PairedMultimodelAttention
+    m = PairedMultimodelAttention(pmma_config(64), vis=False).eval()
+    with pytest.raises(RuntimeError):
+        m(T("pmma_mid.prot", (2, 64, 256)), T("pmma_mid.mol", (2, 64, 256)))
