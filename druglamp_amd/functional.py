@@ -458,3 +458,64 @@ def attention_maps(x, blk, H: int, paired: bool):
     w = raw_of(qkvs[0], qkvs[0])
     gw = raw_of(qkvs[1], qkvs[0]) if paired else None
     return w, gw
+
+
+# ------------------------------------------------------------------------------------------------
+# loss Functions (fp32)
+# ------------------------------------------------------------------------------------------------
+class CosRowLossFn(torch.autograd.Function):
+    """mean over rows of 2 - 2 cos(x, y); y is a detached target (SimSiam, self_supervised_learning.py:184-187)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x = x.float().contiguous()
+        y = y.detach().float().contiguous()
+        rows = ops.cos_rowloss_fwd(x, y)
+        ctx.save_for_backward(x, y)
+        return rows
+
+    @staticmethod
+    def backward(ctx, drows):
+        x, y = ctx.saved_tensors
+        # per-row upstream gradient: the kernel takes one scalar scale, so scale rows afterwards
+        dx = ops.cos_rowloss_bwd(x, y, 1.0)
+        return dx * drows.unsqueeze(-1), None
+
+
+class NTXentFn(torch.autograd.Function):
+    """nt_xent_loss(q, k, T) (self_supervised_learning.py:168-182), streaming: no (2n)^2 matrix."""
+
+    @staticmethod
+    def forward(ctx, q, k, temperature):
+        q = q.float().contiguous()
+        k = k.float().contiguous()
+        loss, lse = ops.ntxent_fwd(q, k, temperature)
+        ctx.save_for_backward(q, k, lse)
+        ctx.t = temperature
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        q, k, lse = ctx.saved_tensors
+        dq, dk = ops.ntxent_bwd(q, k, ctx.t, lse, 1.0)
+        return dq * dl, dk * dl, None
+
+
+class TripletSigCosFn(torch.autograd.Function):
+    """ccpp_p_tri_loss with distance 1 - sigmoid(cos) (cross_modality.py:15-47, utils.py:571-574) over a
+    dense label matrix gt[n_p][n_d] (int8: 1 positive, 0 negative, -1 ignored)."""
+
+    @staticmethod
+    def forward(ctx, p_lats, d_lats, gt, margin):
+        p = p_lats.float().contiguous()
+        d = d_lats.float().contiguous()
+        loss, ntri, buf = ops.triplet_sigcos_fwd(p, d, gt, margin)
+        ctx.save_for_backward(p, d, gt, buf, ntri)
+        ctx.margin = margin
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dl):
+        p, d, gt, buf, ntri = ctx.saved_tensors
+        dp, dd = ops.triplet_sigcos_bwd(p, d, gt, ctx.margin, buf, ntri, 1.0)
+        return dp * dl, dd * dl, None, None

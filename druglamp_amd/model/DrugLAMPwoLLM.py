@@ -1,0 +1,25 @@
+"""DrugLAMPwoLLM (reference: model/DrugLAMPwoLLM.py:8-51): no LLM branch; pmma(mv, mv)."""
+from .basic_model import DrugLAMPBase
+
+
+class DrugLAMPwoLLM(DrugLAMPBase):
+    def __init__(self, n_drug_feature, n_prot_feature, n_hidden=128, **cfg):
+        super().__init__(n_drug_feature, n_prot_feature, n_hidden, **cfg)
+
+    def forward(self, vd, vp, xd, xp, mode="train"):
+        with self._glue():
+            vd = self.drug_extractor(vd)
+        fill_p = self._fill_bit(xp)
+        ssl = {"vp": vp, "xp": None, "fill_bit_p": fill_p, "vd": vd, "xd": None, "p_mode": "vp"}
+        with self._glue():
+            vpf = self._site_pool(self.protein_extractor(vp, fill_p))
+        vpf, vdf = vpf.float(), vd.float()
+        mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpf, vdf)
+        f, self.attn, self.guide_attn = self.pmma(mv, mv)
+        with self._glue():
+            score = self.mlp_classifier(f.mean(dim=1))
+        score = score.float()
+        if mode == "train":
+            return vd, vpf, ssl, None, score
+        elif mode == "eval":
+            return vd, vpf, score, self.attn

@@ -1,0 +1,1 @@
+from .model_interface import MInterface  # noqa: F401

@@ -1,0 +1,258 @@
+"""DrugLAMPBase and the glue modules around the hot path (reference: model/basic_model.py).
+
+Hot path (HIP): v_gca / x_gca (PGCA), v_mhla / x_mhla (MHLA), pmma (PMMA), the SSL / CM loss kernels.
+Glue (torch-ROCm ops, run under bf16 autocast when the model computes in bf16): ProteinCNN, the LLM
+adaptors, the BN-MLP classifier, and a DGL-free dense restatement of MolecularGCN.
+"""
+from __future__ import annotations
+
+import contextlib
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as Fn
+from ..configs import get_model_defaults
+from .cross_modality import CrossModality
+from .PGCA import GuidedCrossAttention
+from .PMMA import MultiHeadLinearAttention, PairedMultimodelAttention
+from .self_supervised_learning import SSL
+
+CONFIGS = {"LAMP": get_model_defaults}
+
+
+def binary_cross_entropy(pred_output, labels):
+    n = torch.sigmoid(pred_output.float()).squeeze(1)
+    return n, F.binary_cross_entropy(n, labels.float())
+
+
+def cross_entropy_logits(linear_output, label, weights=None):
+    logp = F.log_softmax(linear_output.float(), dim=1)
+    n = logp.exp()[:, 1]
+    tgt = label.long().view(label.size(0))
+    if weights is None:
+        return n, F.nll_loss(logp, tgt)
+    losses = F.nll_loss(logp, tgt, reduction="none")
+    return n, torch.sum(weights * losses) / torch.sum(weights)
+
+
+class _GraphConvDense(nn.Module):
+    """weight (in, out) + bias, symmetric normalisation D^-1/2 A D^-1/2 (reference GraphConv 'both',
+    basic_model.py:545-638) on a dense per-sample adjacency."""
+
+    def __init__(self, in_feats, out_feats):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(in_feats, out_feats))
+        self.bias = nn.Parameter(torch.zeros(out_feats))
+        nn.init.xavier_uniform_(self.weight)
+
+    def forward(self, adj, feat):
+        dout = adj.sum(dim=-1).clamp(min=1).pow(-0.5).unsqueeze(-1)     # out-degree of the source node
+        din = adj.sum(dim=-2).clamp(min=1).pow(-0.5).unsqueeze(-1)      # in-degree of the destination
+        rst = torch.bmm(adj.transpose(1, 2), feat * dout)                # sum over incoming edges
+        rst = torch.matmul(rst, self.weight) * din + self.bias
+        return F.relu(rst)
+
+
+class _GCNLayerDense(nn.Module):
+    def __init__(self, in_feats, out_feats):
+        super().__init__()
+        self.graph_conv = _GraphConvDense(in_feats, out_feats)
+        self.res_connection = nn.Linear(in_feats, out_feats)
+        self.bn_layer = nn.BatchNorm1d(out_feats)
+
+    def forward(self, adj, feats):
+        new = self.graph_conv(adj, feats) + F.relu(self.res_connection(feats))
+        B, N, C = new.shape
+        return self.bn_layer(new.reshape(B * N, C)).reshape(B, N, C)
+
+
+class _GCNDense(nn.Module):
+    def __init__(self, in_feats, hidden_feats):
+        super().__init__()
+        self.gnn_layers = nn.ModuleList()
+        for h in hidden_feats:
+            self.gnn_layers.append(_GCNLayerDense(in_feats, h))
+            in_feats = h
+
+    def forward(self, adj, feats):
+        for layer in self.gnn_layers:
+            feats = layer(adj, feats)
+        return feats
+
+
+class MolecularGCN(nn.Module):
+    """MolecularGCN (basic_model.py:137-153) without DGL.  Accepts either
+      * a (node_feats (B, N, in_feats), adjacency (B, N, N)) pair — batched dense graphs with the
+        reference's virtual padding nodes carrying self loops — or
+      * an already extracted (B, N, dim_embedding) node-feature tensor, returned unchanged
+        (pre-extracted features; DGL/dgllife featurisation is out of scope).
+    state_dict keys equal the reference's (init_transform, gnn.gnn_layers.i.{graph_conv,res_connection,bn_layer})."""
+
+    def __init__(self, in_feats, dim_embedding=128, padding=True, hidden_feats=None, activation=None):
+        super().__init__()
+        self.init_transform = nn.Linear(in_feats, dim_embedding, bias=False)
+        if padding:
+            with torch.no_grad():
+                self.init_transform.weight[-1].fill_(0)
+        self.gnn = _GCNDense(dim_embedding, hidden_feats)
+        self.output_feats = hidden_feats[-1]
+        self.in_feats = in_feats
+
+    def forward(self, batch_graph):
+        if torch.is_tensor(batch_graph):
+            if batch_graph.shape[-1] != self.output_feats:
+                raise ValueError("MolecularGCN: a bare tensor must be pre-extracted node features of width %d"
+                                 % self.output_feats)
+            return batch_graph
+        node_feats, adj = batch_graph
+        return self.gnn(adj, self.init_transform(node_feats))
+
+
+class ProteinCNN(nn.Module):
+    """basic_model.py:155-180 (torch glue; conv via MIOpen).  Keeps the `view`-not-transpose output."""
+
+    def __init__(self, embedding_dim, num_filters, kernel_size, padding=True):
+        super().__init__()
+        self.embedding = nn.Embedding(26 + 1, embedding_dim - 1, padding_idx=0 if padding else None)
+        in_ch = [embedding_dim] + num_filters
+        self.in_ch = in_ch[-1]
+        self.conv1 = nn.Conv1d(in_ch[0], in_ch[1], kernel_size[0], padding="same")
+        self.bn1 = nn.BatchNorm1d(in_ch[1])
+        self.conv2 = nn.Conv1d(in_ch[1], in_ch[2], kernel_size[1], padding="same")
+        self.bn2 = nn.BatchNorm1d(in_ch[2])
+        self.conv3 = nn.Conv1d(in_ch[2], in_ch[3], kernel_size[2], padding="same")
+        self.bn3 = nn.BatchNorm1d(in_ch[3])
+
+    def forward(self, v, fill_mask):
+        v = self.embedding(v.long())
+        v = torch.cat((v, fill_mask.unsqueeze(-1).to(v.dtype)), dim=-1).transpose(2, 1)
+        v = self.bn1(F.relu(self.conv1(v)))
+        v = self.bn2(F.relu(self.conv2(v)))
+        v = self.bn3(F.relu(self.conv3(v)))
+        v = v.contiguous()
+        return v.view(v.size(0), v.size(2), -1)
+
+
+class FeedForwardLayer(nn.Module):
+    def __init__(self, d_in, d_h):
+        super().__init__()
+        self.lin1 = nn.Linear(d_in, d_h)
+        self.lin2 = nn.Linear(d_h, d_in)
+        self.act = nn.GELU()
+        self.norm = nn.LayerNorm(d_h)
+
+    def forward(self, x):
+        return self.lin2(self.norm(self.act(self.lin1(x))))
+
+
+class MLP(nn.Module):
+    def __init__(self, in_dim, hidden_dim, out_dim, binary=1):
+        super().__init__()
+        self.fc1 = nn.Linear(in_dim, hidden_dim)
+        self.bn1 = nn.BatchNorm1d(hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+        self.bn2 = nn.BatchNorm1d(hidden_dim)
+        self.fc3 = nn.Linear(hidden_dim, out_dim)
+        self.bn3 = nn.BatchNorm1d(out_dim)
+        self.fc4 = nn.Linear(out_dim, binary)
+
+    def forward(self, x):
+        x = self.bn1(F.gelu(self.fc1(x)))
+        x = self.bn2(F.gelu(self.fc2(x)))
+        x = self.bn3(F.gelu(self.fc3(x)))
+        return self.fc4(x)
+
+
+class DrugLAMPBase(nn.Module):
+    def __init__(self, n_drug_feature, n_prot_feature, n_hidden=128, **cfg):
+        super().__init__()
+        self.site_len = cfg["PROTEIN"]["SITE_LEN"]
+        self.seq_len_q = cfg["PROTEIN"]["SEQ_LEN"]
+        dec = cfg["DECODER"]
+        self.drug_extractor = MolecularGCN(in_feats=cfg["DRUG"]["NODE_IN_FEATS"], dim_embedding=n_hidden,
+                                           padding=cfg["DRUG"]["PADDING"], hidden_feats=[n_hidden] * 3)
+        self.protein_extractor = ProteinCNN(n_hidden, [n_hidden] * 3, cfg["PROTEIN"]["KERNEL_SIZE"],
+                                            cfg["PROTEIN"]["PADDING"])
+        self.ssl_model = SSL(prot_extractor=self.protein_extractor, n_prot_feature=n_prot_feature,
+                             drug_ssl_type="simsiam", n_hidden=n_hidden)
+        self.cm_model = CrossModality(use_cm=True, hidden_size=n_hidden, max_margin=cfg["RS"]["MAX_MARGIN"],
+                                      n_re=cfg["RS"]["RESET_EPOCH"])
+        model_cfg = CONFIGS["LAMP"](n_hidden)
+
+        self.lin_d1 = nn.Linear(n_drug_feature + 1, 2 * n_hidden)
+        self.act_d = nn.GELU()
+        self.d_norm = nn.LayerNorm(2 * n_hidden)
+        self.lin_d2 = nn.Linear(2 * n_hidden, n_hidden)
+
+        self.p_adaptor_wo_skip_connect = FeedForwardLayer(n_prot_feature + 1, n_hidden)
+        self.lin_p1 = nn.Linear(n_prot_feature + 1, 2 * n_hidden)
+        self.act_p = nn.GELU()
+        self.p_norm = nn.LayerNorm(2 * n_hidden)
+        self.lin_p2 = nn.Linear(2 * n_hidden, n_hidden)
+
+        self.v_gca = GuidedCrossAttention(embed_dim=n_hidden, num_heads=1)
+        self.v_mhla = MultiHeadLinearAttention(d_model=n_hidden * 2, d_diff=n_hidden * 8, nhead=8,
+                                               dropout=model_cfg.mlha_dropout, activation="gelu")
+        self.v_gca_norm = nn.LayerNorm(n_hidden * 2)
+        self.x_gca = GuidedCrossAttention(embed_dim=n_hidden, num_heads=1)
+        self.x_mhla = MultiHeadLinearAttention(d_model=n_hidden * 2, d_diff=n_hidden * 8, nhead=8,
+                                               dropout=model_cfg.mlha_dropout, activation="gelu")
+        self.x_gca_norm = nn.LayerNorm(n_hidden * 2)
+
+        self.pmma = PairedMultimodelAttention(config=model_cfg, vis=False)
+        self.mlp_classifier = MLP(dec["IN_DIM"] * 2, dec["HIDDEN_DIM"] * 2, dec["OUT_DIM"] * 2, binary=dec["BINARY"])
+        self.A_v_gca = None
+        self.A_x_gca = None
+        self.attn, self.guide_attn = [], []
+        self.keep_raw_attention = True
+        self.compute_dtype = torch.float32
+
+    # ---- precision ---------------------------------------------------------------------------
+    def set_compute_dtype(self, dtype: torch.dtype):
+        """float32: exact-fp32 MFMA kernels (parity mode).  bfloat16: bf16 MFMA kernels with fp32
+        accumulation / statistics, and bf16 autocast for the torch glue."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be float32 or bfloat16")
+        self.compute_dtype = dtype
+        for m in self.modules():
+            if isinstance(m, (GuidedCrossAttention, MultiHeadLinearAttention, PairedMultimodelAttention)):
+                m.compute_dtype = dtype
+        return self
+
+    def _glue(self):
+        if self.compute_dtype == torch.bfloat16:
+            return torch.autocast(device_type="cuda", dtype=torch.bfloat16)
+        return contextlib.nullcontext()
+
+    # ---- shared pieces of the three forwards ------------------------------------------------------
+    @staticmethod
+    def _fill_bit(x):
+        return (x.sum(dim=-1) == 0).to(x.dtype)
+
+    def _site_pool(self, t):
+        n_site = self.seq_len_q // self.site_len
+        return t.view(-1, self.site_len, n_site, t.size(-1)).mean(dim=1)
+
+    def _gca_branch(self, gca, mhla, norm, prot_sites, drug_nodes):
+        """PGCA -> concat -> MHLA + residual -> LayerNorm (DrugLAMP.py:55-71).  Returns (m, raw logits)."""
+        m, raw = gca(prot_sites.permute(1, 0, 2), drug_nodes.permute(1, 0, 2), drug_nodes.permute(1, 0, 2),
+                     need_weights=self.keep_raw_attention, need_raw=True)
+        m = torch.cat((prot_sites, m.permute(1, 0, 2)), 2)
+        m = mhla(m, add_residual=True)                                  # mhla(h) + h in one launch set
+        m = Fn.layer_norm(m.float(), norm.weight, norm.bias, norm.eps)
+        return m, raw
+
+    def get_cross_attn_mat(self, modality="v"):
+        if modality == "v":
+            self.A_v_gca = self.A_v_gca.cpu()
+            return self.A_v_gca
+        self.A_x_gca = self.A_x_gca.cpu()
+        return self.A_x_gca
+
+    def get_inter_attn_mat(self):
+        return self.attn, self.guide_attn
+
+    def forward(self, vd, vp, xd, xp, mode="train"):
+        pass

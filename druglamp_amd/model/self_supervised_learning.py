@@ -1,0 +1,124 @@
+"""SSL head (reference: model/self_supervised_learning.py).  Same constructor / forward surface and
+state_dict keys.  The protein masked-LM re-runs the shared ProteinCNN (torch glue); the SimSiam row
+loss and the (normally unreachable) NT-Xent loss run as HIP kernels."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as Fn
+
+
+def mask_with_tokens(t, token_ids):
+    m = torch.zeros_like(t, dtype=torch.bool)
+    for tid in token_ids:
+        m |= (t == tid)
+    return m
+
+
+def get_mask_subset_with_prob(mask, prob):
+    """Exactly ceil(prob * n_tokens) random positions per row among mask==True (utils.py:537-551)."""
+    batch, seq_len = mask.shape
+    max_masked = math.ceil(prob * seq_len)
+    num_tokens = mask.sum(dim=-1, keepdim=True)
+    excess = (mask.cumsum(dim=-1) > (num_tokens * prob).ceil())[:, :max_masked]
+    rand = torch.rand((batch, seq_len), device=mask.device).masked_fill(~mask, -1e9)
+    _, idx = rand.topk(max_masked, dim=-1)
+    idx = (idx + 1).masked_fill_(excess, 0)
+    new_mask = torch.zeros((batch, seq_len + 1), device=mask.device)
+    new_mask.scatter_(-1, idx, 1)
+    return new_mask[:, 1:].bool()
+
+
+def prob_mask_like(t, prob):
+    return torch.zeros_like(t).float().uniform_(0, 1) < prob
+
+
+def _simsiam_mlp(dim, proj_out, hidden=512):
+    return nn.Sequential(nn.Linear(dim, hidden, bias=False), nn.BatchNorm1d(hidden), nn.ReLU(inplace=True),
+                         nn.Linear(hidden, hidden, bias=False), nn.BatchNorm1d(hidden), nn.ReLU(inplace=True),
+                         nn.Linear(hidden, proj_out, bias=False), nn.BatchNorm1d(proj_out, affine=False))
+
+
+class SimProj(nn.Module):
+    """Projector built lazily on first use, as in the reference (:126-143): it therefore is in no
+    optimiser that was created before the first SSL forward."""
+
+    def __init__(self, projection_out, projection_hidden_size=512):
+        super().__init__()
+        self.projector = None
+        self.projection_out = projection_out
+        self.projection_hidden_size = projection_hidden_size
+
+    def forward(self, x):
+        if self.projector is None:
+            self.projector = _simsiam_mlp(x.shape[1], self.projection_out, self.projection_hidden_size).to(x.device)
+        return self.projector(x)
+
+
+class SSL(nn.Module):
+    def __init__(self, prot_extractor, n_prot_feature, *, drug_ssl_type="simsiam", n_hidden=128, **kwargs):
+        super().__init__()
+        self.extractor = prot_extractor
+        self.to_logits = nn.Linear(128, 26 + 1)
+        self.llm_to_logits = nn.Linear(n_prot_feature + 1, 26 + 1)
+        self.drug_ssl_type = drug_ssl_type
+        self.net = SimProj(n_hidden)
+        self.llm_net = SimProj(n_hidden)
+        if drug_ssl_type == "simsiam":
+            self.predictor = nn.Sequential(nn.Linear(n_hidden, n_hidden * 4), nn.BatchNorm1d(n_hidden * 4),
+                                           nn.ReLU(inplace=True), nn.Linear(n_hidden * 4, n_hidden))
+        else:
+            self.temperature = 0.1
+
+    def build_projectors(self, vd_dim: int, xd_dim: int, device=None):
+        """Create the lazily-built SimSiam projectors ahead of time (e.g. before load_state_dict of a
+        checkpoint that contains them).  The reference creates them on the first SSL forward."""
+        for proj, dim in ((self.net, vd_dim), (self.llm_net, xd_dim)):
+            if proj.projector is None:
+                proj.projector = _simsiam_mlp(dim, proj.projection_out, proj.projection_hidden_size).to(device)
+
+    def drug_simclr(self, vd, xd):
+        q = self.net(vd.reshape(-1, vd.shape[-1]))
+        k = self.llm_net(xd.reshape(-1, xd.shape[-1]))
+        return Fn.NTXentFn.apply(q, k, self.temperature)
+
+    def drug_simsiam(self, vd, xd):
+        one, two = vd.reshape(-1, vd.shape[-1]), xd.reshape(-1, xd.shape[-1])
+        pred_one = self.predictor(self.net(one))
+        pred_two = self.predictor(self.llm_net(two))
+        with torch.no_grad():
+            t_one = self.net(one)
+            t_two = self.llm_net(two)
+        rows = Fn.CosRowLossFn.apply(pred_one, t_two) + Fn.CosRowLossFn.apply(pred_two, t_one)
+        return rows.mean()
+
+    def prot_mlm(self, seq, extractor, xp, fill_bit, mode, mask_ignore_token_ids=(0,), mask_prob=0.15,
+                 replace_prob=0.9, pad_token_id=0, mask_token_id=26, mask=None, replace=None):
+        if mask is None:
+            mask = get_mask_subset_with_prob(~mask_with_tokens(seq, mask_ignore_token_ids), mask_prob)
+        if replace is None:
+            replace = prob_mask_like(seq, replace_prob)
+        labels = seq.masked_fill(~mask, pad_token_id).long()
+        masked_seq = seq.clone().detach().masked_fill(mask & replace, mask_token_id)
+        loss = 0.0
+        if mode != "xp":
+            logits = self.to_logits(extractor(masked_seq, fill_bit))
+            loss = loss + F.cross_entropy(logits.float().transpose(1, 2), labels, ignore_index=pad_token_id)
+        if mode != "vp":
+            llm_logits = self.llm_to_logits(xp)
+            loss = loss + F.cross_entropy(llm_logits.float().transpose(1, 2), labels, ignore_index=pad_token_id)
+        return loss / 2 if mode == "double" else loss
+
+    def forward(self, vp, xp, fill_bit_p, vd, xd, p_mode="double", mask=None, replace=None):
+        prot = self.prot_mlm(vp, self.extractor, xp, fill_bit_p, p_mode, mask=mask, replace=replace)
+        if vd is None or xd is None:
+            drug = 0
+        elif self.drug_ssl_type == "simsiam":
+            drug = self.drug_simsiam(vd, xd)
+        else:
+            drug = self.drug_simclr(vd, xd)
+        return {"prot_ssl": prot, "drug_ssl": drug}

@@ -1,0 +1,256 @@
+"""Data-parallel training loop (reference: trainer.py:39-292 + main.py:155-168), one process per GPU.
+
+What is restated from the reference, in its order (trainer.py:179-231):
+    forward -> opt.zero_grad -> cls backward -> [opt_ssl.zero_grad -> ssl forward/backward]
+            -> [opt_cm.zero_grad -> cm forward (+ one-time weight auto-scale) -> backward]
+            -> opt.step -> [opt_ssl.step] -> [opt_cm.step]
+All three AdamW instances own the SAME parameter list (main.py:158-160), so every zero_grad wipes the
+previous loss's gradients and each optimiser steps on whatever gradient is present last — kept as is.
+Parameters whose gradient is None are skipped by torch.optim.AdamW; here too (per-parameter step
+counts, contiguous "runs" of parameters with gradients).
+
+What is new (MI355X-native):
+  * parameters live in ONE flat fp32 arena; gradients are packed into a flat buffer by a single
+    multi-tensor copy; each optimiser step is a handful of fused dl_adamw_step launches over
+    contiguous runs instead of ~250 per-tensor updates;
+  * gradient all-reduce = one RCCL all-reduce per run on the flat buffer (sum; the 1/world factor is
+    folded into the AdamW kernel's grad_scale), instead of Lightning's DDP wrapper.  Unlike the
+    reference's DDP (which only reduces the cls backward that ran under the wrapper), EVERY loss's
+    gradients are reduced, so replicas never drift.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import functional as Fn
+from . import ops
+from .model.basic_model import binary_cross_entropy, cross_entropy_logits
+
+
+class CosineAnnealingWarmupRestarts:
+    """scheduler/cosine_annealing_warmup.py:5-88 as plain arithmetic (cycle_mult = 1, gamma = 1): lr starts
+    at min_lr; the k-th step() gives linear warm-up for k < warmup_steps, then half-cosine to min_lr."""
+
+    def __init__(self, first_cycle_steps: int, max_lr: float, min_lr: float = 1e-8, warmup_steps: int = 0):
+        assert warmup_steps < first_cycle_steps
+        self.first_cycle_steps, self.max_lr, self.min_lr, self.warmup_steps = first_cycle_steps, max_lr, min_lr, warmup_steps
+        self.step_in_cycle = 0
+        self.cycle = 0
+        self.lr = min_lr
+
+    def step(self) -> float:
+        self.step_in_cycle += 1
+        if self.step_in_cycle >= self.first_cycle_steps:
+            self.cycle += 1
+            self.step_in_cycle -= self.first_cycle_steps
+        s = self.step_in_cycle
+        if s < self.warmup_steps:
+            self.lr = (self.max_lr - self.min_lr) * s / self.warmup_steps + self.min_lr
+        else:
+            self.lr = self.min_lr + (self.max_lr - self.min_lr) * (
+                1 + math.cos(math.pi * (s - self.warmup_steps) / (self.first_cycle_steps - self.warmup_steps))) / 2
+        return self.lr
+
+
+class FlatParams:
+    """All optimised parameters as views into one fp32 arena (+ a same-layout gradient buffer)."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter]):
+        self.params = list(params)
+        dev = self.params[0].device
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
+        self.numel = n
+        self.arena = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                view = self.arena[off:off + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+        self.grad_views = [self.grads[off:off + p.numel()].view(p.shape) for p, off in zip(self.params, self.offsets)]
+
+    def pack_grads(self) -> List[int]:
+        """Copy the present .grad tensors into the flat buffer; returns the indices that had one."""
+        idx = [i for i, p in enumerate(self.params) if p.grad is not None]
+        if idx:
+            torch._foreach_copy_([self.grad_views[i] for i in idx], [self.params[i].grad for i in idx])
+        return idx
+
+    def runs(self, idx: List[int], key) -> List[tuple]:
+        """Merge adjacent parameter indices with equal key(i) into (start_elem, end_elem, first_index)."""
+        out = []
+        for i in idx:
+            s, e = self.offsets[i], self.offsets[i] + (self.params[i].numel() + 3) // 4 * 4
+            if out and out[-1][1] == s and key(out[-1][2]) == key(i) and out[-1][3] + 1 == i:
+                out[-1] = (out[-1][0], e, out[-1][2], i)
+            else:
+                out.append((s, e, i, i))
+        return [(s, e, first) for s, e, first, _ in out]
+
+
+class FusedAdamW:
+    """torch.optim.AdamW semantics (lr, betas (0.9, 0.999), eps 1e-8, weight_decay 1e-2) on a FlatParams."""
+
+    def __init__(self, flat: FlatParams, lr: float, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.flat, self.lr, self.betas, self.eps, self.wd = flat, lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(flat.arena)
+        self.exp_avg_sq = torch.zeros_like(flat.arena)
+        self.steps = [0] * len(flat.params)
+
+    def step(self, idx: List[int], grad_scale: float = 1.0):
+        for s, e, first in self.flat.runs(idx, lambda i: self.steps[i]):
+            ops.adamw_step(self.flat.arena[s:e], self.flat.grads[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e],
+                           lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd,
+                           step=self.steps[first] + 1, grad_scale=grad_scale)
+        for i in idx:
+            self.steps[i] += 1
+
+
+class Trainer:
+    """ExpModule restated (trainer.py:39-292).  `cfg` is the merged config tree."""
+
+    def __init__(self, model, cfg, device=None, compute_dtype=torch.float32):
+        self.model = model
+        self.cfg = cfg
+        self.device = device or next(model.parameters()).device
+        self.n_class = cfg["DECODER"]["BINARY"]
+        self.epochs = cfg["SOLVER"]["MAX_EPOCH"]
+        self.use_ssl = bool(cfg["RS"]["SSL"])
+        self.use_cm = bool(cfg["RS"]["CM"])
+        self.ssl_epoch_step = cfg["RS"]["EPOCH_STEP"]
+        self.cm_init_epoch = cfg["RS"]["INIT_EPOCH"]
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        model.set_compute_dtype(compute_dtype)
+        # main.py:158-160: three AdamW over model.parameters() built BEFORE any SSL forward (the lazily
+        # created SimSiam projectors are therefore in none of them)
+        self.flat = FlatParams([p for p in model.parameters()])
+        Fn.bump_param_epoch()
+        warm = int(self.epochs * 0.2)
+        self.opt = FusedAdamW(self.flat, cfg["SOLVER"]["LR"])
+        self.opt_ssl = FusedAdamW(self.flat, cfg["SOLVER"]["SSL_LR"]) if self.use_ssl else None
+        self.opt_cm = FusedAdamW(self.flat, cfg["SOLVER"]["CM_LR"]) if self.use_cm else None
+        self.schd = CosineAnnealingWarmupRestarts(self.epochs, cfg["SOLVER"]["LR"], 1e-8, warm)
+        self.schd_ssl = CosineAnnealingWarmupRestarts(self.epochs, cfg["SOLVER"]["SSL_LR"], 1e-8, warm) if self.use_ssl else None
+        self.schd_cm = CosineAnnealingWarmupRestarts(self.epochs, cfg["SOLVER"]["CM_LR"], 1e-8, warm) if self.use_cm else None
+        self.opt.lr = self.schd.lr
+        if self.opt_ssl:
+            self.opt_ssl.lr = self.schd_ssl.lr
+        if self.opt_cm:
+            self.opt_cm.lr = self.schd_cm.lr
+        self.cm_weight = 1.0
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _zero_grad(self):
+        for p in self.flat.params:
+            p.grad = None
+
+    def _reduce_and_pack(self) -> List[int]:
+        idx = self.flat.pack_grads()
+        if self.world > 1 and idx:
+            for s, e, _ in self.flat.runs(idx, lambda i: 0):
+                dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM)
+        return idx
+
+    def set_lrs(self, lr=None, ssl_lr=None, cm_lr=None):
+        if lr is not None:
+            self.opt.lr = lr
+        if ssl_lr is not None and self.opt_ssl:
+            self.opt_ssl.lr = ssl_lr
+        if cm_lr is not None and self.opt_cm:
+            self.opt_cm.lr = cm_lr
+
+    # -- the step ---------------------------------------------------------------------------------------
+    def training_step(self, batch, meta=None, cur_epoch: int = 1, ssl_masks=None) -> Dict[str, float]:
+        """batch = (feat_d, feat_p, labels, llm_d, llm_p) as the reference's collate yields them.
+        cur_epoch is 1-based (trainer.py:180).  Returns python floats of the losses (one host sync)."""
+        m = self.model
+        m.train()
+        compute_ssl = self.use_ssl and (cur_epoch % self.ssl_epoch_step == 0)
+        compute_cm = self.use_cm and (cur_epoch >= self.cm_init_epoch)
+        feat_d, feat_p, labels, llm_d, llm_p = batch
+        _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p)
+        self._zero_grad()
+        _, cls_loss = binary_cross_entropy(score, labels) if self.n_class == 1 else cross_entropy_logits(score, labels)
+        cls_loss.backward(retain_graph=compute_ssl or compute_cm)
+        out = {"cls": cls_loss.detach()}
+        if compute_ssl:
+            self._zero_grad()
+            kw = dict(ssl_input)
+            if ssl_masks is not None:
+                kw.update(mask=ssl_masks[0], replace=ssl_masks[1])
+            d = m.ssl_model(**kw)
+            ssl_loss = (d["prot_ssl"] + d["drug_ssl"]) * 0.1
+            ssl_loss.backward(retain_graph=compute_cm)
+            out["ssl"] = ssl_loss.detach()
+        if compute_cm:
+            self._zero_grad()
+            cm_loss = m.cm_model(**cm_input, meta=meta)
+            if cur_epoch == self.cm_init_epoch:
+                c, l = float(cm_loss), float(cls_loss)
+                if c > 0:
+                    while c * self.cm_weight / 10 > l:
+                        self.cm_weight /= 10
+                    while c * self.cm_weight * 10 < l:
+                        self.cm_weight *= 10
+            cm_loss = cm_loss * self.cm_weight
+            cm_loss.backward()
+            out["cm"] = cm_loss.detach()
+        idx = self._reduce_and_pack()
+        scale = 1.0 / self.world
+        self.opt.step(idx, scale)
+        if compute_ssl:
+            self.opt_ssl.step(idx, scale)
+        if compute_cm:
+            self.opt_cm.step(idx, scale)
+        Fn.bump_param_epoch()
+        return out
+
+    def on_train_epoch_end(self, cur_epoch: int):
+        compute_ssl = self.use_ssl and (cur_epoch % self.ssl_epoch_step == 0)
+        compute_cm = self.use_cm and (cur_epoch >= self.cm_init_epoch)
+        self.opt.lr = self.schd.step()
+        if compute_ssl:
+            self.opt_ssl.lr = self.schd_ssl.step()
+        if compute_cm:
+            self.opt_cm.lr = self.schd_cm.step()
+            self.model.cm_model.step()
+
+    # -- evaluation (trainer.py:256-292; torchmetrics replaced by sklearn on the gathered predictions) -----
+    @torch.no_grad()
+    def evaluate(self, batches) -> Dict[str, float]:
+        from sklearn.metrics import average_precision_score, roc_auc_score
+        self.model.eval()
+        preds, labs, losses = [], [], []
+        for batch in batches:
+            feat_d, feat_p, labels, llm_d, llm_p = batch
+            _, _, _, _, score = self.model(feat_d, feat_p, llm_d, llm_p)
+            n, loss = binary_cross_entropy(score, labels) if self.n_class == 1 else cross_entropy_logits(score, labels)
+            preds.append(n.float())
+            labs.append(labels.float())
+            losses.append(loss.float().reshape(1))
+        p, y = torch.cat(preds), torch.cat(labs)
+        if self.world > 1:
+            ps = [torch.empty_like(p) for _ in range(self.world)]
+            ys = [torch.empty_like(y) for _ in range(self.world)]
+            dist.all_gather(ps, p)
+            dist.all_gather(ys, y)
+            p, y = torch.cat(ps), torch.cat(ys)
+        p, y = p.cpu().numpy(), y.cpu().numpy()
+        auroc = float(roc_auc_score(y, p)) if len(set(y.tolist())) > 1 else float("nan")
+        auprc = float(average_precision_score(y, p)) if y.sum() > 0 else float("nan")
+        yhat = (p >= 0.5).astype("float32")
+        tp, tn = float(((yhat == 1) & (y == 1)).sum()), float(((yhat == 0) & (y == 0)).sum())
+        fp, fn = float(((yhat == 1) & (y == 0)).sum()), float(((yhat == 0) & (y == 1)).sum())
+        prec = tp / max(tp + fp, 1.0)
+        rec = tp / max(tp + fn, 1.0)
+        return {"loss": float(torch.cat(losses).mean()), "auroc": auroc, "auprc": auprc, "ausum": auroc + auprc,
+                "acc": (tp + tn) / max(len(y), 1), "sn": rec, "sp": tn / max(tn + fp, 1.0), "pr": prec,
+                "f1": 2 * prec * rec / max(prec + rec, 1e-12)}

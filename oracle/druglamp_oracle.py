@@ -337,3 +337,70 @@ def cm_forward(sd: SD, p: str, prot, aug_prot, drug, aug_drug, meta: List[dict],
     dl = F.normalize(F.linear(de, sd[p + ".to_drug_latent.weight"]), dim=-1)
     loss = triplet_sigcos(pl, dl, gt, margin)
     return (loss, pl, dl, gt) if return_latents else loss
+
+
+# ------------------------------------------------------------------------------------------
+# training step (trainer.py:179-231) — also the CPU baseline timed by bench.py
+# ------------------------------------------------------------------------------------------
+class OracleTrainer:
+    """The reference's manual-optimisation step on the functional oracle model: three torch AdamW over
+    the SAME parameter list (main.py:158-160), zero_grad before each loss's backward, cm-weight
+    auto-scale at cur_epoch == INIT_EPOCH.  Lazily created SimSiam projectors are in no optimiser."""
+
+    def __init__(self, sd: SD, kind: str, lr=1e-4, ssl_lr=3e-5, cm_lr=3e-5, use_ssl=True, use_cm=True,
+                 epoch_step=5, init_epoch=5, max_margin=0.5, n_re=100):
+        self.sd, self.kind = sd, kind
+        self.params = []
+        for k, v in sd.items():
+            if v.is_floating_point() and "running_" not in k and ".projector." not in k:
+                v.requires_grad_(True)
+                self.params.append(v)
+        # `protein_extractor.*` and `ssl_model.extractor.*` are the same tensors: optimise them once
+        uniq, seen = [], set()
+        for p in self.params:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        self.params = uniq
+        self.opt = torch.optim.AdamW(self.params, lr=lr)
+        self.opt_ssl = torch.optim.AdamW(self.params, lr=ssl_lr) if use_ssl else None
+        self.opt_cm = torch.optim.AdamW(self.params, lr=cm_lr) if use_cm else None
+        self.use_ssl, self.use_cm, self.epoch_step, self.init_epoch = use_ssl, use_cm, epoch_step, init_epoch
+        self.margin = MarginSchedule(max_margin, n_re)
+        self.cm_weight = 1.0
+
+    def step(self, vd, vp, xd, xp, y, meta=None, cur_epoch=1, mask=None, replace=None):
+        compute_ssl = self.use_ssl and cur_epoch % self.epoch_step == 0
+        compute_cm = self.use_cm and cur_epoch >= self.init_epoch
+        out = model_forward(self.sd, self.kind, vd, vp, xd, xp, bn_training=True)
+        self.opt.zero_grad()
+        _, cls = bce_loss(out["score"], y)
+        cls.backward(retain_graph=compute_ssl or compute_cm)
+        rec = {"cls": float(cls), "ssl": 0.0, "cm": 0.0}
+        if compute_ssl:
+            self.opt_ssl.zero_grad()
+            s = out["ssl"]
+            mode = s.get("p_mode", "double")
+            prot = prot_mlm_loss(self.sd, "ssl_model", s["vp"], s["xp"], s["fill_bit_p"], mode, mask, replace)
+            drug = simsiam_loss(self.sd, "ssl_model", s["vd"], s["xd"]) if s["xd"] is not None else 0.0
+            ssl = (prot + drug) * 0.1
+            ssl.backward(retain_graph=compute_cm)
+            rec["ssl"] = float(ssl)
+        if compute_cm:
+            self.opt_cm.zero_grad()
+            cm = cm_forward(self.sd, "cm_model", **out["cm"], meta=meta, margin=self.margin.margin)
+            if cur_epoch == self.init_epoch and float(cm) > 0:
+                while float(cm) * self.cm_weight / 10 > float(cls):
+                    self.cm_weight /= 10
+                while float(cm) * self.cm_weight * 10 < float(cls):
+                    self.cm_weight *= 10
+            cm = cm * self.cm_weight
+            cm.backward()
+            rec["cm"] = float(cm)
+        self.opt.step()
+        if compute_ssl:
+            self.opt_ssl.step()
+        if compute_cm:
+            self.opt_cm.step()
+        rec["cm_weight"] = self.cm_weight
+        return rec

@@ -1,0 +1,160 @@
+"""GPU parity of the whole models, the SSL / CM heads and the training-step sequence against the
+reference's golden outputs (fp32 compute: north-star tolerance 1e-4 on outputs)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import check_sub, det_state_dict, gradnorms, load, model_inputs, relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(kind, g, dtype=torch.float32, projectors=False):
+    from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
+    from druglamp_amd.model import MInterface
+    cfg = load_yaml_into(get_cfg_defaults(), kind)
+    m = MInterface(kind, cfg).load_model(n_drug_feature=384, n_prot_feature=640)
+    if projectors:
+        m.ssl_model.build_projectors(128, 385)
+    sd = det_state_dict(g)
+    own = m.state_dict()
+    for k in own:                      # the fixture models ran with the GCN bypassed: keep own init there
+        if k.startswith("drug_extractor."):
+            sd[k] = own[k]
+    m.load_state_dict(sd, strict=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.pmma.p_drop = 0.0
+    m.pmma.embeddings.p_drop = 0.0
+    m = m.to(DEV)
+    m.set_compute_dtype(dtype)
+    return m, cfg
+
+
+def to_dev(*ts):
+    return tuple(t.to(DEV) for t in ts)
+
+
+@pytest.mark.parametrize("kind", ["DrugLAMP", "DrugLAMP2C2P", "DrugLAMPwoLLM"])
+def test_model_eval_and_train(kind):
+    g = load("model_" + kind)
+    m, _ = build(kind, g)
+    vd, vp, xd, xp, y = to_dev(*model_inputs("model." + kind, 2))
+    m.eval()
+    with torch.no_grad():
+        out = m(vd, vp, xd, xp)
+    assert len(out) == 5
+    score = out[4]
+    assert relerr(score, g["score"]) <= 1e-4
+    check_sub(out[1], g, "vp", 1e-4)
+    assert relerr(m.A_v_gca[:, :, :4, :8], g["A_v"]) <= 1e-4
+    if kind != "DrugLAMPwoLLM":
+        assert relerr(m.A_x_gca[:, :, :4, :8], g["A_x"]) <= 1e-4
+    if kind == "DrugLAMP2C2P":
+        check_sub(out[3]["aug_prot"], g, "cm_aug_prot", 1e-4)
+        check_sub(out[3]["aug_drug"], g, "cm_aug_drug", 1e-4)
+    with torch.no_grad():
+        ev = m(vd, vp, xd, xp, mode="eval")
+    assert len(ev) == 4 and relerr(ev[2], g["score"]) <= 1e-4
+    # train-mode BN, BCE backward
+    from druglamp_amd.model.basic_model import binary_cross_entropy
+    vd, vp, xd, xp, y = to_dev(*model_inputs("modeltrain." + kind, 8))
+    m.train()
+    m.zero_grad()
+    out = m(vd, vp, xd, xp)
+    assert relerr(out[4], g["score_train"]) <= 1e-3
+    n, loss = binary_cross_entropy(out[4], y)
+    assert abs(float(loss) - float(g["cls_loss"])) <= 1e-4
+    loss.backward()
+    ref = gradnorms(g)
+    sd = dict(m.named_parameters())
+    scale = max(ref.values())
+    for k, n_ref in ref.items():
+        if k.startswith("ssl_model.extractor."):
+            continue                                  # alias of protein_extractor.* (shared module)
+        got = float(sd[k].grad.double().norm())
+        assert abs(got - n_ref) <= 2e-3 * max(n_ref, 1e-5 * scale), (k, got, n_ref)
+
+
+def _unpack(bits, shape):
+    return torch.from_numpy(np.unpackbits(bits)[:int(np.prod(shape))].reshape(shape).astype(bool)).to(DEV)
+
+
+def test_ssl_cm_losses():
+    g = load("ssl_cm")
+    m, _ = build("DrugLAMP2C2P", g, projectors=True)
+    B = 6
+    vd, vp, xd, xp, y = to_dev(*model_inputs("sslcm", B))
+    m.train()
+    _, _, ssl, cm, score = m(vd, vp, xd, xp)
+    mask, replace = _unpack(g["mask"], (B, 2304)), _unpack(g["replace"], (B, 2304))
+    d = m.ssl_model(**ssl, mask=mask, replace=replace)
+    assert abs(float(d["prot_ssl"]) - float(g["prot_ssl"])) <= 1e-4 * abs(float(g["prot_ssl"]))
+    assert abs(float(d["drug_ssl"]) - float(g["drug_ssl"])) <= 1e-4 * abs(float(g["drug_ssl"]))
+    meta = [{"Prot_ID": int(p), "Drug_ID": int(dd), "Y": float(y[t])} for t, (p, dd) in
+            enumerate(zip(g["meta_pid"], g["meta_did"]))]
+    cm_loss = m.cm_model(**cm, meta=meta)
+    assert abs(float(cm_loss) - float(g["cm_loss"])) <= 1e-4 * max(abs(float(g["cm_loss"])), 1e-3)
+    # gradients of both heads
+    m.zero_grad()
+    ((d["prot_ssl"] + d["drug_ssl"]) * 0.1).backward(retain_graph=True)
+    ref = gradnorms(g, "gradnorm_ssl")
+    sd = dict(m.named_parameters())
+    scale = max(ref.values())
+    for k, n_ref in ref.items():
+        if k.startswith("ssl_model.extractor."):
+            continue
+        got = float(sd[k].grad.double().norm()) if sd[k].grad is not None else 0.0
+        assert abs(got - n_ref) <= 5e-3 * n_ref + 1e-5 * scale, ("ssl", k, got, n_ref)
+    m.zero_grad()
+    cm_loss.backward()
+    ref = gradnorms(g, "gradnorm_cm")
+    scale = max(ref.values())
+    for k, n_ref in ref.items():
+        if k.startswith("ssl_model.extractor."):
+            continue
+        got = float(sd[k].grad.double().norm()) if sd[k].grad is not None else 0.0
+        assert abs(got - n_ref) <= 5e-3 * n_ref + 1e-5 * scale, ("cm", k, got, n_ref)
+
+
+def test_training_step_sequence():
+    """trainer.Trainer (flat arena, fused AdamW runs) against the reference-driven sequence."""
+    from druglamp_amd.trainer import Trainer
+    g = load("train_steps")
+    m, cfg = build("DrugLAMP2C2P", g, projectors=True)
+    B = 8
+    vd, vp, xd, xp, y = to_dev(*model_inputs("train", B))
+    meta = [{"Prot_ID": [0, 1, 0, 2, 3, 1, 4, 0][t], "Drug_ID": [5, 5, 6, 7, 5, 8, 9, 7][t], "Y": float(y[t])}
+            for t in range(B)]
+    # the reference run used optimisers that exclude the lazily created projectors and the bypassed GCN
+    keep = [p for n, p in m.named_parameters() if ".projector." not in n and not n.startswith("drug_extractor.")]
+    for n, p in m.named_parameters():
+        if ".projector." in n or n.startswith("drug_extractor."):
+            p.requires_grad_(False)
+    tr = Trainer.__new__(Trainer)
+    Trainer.__init__(tr, m, cfg)
+    tr.set_lrs(1e-4, 3e-5, 3e-5)       # the recorded run used constant learning rates
+    flat_idx = [i for i, p in enumerate(tr.flat.params) if p.requires_grad]
+
+    def snapshot():
+        return torch.cat([tr.flat.params[i].detach().flatten() for i in flat_idx]).double()
+    before = snapshot()
+    mi = 0
+    for step, ep in enumerate([1, 5, 5, 6]):
+        masks = None
+        if ep % 5 == 0:
+            masks = (_unpack(g["masks"][mi], (B, 2304)), _unpack(g["replaces"][mi], (B, 2304)))
+            mi += 1
+        rec = tr.training_step((vd, vp, y, xd, xp), meta=meta, cur_epoch=ep, ssl_masks=masks)
+        after = snapshot()
+        assert abs(float(rec["cls"]) - g["cls"][step]) <= 3e-4 * abs(g["cls"][step]), (step, float(rec["cls"]))
+        if "ssl" in rec:
+            assert abs(float(rec["ssl"]) - g["ssl"][step]) <= 3e-4 * abs(g["ssl"][step]), (step, float(rec["ssl"]))
+        if "cm" in rec:
+            assert abs(float(rec["cm"]) - g["cm"][step]) <= 3e-3 * max(abs(g["cm"][step]), 1e-6), (step, float(rec["cm"]))
+        assert tr.cm_weight == g["cm_weight"][step]
+        delta = float((after - before).norm())
+        assert abs(delta - g["delta"][step]) <= 3e-2 * g["delta"][step], (step, delta, g["delta"][step])
+        before = after
