@@ -8,6 +8,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (must be imported BEFORE the dlopen below: the library then binds to the HIP runtime
+#                            torch already loaded instead of bringing up a second, device-less copy)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdruglamp_hip.so")
 
@@ -76,6 +79,12 @@ SIGNATURES = {
     "dl_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "dl_colsum": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "dl_colsum_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "dl_bn_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "dl_bn_stats": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "dl_bn_apply_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "dl_bn_bwd_reduce": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "dl_bn_bwd_apply": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                c_i32, c_vp]),
     "dl_layernorm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "dl_layernorm_bwd_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "dl_layernorm_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,

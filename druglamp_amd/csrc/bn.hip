@@ -1,0 +1,176 @@
+// bn.hip — channel-last BatchNorm pieces for the ProteinCNN path (HBM-bound column statistics +
+// elementwise apply), with a row-validity window so that zero-padding halos stay zero.
+#include "common.cuh"
+
+namespace {
+constexpr int BN_ROWS_PER_BLOCK = 256;
+
+__device__ __forceinline__ bool row_valid(int64_t r, int64_t win, int64_t halo, int64_t valid) {
+  if (win == 0) return true;
+  const int64_t q = r % win;
+  return q >= halo && q < halo + valid;
+}
+
+// grid (ceil(C/256), chunks); lane -> 4 columns; MODE 0: (y, y^2); MODE 1: (dz, dz*yhat)
+template <typename T, int MODE>
+__global__ void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const float* __restrict__ mean,
+                                  const float* __restrict__ rstd, int64_t R, int C, int64_t win, int64_t halo,
+                                  int64_t valid, float* __restrict__ partial) {
+  __shared__ f32x4 red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS_PER_BLOCK;
+  const int64_t r1 = min(R, r0 + BN_ROWS_PER_BLOCK);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f};
+    if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + c); rs = *reinterpret_cast<const f32x4*>(rstd + c); }
+    for (int64_t r = r0 + wave; r < r1; r += 4) {
+      if (!row_valid(r, win, halo, valid)) continue;
+      const f32x4 v = load4<T>(a + r * C + c);
+      if (MODE == 0) { s0 += v; s1 += v * v; }
+      else {
+        const f32x4 yv = load4<T>(y + r * C + c);
+        s0 += v; s1 += v * ((yv - mu) * rs);
+      }
+    }
+  }
+  red[0][wave][lane] = s0; red[1][wave][lane] = s1;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    s0 = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    s1 = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    float* d0 = partial + ((int64_t)blockIdx.y * 2 + 0) * C + c;
+    float* d1 = partial + ((int64_t)blockIdx.y * 2 + 1) * C + c;
+    *reinterpret_cast<f32x4*>(d0) = s0; *reinterpret_cast<f32x4*>(d1) = s1;
+  }
+}
+__global__ void bn_final_kernel(const float* __restrict__ partial, int chunks, int C, float* __restrict__ sums) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C) return;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * 2 * C + i];
+  sums[i] = s;
+}
+
+template <typename T>
+__global__ void bn_apply_fwd_kernel(const T* __restrict__ y, T* __restrict__ z, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, int64_t R, int C, int64_t win, int64_t halo,
+                                    int64_t valid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (i >= R * c4) return;
+  const int64_t r = i / c4;
+  const int c = (int)(i % c4) * 4;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  if (row_valid(r, win, halo, valid)) {
+    const f32x4 v = load4<T>(y + r * C + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+    o = (v - mu) * rs * g + b;
+  }
+  store4<T>(z + r * C + c, o);
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sums, float inv_n, int relu_mask, T* __restrict__ dy,
+                                    int64_t R, int C, int64_t win, int64_t halo, int64_t valid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (i >= R * c4) return;
+  const int64_t r = i / c4;
+  const int c = (int)(i % c4) * 4;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  if (row_valid(r, win, halo, valid)) {
+    const f32x4 d = load4<T>(dz + r * C + c), yv = load4<T>(y + r * C + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c), s1 = *reinterpret_cast<const f32x4*>(sums + C + c);
+    const f32x4 yh = (yv - mu) * rs;
+    o = g * rs * (d - s0 * inv_n - yh * (s1 * inv_n));
+    if (relu_mask) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = yv[e] > 0.f ? o[e] : 0.f;
+    }
+  }
+  store4<T>(dy + r * C + c, o);
+}
+}  // namespace
+
+extern "C" size_t dl_bn_workspace_bytes(int64_t R, int64_t C) {
+  const int64_t chunks = (R + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK;
+  return (size_t)chunks * 2 * (size_t)C * sizeof(float);
+}
+
+template <int MODE>
+static int bn_reduce(const char* who, const void* a, const void* y, const float* mean, const float* rstd, int64_t R,
+                     int64_t C, int64_t win, int64_t halo, int64_t valid, int32_t dtype, float* sums, void* ws,
+                     size_t ws_bytes, hipStream_t s) {
+  DL_CHECK_ARG(a && sums && R > 0 && C > 0 && C % 4 == 0, DL_ERR_ARG, "%s: bad args", who);
+  DL_CHECK_ARG(ws && ws_bytes >= dl_bn_workspace_bytes(R, C), DL_ERR_WORKSPACE, "%s: workspace too small", who);
+  const int chunks = (int)((R + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
+  dim3 grid((uint32_t)((C + 255) / 256), (uint32_t)chunks);
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((bn_partial_kernel<bf16_t, MODE>), grid, dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)y,
+                       mean, rstd, R, (int)C, win, halo, valid, (float*)ws);
+  else
+    hipLaunchKernelGGL((bn_partial_kernel<float, MODE>), grid, dim3(256), 0, s, (const float*)a, (const float*)y, mean,
+                       rstd, R, (int)C, win, halo, valid, (float*)ws);
+  hipLaunchKernelGGL(bn_final_kernel, dim3((uint32_t)((2 * C + 255) / 256)), dim3(256), 0, s, (const float*)ws, chunks,
+                     (int)C, sums);
+  DL_CHECK_LAUNCH(who);
+  return DL_OK;
+}
+
+extern "C" int dl_bn_stats(const void* y, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid, int32_t dtype,
+                           float* sums, void* workspace, size_t workspace_bytes, dl_stream stream) {
+  return bn_reduce<0>("dl_bn_stats", y, nullptr, nullptr, nullptr, R, C, win, halo, valid, dtype, sums, workspace,
+                      workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int dl_bn_bwd_reduce(const void* dz, const void* y, const float* mean, const float* rstd, int64_t R, int64_t C,
+                                int64_t win, int64_t halo, int64_t valid, int32_t dtype, float* sums, void* workspace,
+                                size_t workspace_bytes, dl_stream stream) {
+  DL_CHECK_ARG(y && mean && rstd, DL_ERR_ARG, "dl_bn_bwd_reduce: null pointer");
+  return bn_reduce<1>("dl_bn_bwd_reduce", dz, y, mean, rstd, R, C, win, halo, valid, dtype, sums, workspace,
+                      workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int dl_bn_apply_fwd(const void* y, void* z, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid,
+                               int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(y && z && mean && rstd && gamma && beta && R > 0 && C > 0 && C % 4 == 0, DL_ERR_ARG,
+               "dl_bn_apply_fwd: bad args");
+  const int64_t n = R * (C / 4);
+  const uint32_t blocks = (uint32_t)((n + 255) / 256);
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((bn_apply_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean,
+                       rstd, gamma, beta, R, (int)C, win, halo, valid);
+  else
+    hipLaunchKernelGGL((bn_apply_fwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)y, (float*)z, mean,
+                       rstd, gamma, beta, R, (int)C, win, halo, valid);
+  DL_CHECK_LAUNCH("dl_bn_apply_fwd");
+  return DL_OK;
+}
+
+extern "C" int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean, const float* rstd, const float* gamma,
+                               const float* sums, float inv_n, int32_t relu_mask, void* dy, int64_t R, int64_t C,
+                               int64_t win, int64_t halo, int64_t valid, int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(dz && y && mean && rstd && gamma && sums && dy && R > 0 && C > 0 && C % 4 == 0, DL_ERR_ARG,
+               "dl_bn_bwd_apply: bad args");
+  const int64_t n = R * (C / 4);
+  const uint32_t blocks = (uint32_t)((n + 255) / 256);
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y,
+                       mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, R, (int)C, win, halo, valid);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)dz, (const float*)y,
+                       mean, rstd, gamma, sums, inv_n, relu_mask, (float*)dy, R, (int)C, win, halo, valid);
+  DL_CHECK_LAUNCH("dl_bn_bwd_apply");
+  return DL_OK;
+}

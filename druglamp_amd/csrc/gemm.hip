@@ -201,6 +201,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
         if (p.act == 1) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
         }
         if (p.dact_pre) {
           const T* src = reinterpret_cast<const T*>(p.dact_pre) + (int64_t)m * p.lddp + n;

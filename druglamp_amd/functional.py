@@ -519,3 +519,115 @@ class TripletSigCosFn(torch.autograd.Function):
         p, d, gt, buf, ntri = ctx.saved_tensors
         dp, dd = ops.triplet_sigcos_bwd(p, d, gt, ctx.margin, buf, ntri, 1.0)
         return dp * dl, dd * dl, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# ProteinCNN: 3 x [Conv1d('same') -> ReLU -> BatchNorm1d] as channel-last implicit GEMMs
+# ------------------------------------------------------------------------------------------------
+_CNN_HALO = 4          # zero rows kept on each side of every sample (max 'same' padding of k = 9)
+
+
+def _conv_weight(w: torch.Tensor, dtype: torch.dtype, backward: bool) -> torch.Tensor:
+    """Conv1d weight [co][ci][k] as the GEMM operand of the overlapping-row formulation.
+    forward : Wg[co][j*ci + c]  = w[co][c][j]
+    backward: Wd[ci][j'*co + o] = w[o][ci][k-1-j']   (data gradient = correlation with the flipped kernel)"""
+    key = ((id(w), "convb" if backward else "convf"), dtype)
+    ver = (_param_epoch, w._version)
+    hit = _lowp_cache.get(key)
+    if hit is not None and hit[0] == ver and hit[2][0]() is w:
+        return hit[1]
+    with torch.no_grad():
+        co, ci, k = w.shape
+        if backward:
+            g = w.detach().flip(2).permute(1, 2, 0).reshape(ci, k * co)
+        else:
+            g = w.detach().permute(0, 2, 1).reshape(co, k * ci)
+        g = g.contiguous()
+        if g.dtype != dtype:
+            g = ops.cast(g, dtype)
+    _lowp_cache[key] = (ver, g, (weakref.ref(w),))
+    return g
+
+
+class ProteinCNNFn(torch.autograd.Function):
+    """x: [B, L + 2*HALO, C] channel-last with zero halo rows (embedding + fill bit, already padded).
+    Each Conv1d with kernel k and 'same' padding (left (k-1)//2, right k-1-left, as torch pads) is ONE
+    dl_gemm whose A operand has row pitch C and K = k*C: consecutive rows overlap, so the im2col matrix
+    is never built.  Bias + ReLU ride in the GEMM epilogue; BatchNorm = masked column statistics + one
+    elementwise pass that also re-zeroes the halo rows.  Returns (z [B, L, C] view, batch mean/var x3)."""
+
+    @staticmethod
+    def forward(ctx, x, training, eps, *params):
+        B, LP, C = x.shape
+        Lv = LP - 2 * _CNN_HALO
+        R = B * LP
+        cdt = x.dtype
+        x2 = x.reshape(R, C)
+        n = B * Lv
+        saved, stats_out, meta = [], [], []
+        cur = x2
+        for i in range(3):
+            w, b, gamma, beta, rmean, rvar = params[i * 6:(i + 1) * 6]
+            k = w.shape[2]
+            pl = (k - 1) // 2
+            Wg = _conv_weight(w, cdt, False)
+            y = torch.empty((R, C), dtype=cdt, device=x.device)
+            Mg = R - (k - 1)
+            ops.gemm(cur, Wg, M=Mg, N=C, K=k * C, ldx=C, bias=_f32(b), act=2, out=y[pl:pl + Mg])
+            if training:
+                sums = ops.bn_stats(y, LP, _CNN_HALO, Lv)
+                mean = sums[:C] / n
+                var = (sums[C:] / n - mean * mean).clamp_(min=0)
+            else:
+                mean, var = rmean.detach().float(), rvar.detach().float()
+            rstd = torch.rsqrt(var + eps)
+            z = ops.bn_apply_fwd(y, mean, rstd, gamma.detach().float(), beta.detach().float(), LP, _CNN_HALO, Lv)
+            saved += [cur, y, mean, rstd, gamma.detach().float()]
+            stats_out += [mean, var]
+            meta.append((k, pl, w))
+            cur = z
+        ctx.save_for_backward(*saved)
+        ctx.cfg = (B, LP, C, Lv, training)
+        ctx.weights = [m[2] for m in meta]
+        out = cur.reshape(B, LP, C)[:, _CNN_HALO:_CNN_HALO + Lv]
+        ctx.mark_non_differentiable(*stats_out)
+        return (out,) + tuple(stats_out)
+
+    @staticmethod
+    def backward(ctx, dout, *_):
+        B, LP, C, Lv, training = ctx.cfg
+        if not training:
+            raise RuntimeError("ProteinCNNFn.backward is only implemented for training-mode BatchNorm")
+        sv = ctx.saved_tensors
+        R = B * LP
+        n = B * Lv
+        cdt = sv[0].dtype
+        dz = torch.zeros((B, LP, C), dtype=cdt, device=dout.device)
+        dz[:, _CNN_HALO:_CNN_HALO + Lv] = dout
+        dz = dz.reshape(R, C)
+        grads = [None] * 18
+        for i in (2, 1, 0):
+            xin, y, mean, rstd, gamma = sv[i * 5:(i + 1) * 5]
+            w = ctx.weights[i]
+            k = w.shape[2]
+            pl = (k - 1) // 2
+            pr = k - 1 - pl
+            Mg = R - (k - 1)
+            sums = ops.bn_bwd_reduce(dz, y, mean, rstd, LP, _CNN_HALO, Lv)
+            dpre = ops.bn_bwd_apply(dz, y, mean, rstd, gamma, sums, 1.0 / n, True, LP, _CNN_HALO, Lv)
+            dWg = ops.gemm(dpre[pl:pl + Mg], xin, M=C, N=k * C, K=Mg, x_kslow=True, w_kslow=True, ldx=C, ldw=C,
+                           out_dtype=torch.float32, split_k=0)
+            grads[i * 6 + 0] = dWg.reshape(C, k, C).permute(0, 2, 1).contiguous()
+            grads[i * 6 + 1] = ops.colsum(dpre)
+            grads[i * 6 + 2] = sums[C:].clone()
+            grads[i * 6 + 3] = sums[:C].clone()
+            if i > 0 or ctx.needs_input_grad[0]:
+                Wd = _conv_weight(w, cdt, True)
+                dprev = torch.empty((R, C), dtype=cdt, device=dout.device)
+                ops.gemm(dpre, Wd, M=Mg, N=C, K=k * C, ldx=C, out=dprev[pr:pr + Mg])
+                dz = dprev
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros((B, LP, C), dtype=cdt, device=dout.device)
+            dx[:, _CNN_HALO:_CNN_HALO + Lv] = dz.reshape(B, LP, C)[:, _CNN_HALO:_CNN_HALO + Lv]
+        return (dx, None, None) + tuple(grads)

@@ -125,14 +125,32 @@ class ProteinCNN(nn.Module):
         self.conv3 = nn.Conv1d(in_ch[2], in_ch[3], kernel_size[2], padding="same")
         self.bn3 = nn.BatchNorm1d(in_ch[3])
 
+    compute_dtype = torch.float32
+
     def forward(self, v, fill_mask):
-        v = self.embedding(v.long())
-        v = torch.cat((v, fill_mask.unsqueeze(-1).to(v.dtype)), dim=-1).transpose(2, 1)
-        v = self.bn1(F.relu(self.conv1(v)))
-        v = self.bn2(F.relu(self.conv2(v)))
-        v = self.bn3(F.relu(self.conv3(v)))
-        v = v.contiguous()
-        return v.view(v.size(0), v.size(2), -1)
+        """Embedding lookup + fill bit are torch glue; the three Conv1d + ReLU + BatchNorm1d stages run as
+        channel-last implicit GEMMs + BatchNorm kernels (functional.ProteinCNNFn).  The reference's final
+        `.view(B, L, C)` of the channel-first (B, C, L) buffer is reproduced exactly."""
+        from ..functional import _CNN_HALO, ProteinCNNFn, cast
+        x = self.embedding(v.long())
+        x = torch.cat((x, fill_mask.unsqueeze(-1).to(x.dtype)), dim=-1)            # (B, L, C) channel-last
+        B, L, C = x.shape
+        x = F.pad(cast(x.float(), self.compute_dtype), (0, 0, _CNN_HALO, _CNN_HALO))
+        params = []
+        for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)):
+            params += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        outs = ProteinCNNFn.apply(x, self.training, self.bn1.eps, *params)
+        z = outs[0]
+        if self.training:
+            n = B * L
+            with torch.no_grad():
+                for i, bn in enumerate((self.bn1, self.bn2, self.bn3)):
+                    mean, var = outs[1 + 2 * i], outs[2 + 2 * i]
+                    bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
+                    bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
+                    bn.num_batches_tracked += 1
+        z = z.transpose(1, 2).contiguous()                                          # (B, C, L) like the reference
+        return z.view(B, L, C)
 
 
 class FeedForwardLayer(nn.Module):
@@ -217,7 +235,7 @@ class DrugLAMPBase(nn.Module):
             raise ValueError("compute dtype must be float32 or bfloat16")
         self.compute_dtype = dtype
         for m in self.modules():
-            if isinstance(m, (GuidedCrossAttention, MultiHeadLinearAttention, PairedMultimodelAttention)):
+            if isinstance(m, (GuidedCrossAttention, MultiHeadLinearAttention, PairedMultimodelAttention, ProteinCNN)):
                 m.compute_dtype = dtype
         return self
 

@@ -320,3 +320,40 @@ def triplet_sigcos_bwd(p_lats, d_lats, gt_i8, margin: float, buf, ntri, grad_out
                                            n_d, dim, float(margin), ntri.data_ptr(), float(grad_out), dp.data_ptr(),
                                            dd.data_ptr(), _stream()), "dl_triplet_sigcos_bwd")
     return dp, dd
+
+
+def bn_stats(y2d, win, halo, valid):
+    R, Cc = y2d.shape
+    L = _lib.lib()
+    sums = torch.empty(2 * Cc, dtype=torch.float32, device=y2d.device)
+    ws = _ws2.get(L.dl_bn_workspace_bytes(R, Cc), y2d.device)
+    check(L.dl_bn_stats(y2d.data_ptr(), R, Cc, win, halo, valid, _dt(y2d), sums.data_ptr(), ws.data_ptr(), ws.numel(),
+                        _stream()), "dl_bn_stats")
+    return sums
+
+
+def bn_apply_fwd(y2d, mean, rstd, gamma, beta, win, halo, valid):
+    R, Cc = y2d.shape
+    z = torch.empty_like(y2d)
+    check(_lib.lib().dl_bn_apply_fwd(y2d.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                     beta.data_ptr(), R, Cc, win, halo, valid, _dt(y2d), _stream()), "dl_bn_apply_fwd")
+    return z
+
+
+def bn_bwd_reduce(dz2d, y2d, mean, rstd, win, halo, valid):
+    R, Cc = y2d.shape
+    L = _lib.lib()
+    sums = torch.empty(2 * Cc, dtype=torch.float32, device=y2d.device)
+    ws = _ws2.get(L.dl_bn_workspace_bytes(R, Cc), y2d.device)
+    check(L.dl_bn_bwd_reduce(dz2d.data_ptr(), y2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), R, Cc, win, halo, valid,
+                             _dt(y2d), sums.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_bn_bwd_reduce")
+    return sums
+
+
+def bn_bwd_apply(dz2d, y2d, mean, rstd, gamma, sums, inv_n, relu_mask, win, halo, valid):
+    R, Cc = y2d.shape
+    dy = torch.empty_like(y2d)
+    check(_lib.lib().dl_bn_bwd_apply(dz2d.data_ptr(), y2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                     sums.data_ptr(), float(inv_n), int(relu_mask), dy.data_ptr(), R, Cc, win, halo, valid,
+                                     _dt(y2d), _stream()), "dl_bn_bwd_apply")
+    return dy

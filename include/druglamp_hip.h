@@ -71,7 +71,7 @@ typedef struct {
   const void* residual; int64_t ldr; /* in_dtype, [M or res_row_mod][N] or NULL */
   int64_t res_row_mod;               /* >0: residual row = m % res_row_mod (positional table) */
   int32_t res_before_dropout;
-  int32_t act;                       /* 0 none, 1 exact-erf GELU */
+  int32_t act;                       /* 0 none, 1 exact-erf GELU, 2 ReLU */
   void* pre_out; int64_t ldp;        /* in_dtype, pre-activation copy or NULL */
   const void* dact_pre; int64_t lddp;/* in_dtype, multiply by gelu'(dact_pre[m,n]) or NULL */
   float dropout_p; uint64_t dropout_seed;
@@ -86,6 +86,33 @@ int dl_gemm(const dl_gemm_args* a, dl_stream s);
 int dl_colsum(const void* X, int64_t ldx, int64_t M, int64_t N, int32_t dtype, float* out,
               int32_t accumulate, void* workspace, size_t workspace_bytes, dl_stream s);
 size_t dl_colsum_workspace_bytes(int64_t M, int64_t N);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm over the rows of a channel-last [R][C] matrix (ProteinCNN's BatchNorm1d after each
+ * Conv1d+ReLU, model/basic_model.py:176-178, with activations kept channel-last so that each Conv1d
+ * is ONE dl_gemm over overlapping rows; see druglamp_amd/functional.py ProteinCNNFn).
+ * Row validity: rows are grouped in windows of `win` rows; row r takes part iff
+ * halo <= (r % win) < halo + valid  (win == 0: every row).  Invalid (halo) rows are written as zeros
+ * by the apply kernels, so the next convolution sees zero padding.
+ *   stats      : sums[0..C) = sum_r y, sums[C..2C) = sum_r y^2 over valid rows (fp32)
+ *   apply_fwd  : z = (y - mean) * rstd * gamma + beta
+ *   bwd_reduce : sums[0..C) = sum dz, sums[C..2C) = sum dz * yhat       (yhat = (y-mean)*rstd)
+ *   bwd_apply  : dy = gamma*rstd*(dz - sums0/n - yhat*sums1/n), then * (y > 0) when relu_mask
+ *                (y is the post-ReLU conv output that fed the BatchNorm)
+ * ------------------------------------------------------------------------------------------ */
+size_t dl_bn_workspace_bytes(int64_t R, int64_t C);
+int dl_bn_stats(const void* y, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid,
+                int32_t dtype, float* sums, void* workspace, size_t workspace_bytes, dl_stream s);
+int dl_bn_apply_fwd(const void* y, void* z, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid,
+                    int32_t dtype, dl_stream s);
+int dl_bn_bwd_reduce(const void* dz, const void* y, const float* mean, const float* rstd, int64_t R,
+                     int64_t C, int64_t win, int64_t halo, int64_t valid, int32_t dtype, float* sums,
+                     void* workspace, size_t workspace_bytes, dl_stream s);
+int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean, const float* rstd,
+                    const float* gamma, const float* sums, float inv_n, int32_t relu_mask, void* dy,
+                    int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid, int32_t dtype,
+                    dl_stream s);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps 1e-6 inside PMMA: model/PMMA/block.py:23-27,
