@@ -3,7 +3,7 @@
 #include "common.cuh"
 
 namespace {
-constexpr int BN_ROWS_PER_BLOCK = 256;
+constexpr int BN_ROWS_PER_BLOCK = 1024;
 
 __device__ __forceinline__ bool row_valid(int64_t r, int64_t win, int64_t halo, int64_t valid) {
   if (win == 0) return true;
@@ -119,8 +119,8 @@ static int bn_reduce(const char* who, const void* a, const void* y, const float*
   else
     hipLaunchKernelGGL((bn_partial_kernel<float, MODE>), grid, dim3(256), 0, s, (const float*)a, (const float*)y, mean,
                        rstd, R, (int)C, win, halo, valid, (float*)ws);
-  hipLaunchKernelGGL(bn_final_kernel, dim3((uint32_t)((2 * C + 255) / 256)), dim3(256), 0, s, (const float*)ws, chunks,
-                     (int)C, sums);
+  hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((2 * C + 63) / 64)), dim3(256), 0, s, (const float*)ws,
+                     chunks, (int64_t)(2 * C), (int)(2 * C), sums, 0);
   DL_CHECK_LAUNCH(who);
   return DL_OK;
 }

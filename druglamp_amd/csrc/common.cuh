@@ -218,3 +218,10 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblocks) {
   const uint32_t start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return start + loc;
 }
+
+// Second stage of the two-stage column reductions: out[c] (+)= sum_k partial[k*stride + c], c < ncols.
+// One workgroup (4 waves) per 64 columns; wave w takes chunks w, w+4, ... with 4 independent
+// accumulators (loads are coalesced 256-byte rows), then the 4 waves combine through LDS.
+// Deterministic (fixed summation order).
+__global__ void dl_reduce_partials_kernel(const float* __restrict__ partial, int chunks, int64_t stride, int ncols,
+                                          float* __restrict__ out, int accumulate);

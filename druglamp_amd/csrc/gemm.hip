@@ -394,7 +394,7 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
 
 // ---- column sums ------------------------------------------------------------------------------
 namespace {
-constexpr int CS_ROWS_PER_BLOCK = 512;
+constexpr int CS_ROWS_PER_BLOCK = 1024;
 
 // grid: (ceil(N / 256), row_chunks); block 256 threads = 4 waves; lane -> 4 columns, wave -> row phase
 template <typename T>
@@ -455,8 +455,8 @@ extern "C" int dl_colsum(const void* X, int64_t ldx, int64_t M, int64_t N, int32
     hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)X, ldx, M,
                        (int)N, (float*)workspace);
   DL_CHECK_LAUNCH("dl_colsum(partial)");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, s,
-                     (const float*)workspace, chunks, (int)N, out, accumulate);
+  hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((N + 63) / 64)), dim3(256), 0, s,
+                     (const float*)workspace, chunks, (int64_t)N, (int)N, out, accumulate);
   DL_CHECK_LAUNCH("dl_colsum(final)");
   return DL_OK;
 }

@@ -4,7 +4,7 @@
 
 namespace {
 constexpr int LN_MAXV = 8;            // up to 8 x (64 lanes x 4 elems) = 2048 columns
-constexpr int LN_BWD_ROWS = 64;       // rows per workgroup in backward (16 per wave)
+constexpr int LN_BWD_ROWS = 128;      // rows per workgroup in backward (32 per wave)
 
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int64_t ldx,
@@ -198,10 +198,12 @@ extern "C" int dl_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
                        (const float*)x, ldx, mean, rstd, gamma, (const float*)dres, lddres, (float*)dx,
                        lddx, (float*)workspace, M, (int)D);
   DL_CHECK_LAUNCH("dl_layernorm_bwd");
-  if (dgamma || dbeta) {
-    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((uint32_t)((2 * D + 255) / 256)), dim3(256), 0, s,
-                       (const float*)workspace, nb, (int)D, dgamma, dbeta, accumulate);
-    DL_CHECK_LAUNCH("dl_layernorm_bwd(final)");
-  }
+  if (dgamma)
+    hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(256), 0, s,
+                       (const float*)workspace, nb, (int64_t)(2 * D), (int)D, dgamma, accumulate);
+  if (dbeta)
+    hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(256), 0, s,
+                       (const float*)workspace + D, nb, (int64_t)(2 * D), (int)D, dbeta, accumulate);
+  DL_CHECK_LAUNCH("dl_layernorm_bwd(final)");
   return DL_OK;
 }

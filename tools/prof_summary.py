@@ -18,8 +18,10 @@ tot = defaultdict(lambda: [0, 0])
 for s, e, n in rows:
     if s < cut:
         continue
-    n = re.sub(r"\(.*", "", n)
-    n = n[:110]
+    n = n.replace("(anonymous namespace)::", "").replace("_ZN12_GLOBAL__N_1", "")
+    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"\((?!anonymous).*", "", n)
+    n = n[:120]
     tot[n][0] += e - s
     tot[n][1] += 1
 busy = sum(v[0] for v in tot.values())
