@@ -3,7 +3,13 @@
 #include "common.cuh"
 
 namespace {
-constexpr int BN_ROWS_PER_BLOCK = 1024;
+static inline int bn_rows_per_block(int64_t R, int64_t C) {
+  const int64_t colgroups = (C + 255) / 256;
+  int64_t chunks = (1024 + colgroups - 1) / colgroups;
+  int64_t rows = (R + chunks - 1) / chunks;
+  if (rows < 32) rows = 32;
+  return (int)((rows + 3) / 4 * 4);
+}
 
 __device__ __forceinline__ bool row_valid(int64_t r, int64_t win, int64_t halo, int64_t valid) {
   if (win == 0) return true;
@@ -15,12 +21,12 @@ __device__ __forceinline__ bool row_valid(int64_t r, int64_t win, int64_t halo, 
 template <typename T, int MODE>
 __global__ void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const float* __restrict__ mean,
                                   const float* __restrict__ rstd, int64_t R, int C, int64_t win, int64_t halo,
-                                  int64_t valid, float* __restrict__ partial) {
+                                  int64_t valid, float* __restrict__ partial, int rows_per_block) {
   __shared__ f32x4 red[2][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 256 + lane * 4;
-  const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS_PER_BLOCK;
-  const int64_t r1 = min(R, r0 + BN_ROWS_PER_BLOCK);
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(R, r0 + rows_per_block);
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
   if (c < C) {
     f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f};
@@ -101,7 +107,8 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restric
 }  // namespace
 
 extern "C" size_t dl_bn_workspace_bytes(int64_t R, int64_t C) {
-  const int64_t chunks = (R + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK;
+  const int rpb = bn_rows_per_block(R, C);
+  const int64_t chunks = (R + rpb - 1) / rpb;
   return (size_t)chunks * 2 * (size_t)C * sizeof(float);
 }
 
@@ -111,14 +118,15 @@ static int bn_reduce(const char* who, const void* a, const void* y, const float*
                      size_t ws_bytes, hipStream_t s) {
   DL_CHECK_ARG(a && sums && R > 0 && C > 0 && C % 4 == 0, DL_ERR_ARG, "%s: bad args", who);
   DL_CHECK_ARG(ws && ws_bytes >= dl_bn_workspace_bytes(R, C), DL_ERR_WORKSPACE, "%s: workspace too small", who);
-  const int chunks = (int)((R + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
+  const int rpb = bn_rows_per_block(R, C);
+  const int chunks = (int)((R + rpb - 1) / rpb);
   dim3 grid((uint32_t)((C + 255) / 256), (uint32_t)chunks);
   if (dtype == DL_BF16)
     hipLaunchKernelGGL((bn_partial_kernel<bf16_t, MODE>), grid, dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)y,
-                       mean, rstd, R, (int)C, win, halo, valid, (float*)ws);
+                       mean, rstd, R, (int)C, win, halo, valid, (float*)ws, rpb);
   else
     hipLaunchKernelGGL((bn_partial_kernel<float, MODE>), grid, dim3(256), 0, s, (const float*)a, (const float*)y, mean,
-                       rstd, R, (int)C, win, halo, valid, (float*)ws);
+                       rstd, R, (int)C, win, halo, valid, (float*)ws, rpb);
   hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((2 * C + 63) / 64)), dim3(256), 0, s, (const float*)ws,
                      chunks, (int64_t)(2 * C), (int)(2 * C), sums, 0);
   DL_CHECK_LAUNCH(who);

@@ -92,6 +92,18 @@ __global__ void dropout_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
   store4<T>(y + row * ldy + col, v);
 }
 
+// dx = dy * gelu'(pre)
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ dx, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 d = load4<T>(dy + i * 4);
+  const f32x4 q = load4<T>(pre + i * 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d[e] *= gelu_erf_grad(q[e]);
+  store4<T>(dx + i * 4, d);
+}
+
 template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
   const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -236,6 +248,19 @@ extern "C" int dl_dropout_apply(const void* x, void* y, int64_t n_rows, int64_t 
     hipLaunchKernelGGL((dropout_apply_kernel<float>), dim3(nblk(n4)), dim3(256), 0, s, (const float*)x, (float*)y,
                        n_rows, (int)D, ldx, ldy, dl_dropout_thr16(p), 1.0f / (1.0f - p), seed);
   DL_CHECK_LAUNCH("dl_dropout_apply");
+  return DL_OK;
+}
+
+extern "C" int dl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(dy && pre && dx && n > 0 && n % 4 == 0, DL_ERR_ARG, "dl_gelu_bwd: bad args (n %% 4 == 0 required)");
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t>), dim3(nblk(n / 4)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)pre,
+                       (bf16_t*)dx, n / 4);
+  else
+    hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(nblk(n / 4)), dim3(256), 0, s, (const float*)dy, (const float*)pre,
+                       (float*)dx, n / 4);
+  DL_CHECK_LAUNCH("dl_gelu_bwd");
   return DL_OK;
 }
 

@@ -11,6 +11,7 @@
 //     (bf16) or 4 x ds_read_b32 (f32) — the hardware transpose read.
 // The MFMA is issued "swapped" (A = W fragment, B = X fragment) so each lane ends up holding 4
 // CONSECUTIVE output columns of one output row: 8-byte (bf16) / 16-byte (f32) stores.
+#include <stdlib.h>
 #include "common.cuh"
 
 namespace {
@@ -38,6 +39,7 @@ struct GemmP {
   uint32_t drop_thr16; float drop_inv_keep; uint64_t seed;
   int accumulate;
   float* slabs;   // split mode: [splits][M][N] f32
+  int dbg;
 };
 
 // ---- global -> registers (4 chunks of 16 B per thread per operand) ------------------------
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
     char* cur = smem + (kt & 1) * 2 * TB;
     char* nxt = smem + ((kt + 1) & 1) * 2 * TB;
     const bool more = (kt + 1 < nk);
-    if (more) {
+    if (more && !(p.dbg & 2)) {
       load_tile<T, XS>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, kend, rx);
       load_tile<T, WS>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, kend, rw);
     }
@@ -171,67 +173,125 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds C[m = .. + il][n = .. + 4g .. 4g+3] ---------------------------
-  const bool vec_ok = (p.N & 3) == 0;
+  // ---- epilogue -------------------------------------------------------------------------------
+  // The accumulators (lane: row il, 4 consecutive columns 4g..4g+3 per tile) are first parked in LDS
+  // as an fp32 [128][128] tile (the operand buffers are free now), then every thread takes 8
+  // CONSECUTIVE columns of one row: bias / residual / pre-activation traffic and the final store are
+  // full 16-byte (bf16) or 2x16-byte (f32) accesses, 16 lanes per 256-byte row -> whole cache lines.
+  constexpr int EP = BN * 4 + 16;                       // padded row pitch in bytes
+  static_assert(BM * EP <= 2 * 2 * TB, "epilogue tile must fit the operand buffers");
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + il;
-    if (m >= p.M) continue;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + 4 * g;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      if constexpr (SPLIT) {
-        float* dst = p.slabs + ((int64_t)split * p.M + m) * p.N + n;
-        if (vec_ok) *reinterpret_cast<f32x4*>(dst) = v;
-        else
-          for (int r = 0; r < 4 && n + r < p.N; ++r) dst[r] = v[r];
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(smem + (wm * 64 + i * 16 + il) * EP + (wn * 64 + j * 16 + 4 * g) * 4) = acc[i][j];
+  __syncthreads();
+  const bool vec_ok = (p.N & 7) == 0;
+#pragma unroll 2
+  for (int it = 0; it < 8; ++it) {
+    const int c = tid + it * NTHREADS;
+    const int row = c >> 4, cc = (c & 15) * 8;
+    const int m = m0 + row, n = n0 + cc;
+    if (m >= p.M || n >= p.N) continue;
+    if ((p.dbg & 1)) continue;
+    float v[8];
+    {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4 + 16);
+      v[0] = a0[0]; v[1] = a0[1]; v[2] = a0[2]; v[3] = a0[3]; v[4] = a1[0]; v[5] = a1[1]; v[6] = a1[2]; v[7] = a1[3];
+    }
+    const int nvalid = min(8, p.N - n);
+    const bool full = vec_ok && nvalid == 8;
+    if constexpr (SPLIT) {
+      float* dst = p.slabs + ((int64_t)split * p.M + m) * p.N + n;
+      if (full) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
       } else {
-        const int nvalid = min(4, p.N - n);
-        if (p.bias) {
-          if (nvalid == 4) { const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n); v += b; }
-          else for (int r = 0; r < nvalid; ++r) v[r] += p.bias[n + r];
-        }
-        if (p.pre_out) {
-          T* dst = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
-          if (nvalid == 4 && vec_ok) store4<T>(dst, v);
-          else for (int r = 0; r < nvalid; ++r) dst[r] = from_f32<T>(v[r]);
-        }
-        if (p.act == 1) {
+        for (int r = 0; r < nvalid; ++r) dst[r] = v[r];
+      }
+    } else {
+      if (p.bias) {
+        if (full) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-        } else if (p.act == 2) {
+          for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
+        } else {
+          for (int r = 0; r < nvalid; ++r) v[r] += p.bias[n + r];
+        }
+      }
+      if (p.pre_out) {
+        T* dst = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
+        if (full) { store4<T>(dst, f32x4{v[0], v[1], v[2], v[3]}); store4<T>(dst + 4, f32x4{v[4], v[5], v[6], v[7]}); }
+        else for (int r = 0; r < nvalid; ++r) dst[r] = from_f32<T>(v[r]);
+      }
+      if (p.act == 1) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-        }
-        if (p.dact_pre) {
-          const T* src = reinterpret_cast<const T*>(p.dact_pre) + (int64_t)m * p.lddp + n;
-          f32x4 pre = {0.f, 0.f, 0.f, 0.f};
-          if (nvalid == 4 && vec_ok) pre = load4<T>(src);
-          else for (int r = 0; r < nvalid; ++r) pre[r] = to_f32(src[r]);
+        for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]);
+      } else if (p.act == 2) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(pre[r]);
+        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.0f);
+      }
+      if (p.dact_pre) {
+        const T* src = reinterpret_cast<const T*>(p.dact_pre) + (int64_t)m * p.lddp + n;
+        float pre[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (full) {
+          const f32x4 q0 = load4<T>(src), q1 = load4<T>(src + 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pre[r] = q0[r]; pre[4 + r] = q1[r]; }
+        } else {
+          for (int r = 0; r < nvalid; ++r) pre[r] = to_f32(src[r]);
         }
-        f32x4 resv = {0.f, 0.f, 0.f, 0.f};
-        if (p.res) {
-          const int rr = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
-          const T* src = reinterpret_cast<const T*>(p.res) + (int64_t)rr * p.ldr + n;
-          if (nvalid == 4 && vec_ok) resv = load4<T>(src);
-          else for (int r = 0; r < nvalid; ++r) resv[r] = to_f32(src[r]);
-          if (p.res_before_dropout) v += resv;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad(pre[r]);
+      }
+      float resv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (p.res) {
+        const int rr = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+        const T* src = reinterpret_cast<const T*>(p.res) + (int64_t)rr * p.ldr + n;
+        if (full) {
+          const f32x4 q0 = load4<T>(src), q1 = load4<T>(src + 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { resv[r] = q0[r]; resv[4 + r] = q1[r]; }
+        } else {
+          for (int r = 0; r < nvalid; ++r) resv[r] = to_f32(src[r]);
         }
-        if (p.drop_thr16)
-          v = dl_dropout4(v, p.seed, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16,
-                          p.drop_inv_keep);
-        if (p.res && !p.res_before_dropout) v += resv;
-        TO* dst = reinterpret_cast<TO*>(p.C) + (int64_t)m * p.ldc + n;
-        if (p.accumulate) {
-          if (nvalid == 4 && vec_ok) { const f32x4 o = load4<TO>(dst); v += o; }
-          else for (int r = 0; r < nvalid; ++r) v[r] += to_f32(dst[r]);
+        if (p.res_before_dropout) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += resv[r];
         }
-        if (nvalid == 4 && vec_ok) store4<TO>(dst, v);
-        else for (int r = 0; r < nvalid; ++r) dst[r] = from_f32<TO>(v[r]);
+      }
+      if (p.drop_thr16) {
+        f32x4 d0 = {v[0], v[1], v[2], v[3]}, d1 = {v[4], v[5], v[6], v[7]};
+        d0 = dl_dropout4(d0, p.seed, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+        d1 = dl_dropout4(d1, p.seed, (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = d0[r]; v[4 + r] = d1[r]; }
+      }
+      if (p.res && !p.res_before_dropout) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += resv[r];
+      }
+      TO* dst = reinterpret_cast<TO*>(p.C) + (int64_t)m * p.ldc + n;
+      if (p.accumulate) {
+        if (full) {
+          const f32x4 o0 = load4<TO>(dst), o1 = load4<TO>(dst + 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] += o0[r]; v[4 + r] += o1[r]; }
+        } else {
+          for (int r = 0; r < nvalid; ++r) v[r] += to_f32(dst[r]);
+        }
+      }
+      if (full) {
+        if constexpr (sizeof(TO) == 2) {
+          u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+          *reinterpret_cast<u32x4*>(dst) = o;
+        } else {
+          *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+      } else {
+        for (int r = 0; r < nvalid; ++r) dst[r] = from_f32<TO>(v[r]);
       }
     }
   }
@@ -321,11 +381,19 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   if (!a->w_kslow) DL_CHECK_ARG(a->K % epc == 0, DL_ERR_ALIGN, "dl_gemm: K %% %d != 0", epc);
   else DL_CHECK_ARG(a->N % epc == 0, DL_ERR_ALIGN, "dl_gemm: N %% %d != 0 for k-slow W", epc);
   const int oes = (int)dl_dtype_size(a->out_dtype);
-  if (a->N % 4 == 0)
-    DL_CHECK_ARG(a->ldc % 4 == 0 && ((uintptr_t)a->C % (4 * oes)) == 0, DL_ERR_ALIGN,
-                 "dl_gemm: C / ldc not aligned for 4-wide stores");
+  if (a->N % 8 == 0) {
+    DL_CHECK_ARG(a->ldc % 8 == 0 && ((uintptr_t)a->C % 16) == 0, DL_ERR_ALIGN,
+                 "dl_gemm: C / ldc not aligned for 16-byte stores (N %% 8 == 0 path)");
+    DL_CHECK_ARG(!a->residual || (a->ldr % 8 == 0 && ((uintptr_t)a->residual % 16) == 0), DL_ERR_ALIGN,
+                 "dl_gemm: residual not 16-byte aligned");
+    DL_CHECK_ARG(!a->pre_out || (a->ldp % 8 == 0 && ((uintptr_t)a->pre_out % 16) == 0), DL_ERR_ALIGN,
+                 "dl_gemm: pre_out not 16-byte aligned");
+    DL_CHECK_ARG(!a->dact_pre || (a->lddp % 8 == 0 && ((uintptr_t)a->dact_pre % 16) == 0), DL_ERR_ALIGN,
+                 "dl_gemm: dact_pre not 16-byte aligned");
+    DL_CHECK_ARG(!a->bias || ((uintptr_t)a->bias % 16) == 0, DL_ERR_ALIGN, "dl_gemm: bias not 16-byte aligned");
+  }
   DL_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, DL_ERR_ARG, "dl_gemm: dropout_p out of range");
-  DL_CHECK_ARG(a->dropout_p == 0.f || a->N % 4 == 0, DL_ERR_SHAPE, "dl_gemm: dropout needs N %% 4 == 0");
+  DL_CHECK_ARG(a->dropout_p == 0.f || a->N % 8 == 0, DL_ERR_SHAPE, "dl_gemm: dropout needs N %% 8 == 0");
 
   const int sp = resolve_split(a);
   if (sp > 1) {
@@ -359,6 +427,7 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   p.seed = a->dropout_seed;
   p.accumulate = a->accumulate;
   p.slabs = (float*)a->workspace;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DL_GEMM_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
 
   dl_prof_before(0, s);
   int rc = DL_OK;
@@ -394,17 +463,24 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
 
 // ---- column sums ------------------------------------------------------------------------------
 namespace {
-constexpr int CS_ROWS_PER_BLOCK = 1024;
+// rows per workgroup are chosen per call so that the grid has >= ~1024 workgroups
+static inline int cs_rows_per_block(int64_t M, int64_t N) {
+  const int64_t colgroups = (N + 255) / 256;
+  int64_t chunks = (1024 + colgroups - 1) / colgroups;
+  int64_t rows = (M + chunks - 1) / chunks;
+  if (rows < 32) rows = 32;
+  return (int)((rows + 3) / 4 * 4);
+}
 
 // grid: (ceil(N / 256), row_chunks); block 256 threads = 4 waves; lane -> 4 columns, wave -> row phase
 template <typename T>
 __global__ void colsum_partial_kernel(const T* __restrict__ X, int64_t ldx, int64_t M, int N,
-                                      float* __restrict__ partial) {
+                                      float* __restrict__ partial, int rows_per_block) {
   __shared__ f32x4 red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 256 + lane * 4;
-  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS_PER_BLOCK;
-  const int64_t r1 = min(M, r0 + CS_ROWS_PER_BLOCK);
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(M, r0 + rows_per_block);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (n < N) {
     if (n + 4 <= N && (N & 3) == 0) {
@@ -433,7 +509,8 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int chunk
 }  // namespace
 
 extern "C" size_t dl_colsum_workspace_bytes(int64_t M, int64_t N) {
-  const int64_t chunks = (M + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK;
+  const int rpb = cs_rows_per_block(M, N);
+  const int64_t chunks = (M + rpb - 1) / rpb;
   return (size_t)chunks * (size_t)N * sizeof(float);
 }
 
@@ -446,14 +523,15 @@ extern "C" int dl_colsum(const void* X, int64_t ldx, int64_t M, int64_t N, int32
   if ((N & 3) == 0)
     DL_CHECK_ARG(ldx % 4 == 0 && ((uintptr_t)X % (4 * dl_dtype_size(dtype))) == 0, DL_ERR_ALIGN,
                  "dl_colsum: X not aligned for 4-wide loads");
-  const int chunks = (int)((M + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK);
+  const int rpb = cs_rows_per_block(M, N);
+  const int chunks = (int)((M + rpb - 1) / rpb);
   dim3 grid((uint32_t)((N + 255) / 256), (uint32_t)chunks);
   if (dtype == DL_BF16)
     hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)X, ldx, M,
-                       (int)N, (float*)workspace);
+                       (int)N, (float*)workspace, rpb);
   else
     hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)X, ldx, M,
-                       (int)N, (float*)workspace);
+                       (int)N, (float*)workspace, rpb);
   DL_CHECK_LAUNCH("dl_colsum(partial)");
   hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((N + 63) / 64)), dim3(256), 0, s,
                      (const float*)workspace, chunks, (int64_t)N, (int)N, out, accumulate);

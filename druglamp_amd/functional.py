@@ -631,3 +631,103 @@ class ProteinCNNFn(torch.autograd.Function):
             dx = torch.zeros((B, LP, C), dtype=cdt, device=dout.device)
             dx[:, _CNN_HALO:_CNN_HALO + Lv] = dz.reshape(B, LP, C)[:, _CNN_HALO:_CNN_HALO + Lv]
         return (dx, None, None) + tuple(grads)
+
+
+
+# ------------------------------------------------------------------------------------------------
+# general dense layer for the adaptors: y = act(x W^T + b) (+ residual), with zero-padding of odd
+# feature widths (641 -> 648, 385 -> 392) to the 16-byte granularity of the MFMA operand loaders
+# ------------------------------------------------------------------------------------------------
+def _padded_weight(w: torch.Tensor, Np: int, Kp: int, dtype: torch.dtype) -> torch.Tensor:
+    key = ((id(w), "pad", Np, Kp), dtype)
+    ver = (_param_epoch, w._version)
+    hit = _lowp_cache.get(key)
+    if hit is not None and hit[0] == ver and hit[2][0]() is w:
+        return hit[1]
+    with torch.no_grad():
+        N, K = w.shape
+        g = torch.zeros((Np, Kp), dtype=w.dtype, device=w.device)
+        g[:N, :K] = w.detach()
+        if g.dtype != dtype:
+            g = ops.cast(g, dtype)
+    _lowp_cache[key] = (ver, g, (weakref.ref(w),))
+    return g
+
+
+class DenseFn(torch.autograd.Function):
+    """x: [..., Kp] (Kp >= weight.shape[1], extra columns MUST be zero).  Output [..., Np] with
+    Np = ceil8(weight.shape[0]); padded output columns are exactly zero."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, act):
+        cdt = x.dtype
+        N, K = weight.shape
+        Kp = x.shape[-1]
+        Np = (N + 7) // 8 * 8
+        x2 = x.reshape(-1, Kp).contiguous()
+        M = x2.shape[0]
+        w = _padded_weight(weight, Np, Kp, cdt)
+        b = None
+        if bias is not None:
+            b = torch.zeros(Np, dtype=torch.float32, device=x.device)
+            b[:N] = bias.detach()
+        r2 = None if residual is None else residual.reshape(M, Np).contiguous()
+        pre = torch.empty((M, Np), dtype=cdt, device=x.device) if act else None
+        y = ops.gemm(x2, w, M=M, N=Np, K=Kp, bias=b, act=1 if act else 0, pre_out=pre, residual=r2)
+        ctx.save_for_backward(x2, w, pre)
+        ctx.cfg = (x.shape, M, N, K, Np, Kp, bias is not None, residual is not None, act)
+        return y.reshape(*x.shape[:-1], Np)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, pre = ctx.saved_tensors
+        xshape, M, N, K, Np, Kp, has_bias, has_res, act = ctx.cfg
+        g = dy.reshape(M, Np).contiguous()
+        dres = dy if (has_res and ctx.needs_input_grad[3]) else None
+        if act:
+            g = ops.gelu_bwd(g, pre)
+        dx = ops.gemm(g, w, M=M, N=Kp, K=Np, w_kslow=True, ldw=Kp).reshape(xshape) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm(g, x2, M=Np, N=Kp, K=M, x_kslow=True, w_kslow=True, ldx=Np, ldw=Kp, out_dtype=torch.float32,
+                          split_k=0)[:N, :K]
+        db = ops.colsum(g)[:N] if (has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, dres, None
+
+
+def dense(x, weight, bias=None, residual=None, act=False):
+    return DenseFn.apply(x, weight, bias, residual, act)
+
+
+class EmbeddingFn(torch.autograd.Function):
+    """Row gather forward; the weight gradient (sum of the incoming rows per vocabulary id) is a one-hot
+    GEMM on the MFMA path instead of a serialized scatter-add (ProteinCNN embedding, 27 ids)."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, padding_idx):
+        ctx.save_for_backward(ids)
+        ctx.wshape = tuple(weight.shape)
+        ctx.padding_idx = padding_idx
+        return weight.detach()[ids]
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        V, D = ctx.wshape
+        Vp, Dp = (V + 7) // 8 * 8, (D + 7) // 8 * 8
+        flat = ids.reshape(-1)
+        M = flat.numel()
+        cdt = dy.dtype if dy.dtype in (torch.bfloat16, torch.float32) else torch.float32
+        onehot = torch.zeros((M, Vp), dtype=cdt, device=dy.device)
+        onehot.scatter_(1, flat.unsqueeze(1), 1.0)
+        g = dy.reshape(M, D)
+        if Dp != D or g.dtype != cdt or not g.is_contiguous():
+            gp = torch.zeros((M, Dp), dtype=cdt, device=dy.device)
+            gp[:, :D] = g
+            g = gp
+        dw = ops.gemm(onehot, g, M=Vp, N=Dp, K=M, x_kslow=True, w_kslow=True, ldx=Vp, ldw=Dp, out_dtype=torch.float32,
+                      split_k=0)
+        dw = dw[:V, :D]
+        if ctx.padding_idx is not None:
+            dw[ctx.padding_idx].zero_()          # nn.Embedding(padding_idx=...) never updates that row
+        return None, dw, None

@@ -17,13 +17,9 @@ class DrugLAMP(DrugLAMPBase):
         xp = torch.cat((xp, fill_p.unsqueeze(-1)), dim=-1)
         xd = torch.cat((xd, self._fill_bit(xd).unsqueeze(-1)), dim=-1)
         ssl = {"vp": vp, "xp": xp, "fill_bit_p": fill_p, "vd": vd, "xd": xd}
-        with self._glue():
-            vpf = self._site_pool(self.protein_extractor(vp, fill_p))
-            xps = self._site_pool(xp)
-            t = self.p_adaptor_wo_skip_connect(xps) + xps
-            xpf = self.lin_p2(self.p_norm(self.act_p(self.lin_p1(t))))
-            xdf = self.lin_d2(self.d_norm(self.act_d(self.lin_d1(xd))))
-        vpf, xpf, xdf, vdf = vpf.float(), xpf.float(), xdf.float(), vd.float()
+        vpf = self._site_pool(self.protein_extractor(vp, fill_p))
+        xpf, xdf = self._llm_adaptors(xp, xd)
+        vpf, vdf = vpf.float(), vd.float()
         cp = {"prot": vpf, "aug_prot": xpf, "drug": vdf, "aug_drug": xdf} if self.two_c2p else None
         mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpf, vdf)
         mx, self.A_x_gca = self._gca_branch(self.x_gca, self.x_mhla, self.x_gca_norm, xpf, xdf)

@@ -131,11 +131,14 @@ class ProteinCNN(nn.Module):
         """Embedding lookup + fill bit are torch glue; the three Conv1d + ReLU + BatchNorm1d stages run as
         channel-last implicit GEMMs + BatchNorm kernels (functional.ProteinCNNFn).  The reference's final
         `.view(B, L, C)` of the channel-first (B, C, L) buffer is reproduced exactly."""
-        from ..functional import _CNN_HALO, ProteinCNNFn, cast
-        x = self.embedding(v.long())
+        from ..functional import _CNN_HALO, EmbeddingFn, ProteinCNNFn, cast
+        ids = v.long()
+        w = self.embedding.weight
+        x = EmbeddingFn.apply(ids, cast(w, self.compute_dtype) if w.requires_grad else w.detach().to(self.compute_dtype),
+                              self.embedding.padding_idx)
         x = torch.cat((x, fill_mask.unsqueeze(-1).to(x.dtype)), dim=-1)            # (B, L, C) channel-last
         B, L, C = x.shape
-        x = F.pad(cast(x.float(), self.compute_dtype), (0, 0, _CNN_HALO, _CNN_HALO))
+        x = F.pad(x, (0, 0, _CNN_HALO, _CNN_HALO))
         params = []
         for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)):
             params += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
@@ -261,6 +264,25 @@ class DrugLAMPBase(nn.Module):
         m = mhla(m, add_residual=True)                                  # mhla(h) + h in one launch set
         m = Fn.layer_norm(m.float(), norm.weight, norm.bias, norm.eps)
         return m, raw
+
+    def _llm_adaptors(self, xp_cat, xd_cat):
+        """Protein / drug LLM adaptors (DrugLAMP.py:39-52) on the HIP GEMM path: 641- and 385-wide features
+        are zero-padded to 648 / 392 so that every product is an aligned MFMA GEMM."""
+        cdt = self.compute_dtype
+        xps = self._site_pool(xp_cat)                                             # (B, 256, 641)
+        xps = Fn.cast(F.pad(xps.float(), (0, (-xps.shape[-1]) % 8)), cdt)
+        a = self.p_adaptor_wo_skip_connect
+        h = Fn.dense(xps, a.lin1.weight, a.lin1.bias, act=True)
+        h = Fn.layer_norm(h, a.norm.weight, a.norm.bias, a.norm.eps)
+        t = Fn.dense(h, a.lin2.weight, a.lin2.bias, residual=xps)                   # lin2(...) + xps, 648 wide
+        h = Fn.dense(t, self.lin_p1.weight, self.lin_p1.bias, act=True)
+        h = Fn.layer_norm(h, self.p_norm.weight, self.p_norm.bias, self.p_norm.eps)
+        xpf = Fn.dense(h, self.lin_p2.weight, self.lin_p2.bias)
+        xd = Fn.cast(F.pad(xd_cat.float(), (0, (-xd_cat.shape[-1]) % 8)), cdt)
+        h = Fn.dense(xd, self.lin_d1.weight, self.lin_d1.bias, act=True)
+        h = Fn.layer_norm(h, self.d_norm.weight, self.d_norm.bias, self.d_norm.eps)
+        xdf = Fn.dense(h, self.lin_d2.weight, self.lin_d2.bias)
+        return xpf.float(), xdf.float()
 
     def get_cross_attn_mat(self, modality="v"):
         if modality == "v":

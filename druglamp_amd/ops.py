@@ -357,3 +357,10 @@ def bn_bwd_apply(dz2d, y2d, mean, rstd, gamma, sums, inv_n, relu_mask, win, halo
                                      sums.data_ptr(), float(inv_n), int(relu_mask), dy.data_ptr(), R, Cc, win, halo, valid,
                                      _dt(y2d), _stream()), "dl_bn_bwd_apply")
     return dy
+
+
+def gelu_bwd(dy2d, pre2d):
+    dx = torch.empty_like(dy2d)
+    check(_lib.lib().dl_gelu_bwd(dy2d.data_ptr(), pre2d.data_ptr(), dx.data_ptr(), dy2d.numel(), _dt(dy2d), _stream()),
+          "dl_gelu_bwd")
+    return dx

@@ -202,6 +202,9 @@ int dl_add_rowmod_dropout(const void* x, const void* pe, void* y, int64_t M, int
 /* y = dropout_mask(seed)(x) / (1-p) — regenerates a forward mask for the backward pass. */
 int dl_dropout_apply(const void* x, void* y, int64_t n_rows, int64_t D, int64_t ldx, int64_t ldy,
                      float p, uint64_t seed, int32_t dtype, dl_stream s);
+/* dx = dy * gelu'(pre) (exact-erf GELU): backward of the GELU that sits between a Linear and a LayerNorm in
+ * the LLM adaptors (model/basic_model.py:189-193, DrugLAMP.py:46-52). */
+int dl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dtype, dl_stream s);
 /* dst(bf16|f32) = src(f32|bf16) elementwise cast (weight casts, master fp32 -> compute dtype). */
 int dl_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n,
             dl_stream s);
