@@ -1,0 +1,51 @@
+"""world_size-2 gloo test of the data-parallel gradient path (trainer.FlatParams + per-run all-reduce)
+on CPU tensors: after the reduction every rank holds the SUM of both ranks' gradients for exactly the
+parameters that had one, laid out in the flat buffer the fused AdamW kernel consumes."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from druglamp_amd.trainer import FlatParams, Trainer
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(s)) for s in [(8, 4), (5,), (3, 3), (16,)]]
+    t = Trainer.__new__(Trainer)
+    t.flat = FlatParams(ps)
+    t.world, t.rank = world, rank
+    for i in (0, 1, 3):                                   # parameter 2 has no gradient on any rank
+        ps[i].grad = torch.full_like(ps[i], float(rank + 1) * (i + 1))
+    idx = t._reduce_and_pack()
+    ok = idx == [0, 1, 3]
+    for i in idx:
+        ok &= bool(torch.allclose(t.flat.grad_views[i], torch.full_like(ps[i], 3.0 * (i + 1))))
+    ok &= float(t.flat.grad_views[2].abs().sum()) == 0.0
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -1,0 +1,132 @@
+"""CPU-only checks of the host side: C-ABI export surface, state_dict ABI vs the reference's key
+list, config surface, schedules, label matrices, parameter-run logic."""
+import json
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load, sd_spec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from druglamp_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "druglamp_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dl_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 34
+    L = _lib.lib()                                   # dlopen + argtypes; no compute without a GPU
+    for name in sorted(declared):
+        assert hasattr(L, name), "libdruglamp_hip.so does not export %s" % name
+        assert name in _lib.SIGNATURES, "%s has no ctypes signature" % name
+    assert L.dl_version() >= 100
+    # argument validation happens before any launch and reports through dl_last_error
+    assert L.dl_gemm(None, None) != 0
+    assert b"null" in L.dl_last_error()
+
+
+@pytest.mark.parametrize("kind", ["DrugLAMP", "DrugLAMP2C2P", "DrugLAMPwoLLM"])
+def test_state_dict_abi_matches_reference(kind):
+    from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
+    from druglamp_amd.model import MInterface
+    cfg = load_yaml_into(get_cfg_defaults(), kind)
+    m = MInterface(kind, cfg).load_model(n_drug_feature=384, n_prot_feature=640, unused_dataset_attr=1)
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.startswith("drug_extractor.")}
+    ref = {k: s for k, s, _ in sd_spec(load("model_" + kind))}
+    assert set(mine) == set(ref)
+    assert all(mine[k] == ref[k] for k in ref)
+    assert sum(p.numel() for p in m.parameters()) == 14026568
+    # the shared ProteinCNN (basic_model.py:79-86)
+    assert m.ssl_model.extractor is m.protein_extractor
+    with pytest.raises(ValueError):
+        MInterface("NoSuchModel", cfg).load_model()
+
+
+def test_pmma_state_dict_abi():
+    from druglamp_amd.configs import get_model_defaults
+    from druglamp_amd.model.PMMA import PairedMultimodelAttention
+    g = load("pmma_full")
+    m = PairedMultimodelAttention(get_model_defaults(128), vis=False)
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    ref = {k: s for k, s, _ in sd_spec(g)}
+    assert mine == ref
+    assert sum(p.numel() for p in m.parameters()) == 10252800
+
+
+def test_config_surface():
+    from druglamp_amd.configs import get_cfg_defaults, get_model_defaults, load_yaml_into
+    c = load_yaml_into(get_cfg_defaults(), "DrugLAMP2C2P")
+    assert c.SOLVER.BATCH_SIZE == 16 and c.SOLVER.LR == 1e-4 and c.SOLVER.SSL_LR == 3e-5 and c.SOLVER.CM_LR == 3e-5
+    assert c.RS.SSL is True and c.RS.CM is True and c.RS.INIT_EPOCH == 5 and c.RS.EPOCH_STEP == 5
+    assert c.RS.MAX_MARGIN == 0.5 and c.RS.RESET_EPOCH == 100 and c.DECODER.BINARY == 1
+    assert c.PROTEIN.SEQ_LEN == 2304 and c.PROTEIN.SITE_LEN == 9 and c.DRUG.NODE_IN_FEATS == 75
+    assert load_yaml_into(get_cfg_defaults(), "DrugLAMP").RS.CM is False
+    m = get_model_defaults(128)
+    assert m.hidden_size == 256 and m.mol_len == m.feat_len == 256
+    assert m.transformer.num_heads == 4 and m.transformer.dropout_rate == 0.1 and m.mlha_dropout == 0
+    with pytest.raises(KeyError):
+        get_cfg_defaults().merge_from_dict({"NOPE": 1})
+
+
+def test_margin_schedule_and_label_matrix():
+    from druglamp_amd.model.cross_modality import MarginSchedule, label_matrix
+    g = load("losses")
+    sch = MarginSchedule(m_ori=0.5, n_re=100)
+    got = [sch.margin]
+    for _ in range(205):
+        sch.step()
+        got.append(sch.margin)
+    assert np.allclose(got, g["margins"], rtol=0, atol=1e-12)
+    meta = [{"Prot_ID": "a", "Drug_ID": 1, "Y": 1.0}, {"Prot_ID": "b", "Drug_ID": 1, "Y": 0.0},
+            {"Prot_ID": "a", "Drug_ID": 2, "Y": 0.0}, {"Prot_ID": "a", "Drug_ID": 1, "Y": 0.0}]
+    pidx, didx, gt = label_matrix(meta)
+    assert pidx == [3, 1] and didx == [3, 2]            # LAST occurrence per id, first-seen order
+    assert gt.tolist() == [[0, 0], [0, 0]]              # later duplicate overwrites; unobserved (b,2) = 0
+    assert label_matrix(meta, use_cm=False)[2].tolist() == [[0, 0], [0, -1]]
+
+
+def test_lr_schedule():
+    from druglamp_amd.trainer import CosineAnnealingWarmupRestarts
+    s = CosineAnnealingWarmupRestarts(100, 1e-4, 1e-8, 20)
+    assert s.lr == 1e-8                                  # first epoch runs at min_lr
+    lrs = [s.step() for _ in range(100)]
+    assert abs(lrs[0] - (1e-8 + (1e-4 - 1e-8) / 20)) < 1e-15
+    assert abs(lrs[19] - 1e-4) < 1e-12                   # step 20 = end of warm-up = max_lr
+    assert abs(lrs[59] - (1e-8 + (1e-4 - 1e-8) * (1 + math.cos(math.pi * 40 / 80)) / 2)) < 1e-15
+    assert abs(lrs[99] - 1e-8) < 1e-15                   # cycle restart
+
+
+def test_mlm_mask_counts():
+    from druglamp_amd.model.self_supervised_learning import get_mask_subset_with_prob, mask_with_tokens
+    torch.manual_seed(0)
+    seq = torch.randint(1, 26, (4, 200)).double()
+    seq[0, 150:] = 0
+    seq[3, 10:] = 0
+    valid = ~mask_with_tokens(seq, (0,))
+    m = get_mask_subset_with_prob(valid, 0.15)
+    assert (m & ~valid).sum() == 0
+    for b in range(4):
+        assert int(m[b].sum()) == math.ceil(0.15 * int(valid[b].sum()))
+
+
+def test_flat_params_runs_cpu():
+    from druglamp_amd.trainer import FlatParams
+    ps = [torch.nn.Parameter(torch.randn(s)) for s in [(3, 5), (7,), (4, 4), (2,), (6, 2)]]
+    vals = [p.detach().clone() for p in ps]
+    flat = FlatParams(ps)
+    assert all(torch.equal(p.detach(), v) for p, v in zip(ps, vals))
+    assert all(p.data_ptr() % 16 == 0 for p in ps)
+    for i in (0, 1, 3):
+        ps[i].grad = torch.full_like(ps[i], float(i + 1))
+    idx = flat.pack_grads()
+    assert idx == [0, 1, 3]
+    runs = flat.runs(idx, lambda i: 0)
+    assert [(s, e) for s, e, _ in runs] == [(0, 16 + 8), (flat.offsets[3], flat.offsets[3] + 4)]
+    assert float(flat.grads[:15].sum()) == 15.0 and float(flat.grads[16:23].sum()) == 14.0
+    ps[0].data.add_(1.0)                                  # views write through to the arena
+    assert torch.equal(flat.arena[:15].view(3, 5), ps[0].detach())
