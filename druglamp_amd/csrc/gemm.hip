@@ -86,6 +86,28 @@ __device__ __forceinline__ void store_tile(char* lds, const u32x4 (&r)[4]) {
   }
 }
 
+// K-contiguous operand tile straight into LDS (LDS-DMA, global_load_lds_dwordx4): no VGPR round trip and
+// no ds_write.  The LDS destination of one wave-instruction is linear (wave-uniform base + lane*16), so
+// the XOR swizzle is applied on the SOURCE side: LDS slot (row, physical chunk pc) receives the row's
+// logical chunk pc ^ (row & 7).  Rows beyond the operand are clamped to its last row (their products
+// only reach output rows/columns that are never stored); the K range must be whole steps.
+template <typename T>
+__device__ __forceinline__ void dma_tile(const char* base, int64_t ld, int row0, int nrows, int k0, char* lds) {
+  constexpr int EPC = Mma<T>::EPC;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * NTHREADS;
+    const int row = c >> 3, kc = (c & 7) ^ (row & 7);
+    int gr = row0 + row;
+    gr = gr < nrows ? gr : nrows - 1;
+    const char* src = base + ((int64_t)gr * ld + k0 + kc * EPC) * (int64_t)sizeof(T);
+    const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((c - (tid & 63)) * 16));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
+  }
+}
+
 // fragment for 16 tile rows starting at rb, fragment index kf within the step
 template <typename T, bool KSLOW>
 __device__ __forceinline__ u32x4 read_frag(const char* lds, int rb, int kf, int il, int g) {
@@ -112,47 +134,66 @@ __device__ __forceinline__ u32x4 read_frag(const char* lds, int rb, int kf, int 
   }
 }
 
-template <typename T, typename TO, bool XS, bool WS, bool SPLIT>
+template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
+  constexpr bool XD = DMA && !XS, WD = DMA && !WS;   // operands staged by LDS-DMA
   constexpr int BKE = TileGeom<T>::BKE;
   constexpr int NFRAG = BKE / Mma<T>::KF;
   constexpr int TB = TileGeom<T>::TILE_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TB];
 
-  const uint32_t nblocks = (uint32_t)p.mt * p.nt * p.splits;
-  const uint32_t t = xcd_remap(blockIdx.x, nblocks);
-  const int split = t / (p.mt * p.nt);
-  const int tile = t % (p.mt * p.nt);
-  const int m0 = (tile / p.nt) * BM, n0 = (tile % p.nt) * BN;
-  const int kbeg = split * p.k_per_split;
-  const int kend = min(p.K, kbeg + p.k_per_split);
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int il = lane & 15, g = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
+  constexpr int EP = BN * 4 + 16;                       // padded row pitch of the epilogue tile (bytes)
+  static_assert(BM * EP <= 2 * 2 * TB, "epilogue tile must fit the operand buffers");
 
+  // Persistent tile loop: the grid holds at most two workgroups per CU; each walks the logical tile
+  // list with stride gridDim.x.  Within one round the XCD-aware remap keeps neighbouring logical tiles
+  // (same X row panel) on one XCD / L2.  The first operand tiles of the NEXT output tile are requested
+  // before the epilogue of the current one, so their HBM latency and the epilogue's stores overlap.
+  const uint32_t ntiles = (uint32_t)p.mt * p.nt * p.splits;
+  const uint32_t G = gridDim.x;
+  auto locate = [&](uint32_t it, int& split, int& m0, int& n0, int& kbeg, int& kend) {
+    const uint32_t round0 = (it / G) * G;
+    const uint32_t span = min(G, ntiles - round0);
+    const uint32_t t = round0 + xcd_remap(it - round0, span);
+    split = t / (p.mt * p.nt);
+    const int tile = t % (p.mt * p.nt);
+    m0 = (tile / p.nt) * BM; n0 = (tile % p.nt) * BN;
+    kbeg = split * p.k_per_split;
+    kend = min(p.K, kbeg + p.k_per_split);
+  };
+  u32x4 rx[4], rw[4];
+  uint32_t it = blockIdx.x;
+  if (it >= ntiles) return;
+  if ((p.dbg & 4) && (blockIdx.x & 8)) { for (int z = 0; z < (p.dbg >> 4); ++z) __builtin_amdgcn_s_sleep(127); }
+  int split, m0, n0, kbeg, kend;
+  locate(it, split, m0, n0, kbeg, kend);
+  if constexpr (!XD) load_tile<T, XS>(p.X, p.ldx, m0, p.M, kbeg, kend, rx);
+  if constexpr (!WD) load_tile<T, WS>(p.W, p.ldw, n0, p.N, kbeg, kend, rw);
+  for (;;) {
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 rx[4], rw[4];
   const int nk = (kend - kbeg + BKE - 1) / BKE;
-  if (nk > 0) {
-    load_tile<T, XS>(p.X, p.ldx, m0, p.M, kbeg, kend, rx);
-    load_tile<T, WS>(p.W, p.ldw, n0, p.N, kbeg, kend, rw);
-    store_tile<T, XS>(smem, rx);
-    store_tile<T, WS>(smem + TB, rw);
-  }
+  if constexpr (XD) dma_tile<T>(p.X, p.ldx, m0, p.M, kbeg, smem);
+  else store_tile<T, XS>(smem, rx);
+  if constexpr (WD) dma_tile<T>(p.W, p.ldw, n0, p.N, kbeg, smem + TB);
+  else store_tile<T, WS>(smem + TB, rw);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     char* cur = smem + (kt & 1) * 2 * TB;
     char* nxt = smem + ((kt + 1) & 1) * 2 * TB;
     const bool more = (kt + 1 < nk);
     if (more && !(p.dbg & 2)) {
-      load_tile<T, XS>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, kend, rx);
-      load_tile<T, WS>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, kend, rw);
+      if constexpr (XD) dma_tile<T>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, nxt);
+      else load_tile<T, XS>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, kend, rx);
+      if constexpr (WD) dma_tile<T>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, nxt + TB);
+      else load_tile<T, WS>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, kend, rw);
     }
 #pragma unroll
     for (int kf = 0; kf < NFRAG; ++kf) {
@@ -167,10 +208,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(fw[j], fx[i], acc[i][j]);
     }
     if (more) {
-      store_tile<T, XS>(nxt, rx);
-      store_tile<T, WS>(nxt + TB, rw);
+      if constexpr (!XD) store_tile<T, XS>(nxt, rx);
+      if constexpr (!WD) store_tile<T, WS>(nxt + TB, rw);
     }
     __syncthreads();
+  }
+  // request the next output tile's first operand tiles now (registers only)
+  const int cm0 = m0, cn0 = n0, csplit = split;
+  const uint32_t itn = it + G;
+  const bool have_next = itn < ntiles;
+  if (have_next) {
+    locate(itn, split, m0, n0, kbeg, kend);
+    if constexpr (!XD) load_tile<T, XS>(p.X, p.ldx, m0, p.M, kbeg, kend, rx);
+    if constexpr (!WD) load_tile<T, WS>(p.W, p.ldw, n0, p.N, kbeg, kend, rw);
   }
 
   // ---- epilogue -------------------------------------------------------------------------------
@@ -178,8 +228,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   // as an fp32 [128][128] tile (the operand buffers are free now), then every thread takes 8
   // CONSECUTIVE columns of one row: bias / residual / pre-activation traffic and the final store are
   // full 16-byte (bf16) or 2x16-byte (f32) accesses, 16 lanes per 256-byte row -> whole cache lines.
-  constexpr int EP = BN * 4 + 16;                       // padded row pitch in bytes
-  static_assert(BM * EP <= 2 * 2 * TB, "epilogue tile must fit the operand buffers");
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -191,7 +239,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   for (int it = 0; it < 8; ++it) {
     const int c = tid + it * NTHREADS;
     const int row = c >> 4, cc = (c & 15) * 8;
-    const int m = m0 + row, n = n0 + cc;
+    const int m = cm0 + row, n = cn0 + cc;
     if (m >= p.M || n >= p.N) continue;
     if ((p.dbg & 1)) continue;
     float v[8];
@@ -203,7 +251,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
     const int nvalid = min(8, p.N - n);
     const bool full = vec_ok && nvalid == 8;
     if constexpr (SPLIT) {
-      float* dst = p.slabs + ((int64_t)split * p.M + m) * p.N + n;
+      float* dst = p.slabs + ((int64_t)csplit * p.M + m) * p.N + n;
       if (full) {
         *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -295,6 +343,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
       }
     }
   }
+  if (!have_next) break;
+  it = itn;
+  __syncthreads();          // the epilogue tile aliases the operand buffers
+  }
 }
 
 // out[idx] (+)= sum_z slabs[z][idx]
@@ -333,17 +385,21 @@ int resolve_split(const dl_gemm_args* a) {
   return plain ? auto_split(a->M, a->N, a->K, bke) : 1;
 }
 
-template <typename T, typename TO, bool XS, bool WS, bool SPLIT>
+template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA>
 void launch(const GemmP& p, hipStream_t s) {
-  const uint32_t nblocks = (uint32_t)p.mt * p.nt * p.splits;
-  hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT>), dim3(nblocks), dim3(NTHREADS), 0, s, p);
+  const uint32_t ntiles = (uint32_t)p.mt * p.nt * p.splits;
+  const uint32_t nblocks = ntiles < 512u ? ntiles : 512u;      // 256 CUs x 2 resident workgroups (LDS-limited)
+  hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT, DMA>), dim3(nblocks), dim3(NTHREADS), 0, s, p);
 }
 
 template <typename T, typename TO, bool SPLIT>
 int dispatch_layout(const dl_gemm_args* a, const GemmP& p, hipStream_t s) {
-  if (!a->x_kslow && !a->w_kslow) launch<T, TO, false, false, SPLIT>(p, s);
-  else if (!a->x_kslow && a->w_kslow) launch<T, TO, false, true, SPLIT>(p, s);
-  else if (a->x_kslow && a->w_kslow) launch<T, TO, true, true, SPLIT>(p, s);
+  // LDS-DMA staging needs whole K steps per split and at least one K-contiguous operand
+  const int bke = BKB / (int)sizeof(T);
+  const bool dma = (a->K % bke == 0) && (p.k_per_split % bke == 0) && !(p.dbg & 8);
+  if (!a->x_kslow && !a->w_kslow) { if (dma) launch<T, TO, false, false, SPLIT, true>(p, s); else launch<T, TO, false, false, SPLIT, false>(p, s); }
+  else if (!a->x_kslow && a->w_kslow) { if (dma) launch<T, TO, false, true, SPLIT, true>(p, s); else launch<T, TO, false, true, SPLIT, false>(p, s); }
+  else if (a->x_kslow && a->w_kslow) launch<T, TO, true, true, SPLIT, false>(p, s);
   else {
     dl_set_error("dl_gemm: layout x_kslow=1,w_kslow=0 is not instantiated");
     return DL_ERR_UNSUPPORTED;

@@ -36,18 +36,22 @@ def bump_param_epoch() -> None:
     _lowp_cache.clear()
 
 
-def lowp(params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+def lowp(params: Sequence[torch.Tensor], dtype: torch.dtype, transpose: bool = False) -> torch.Tensor:
     """Compute-dtype tensor holding cat(params, dim=0) (a single param is returned as is in fp32).
+    transpose=True gives the [in][out] copy used by the data-gradient products, so that those are
+    K-contiguous GEMMs too (both operands then stream into LDS by DMA).
 
     Cached per (parameter objects, their versions, optimiser epoch).  Entries hold WEAK references and
     are validated by identity: a Python id can be reused by a new tensor once the old model is gone."""
-    key = (tuple(id(p) for p in params), dtype)
+    key = (tuple(id(p) for p in params) + (("T",) if transpose else ()), dtype)
     ver = (_param_epoch,) + tuple(p._version for p in params)
     hit = _lowp_cache.get(key)
     if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
         return hit[1]
     with torch.no_grad():
         w = params[0].detach() if len(params) == 1 else torch.cat([p.detach() for p in params], dim=0)
+        if transpose:
+            w = w.t().contiguous()
         if w.dtype != dtype:
             w = ops.cast(w, dtype)
         elif not w.is_contiguous():
@@ -79,16 +83,20 @@ class _Stream:
         self.ln1w, self.ln1b = next(it), next(it)
         qw, qb, kw, kb, vw, vb = (next(it) for _ in range(6))
         self.qkv_w = lowp((qw, kw, vw), cdt)
+        self.qkv_wT = lowp((qw, kw, vw), cdt, True)
         self.qkv_b = lowp((qb, kb, vb), torch.float32)
         if paired:
             fw, fb = next(it), next(it)
             self.fc_w, self.fc_b = lowp((fw,), cdt), _f32(fb)
+            self.fc_wT = lowp((fw,), cdt, True)
         ow, ob = next(it), next(it)
         self.out_w, self.out_b = lowp((ow,), cdt), _f32(ob)
+        self.out_wT = lowp((ow,), cdt, True)
         self.ln2w, self.ln2b = next(it), next(it)
         w1, b1, w2, b2 = (next(it) for _ in range(4))
         self.w1, self.b1 = lowp((w1,), cdt), _f32(b1)
         self.w2, self.b2 = lowp((w2,), cdt), _f32(b2)
+        self.w1T, self.w2T = lowp((w1,), cdt, True), lowp((w2,), cdt, True)
 
 
 class TransformerBlockFn(torch.autograd.Function):
@@ -139,7 +147,7 @@ class TransformerBlockFn(torch.autograd.Function):
                      out=out[s].reshape(M, d))
             seeds.append((s1, s2))
             saved += [xn[s], stats1[s][0], stats1[s][1], f if paired else a[s], x1, hn, mean2, rstd2, pre, act,
-                      st.qkv_w, st.out_w, st.w1, st.w2, st.fc_w if paired else st.out_w,
+                      st.qkv_wT, st.out_wT, st.w1T, st.w2T, st.fc_wT if paired else st.out_wT,
                       st.ln1w.detach(), st.ln2w.detach()]
         ctx.save_for_backward(*saved)
         ctx.cfg = (paired, H, p_eff, S, B, L, d, seeds)
@@ -168,24 +176,24 @@ class TransformerBlockFn(torch.autograd.Function):
             dw2 = ops.gemm(g2, act, M=d, N=4 * d, K=M, x_kslow=True, w_kslow=True, ldx=d, ldw=4 * d,
                            out_dtype=torch.float32, split_k=0)
             db2 = ops.colsum(g2)
-            g1 = ops.gemm(g2, w2, M=M, N=4 * d, K=d, w_kslow=True, ldw=4 * d, dact_pre=pre, dropout_p=p_eff, seed=s1)
+            g1 = ops.gemm(g2, w2, M=M, N=4 * d, K=d, dact_pre=pre, dropout_p=p_eff, seed=s1)
             dw1 = ops.gemm(g1, hn, M=4 * d, N=d, K=M, x_kslow=True, w_kslow=True, ldx=4 * d, ldw=d,
                            out_dtype=torch.float32, split_k=0)
             db1 = ops.colsum(g1)
-            dhn = ops.gemm(g1, w1, M=M, N=d, K=4 * d, w_kslow=True, ldw=d)
+            dhn = ops.gemm(g1, w1, M=M, N=d, K=4 * d)
             dx1, dg2, dbt2 = ops.layernorm_bwd(dhn, x1, mean2, rstd2, ln2w, dres=dy)
             dwo = ops.gemm(dx1, f, M=d, N=d, K=M, x_kslow=True, w_kslow=True, ldx=d, ldw=d, out_dtype=torch.float32,
                            split_k=0)
             dbo = ops.colsum(dx1)
             if paired:
-                df = ops.gemm(dx1, out_w, M=M, N=d, K=d, w_kslow=True, ldw=d)
+                df = ops.gemm(dx1, out_w, M=M, N=d, K=d)
                 dwf = ops.gemm(df, a[s], M=d, N=2 * d, K=M, x_kslow=True, w_kslow=True, ldx=d, ldw=2 * d,
                                out_dtype=torch.float32, split_k=0)
                 dbf = ops.colsum(df)
-                ops.gemm(df, fc_w, M=M, N=2 * d, K=d, w_kslow=True, ldw=2 * d, out=da[s])
+                ops.gemm(df, fc_w, M=M, N=2 * d, K=d, out=da[s])
                 grads_tail.append((dwf, dbf, dwo, dbo, dg2, dbt2, dw1, db1, dw2, db2))
             else:
-                ops.gemm(dx1, out_w, M=M, N=d, K=d, w_kslow=True, ldw=d, out=da[s])
+                ops.gemm(dx1, out_w, M=M, N=d, K=d, out=da[s])
                 grads_tail.append((dwo, dbo, dg2, dbt2, dw1, db1, dw2, db2))
             dx1_all.append(dx1)
         # attention backward: dqkv [S, M, 3d]
@@ -205,7 +213,7 @@ class TransformerBlockFn(torch.autograd.Function):
             dwqkv = ops.gemm(g, xn, M=3 * d, N=d, K=M, x_kslow=True, w_kslow=True, ldx=3 * d, ldw=d,
                              out_dtype=torch.float32, split_k=0)
             dbqkv = ops.colsum(g)
-            dxn = ops.gemm(g, qkv_w, M=M, N=d, K=3 * d, w_kslow=True, ldw=d)
+            dxn = ops.gemm(g, qkv_w, M=M, N=d, K=3 * d)
             dxs, dg1, dbt1 = ops.layernorm_bwd(dxn, x[s].reshape(M, d), mean1, rstd1, ln1w, dres=dx1_all[s])
             dx[s].reshape(M, d).copy_(dxs)
             out_grads += [dg1, dbt1, dwqkv[0:d], dbqkv[0:d], dwqkv[d:2 * d], dbqkv[d:2 * d], dwqkv[2 * d:],

@@ -48,10 +48,17 @@ class _GraphConvDense(nn.Module):
         nn.init.xavier_uniform_(self.weight)
 
     def forward(self, adj, feat):
+        """adj: (B, Nr, Nr) with Nr <= N nodes.  Nodes >= Nr are virtual padding nodes whose only edge is
+        their self loop (degree 1): for them the normalised aggregation is the identity, so only the
+        real-atom block goes through the batched product."""
+        Nr = adj.shape[-1]
+        fr = feat[:, :Nr]
         dout = adj.sum(dim=-1).clamp(min=1).pow(-0.5).unsqueeze(-1)     # out-degree of the source node
         din = adj.sum(dim=-2).clamp(min=1).pow(-0.5).unsqueeze(-1)      # in-degree of the destination
-        rst = torch.bmm(adj.transpose(1, 2), feat * dout)                # sum over incoming edges
-        rst = torch.matmul(rst, self.weight) * din + self.bias
+        agg = torch.bmm(adj.transpose(1, 2).to(fr.dtype), fr * dout.to(fr.dtype)) * din.to(fr.dtype)
+        if Nr < feat.shape[1]:
+            agg = torch.cat((agg, feat[:, Nr:]), dim=1)
+        rst = torch.matmul(agg, self.weight.to(agg.dtype)) + self.bias.to(agg.dtype)
         return F.relu(rst)
 
 
@@ -84,8 +91,9 @@ class _GCNDense(nn.Module):
 
 class MolecularGCN(nn.Module):
     """MolecularGCN (basic_model.py:137-153) without DGL.  Accepts either
-      * a (node_feats (B, N, in_feats), adjacency (B, N, N)) pair — batched dense graphs with the
-        reference's virtual padding nodes carrying self loops — or
+      * a (node_feats (B, N, in_feats), adjacency (B, Nr, Nr)) pair — batched dense graphs; the adjacency
+        covers the first Nr <= N nodes (all real atoms, self loops included), the remaining nodes are the
+        reference's virtual padding nodes whose only edge is their self loop — or
       * an already extracted (B, N, dim_embedding) node-feature tensor, returned unchanged
         (pre-extracted features; DGL/dgllife featurisation is out of scope).
     state_dict keys equal the reference's (init_transform, gnn.gnn_layers.i.{graph_conv,res_connection,bn_layer})."""

@@ -6,10 +6,10 @@ from __future__ import annotations
 import torch
 
 
-def make_batch(B: int, device, seed: int = 0, with_graph: bool = True, llm_dtype=torch.float32):
+def make_batch(B: int, device, seed: int = 0, with_graph: bool = True, llm_dtype=torch.float32, adj_nodes: int = 128):
     """Returns (feat_d, feat_p, labels, llm_d, llm_p), meta.
-    feat_d: (node_feats (B,512,75), adjacency (B,512,512)) dense batched graphs with self-looped virtual
-            padding nodes when with_graph, else pre-extracted GCN features (B,512,128);
+    feat_d: (node_feats (B,512,75), adjacency (B,adj_nodes,adj_nodes)) dense batched graphs (real-atom block;
+            nodes beyond it are self-looped virtual padding nodes) when with_graph, else pre-extracted GCN features (B,512,128);
     feat_p: (B,2304) float64 residue codes tiled like repeat_integer_label_protein;
     llm_d : (B,512,384) ChemBERTa-shaped token embeddings, zero after the last token;
     llm_p : (B,2304,640) ESM-2-shaped embeddings of an (Lp+2)-token protein tiled to 2304, zero tail."""
@@ -33,7 +33,7 @@ def make_batch(B: int, device, seed: int = 0, with_graph: bool = True, llm_dtype
     y = (torch.rand(B, generator=g) < 0.5).float()
     if with_graph:
         h = torch.zeros(B, 512, 75)
-        adj = torch.zeros(B, 512, 512)
+        adj = torch.zeros(B, adj_nodes, adj_nodes)
         for b in range(B):
             n = int(n_atom[b])
             h[b, :n, :74] = (torch.rand(n, 74, generator=g) < 0.1).float()
