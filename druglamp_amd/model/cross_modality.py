@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import dist_ops
 from .. import functional as Fn
 
 
@@ -66,19 +67,25 @@ class CrossModality(nn.Module):
         self.to_prot_latent = nn.Linear(hidden_size * 2, hidden_size * 2, bias=False)
         self.to_drug_latent = nn.Linear(hidden_size * 2, hidden_size * 2, bias=False)
         self.m_sch_loss_fn = MarginSchedule(m_ori=max_margin, n_re=n_re)
+        self.global_batch = bool(kwargs.get("global_batch", False))
 
     def step(self):
         self.m_sch_loss_fn.step()
 
-    def latents(self, prot, aug_prot, drug, aug_drug, pidx, didx):
-        pe = torch.cat([self.prot2latent(prot[pidx].float().mean(dim=1)),
-                        self.aug_prot2latent(aug_prot[pidx].float().mean(dim=1))], dim=-1)
-        de = torch.cat([self.drug2latent(drug[didx].float().mean(dim=1)),
-                        self.aug_drug2latent(aug_drug[didx].float().mean(dim=1))], dim=-1)
+    def latents_from_means(self, pm, apm, dm, adm, pidx, didx):
+        """pm/apm/dm/adm: per-sample token means (n, hidden).  Mean2Embed x4 -> concat -> Linear -> l2norm."""
+        pe = torch.cat([self.prot2latent(pm[pidx]), self.aug_prot2latent(apm[pidx])], dim=-1)
+        de = torch.cat([self.drug2latent(dm[didx]), self.aug_drug2latent(adm[didx])], dim=-1)
         return F.normalize(self.to_prot_latent(pe), dim=-1), F.normalize(self.to_drug_latent(de), dim=-1)
 
     def forward(self, prot, aug_prot, drug, aug_drug, meta):
+        means = [t.float().mean(dim=1) for t in (prot, aug_prot, drug, aug_drug)]
+        if self.global_batch and dist_ops.world_size() > 1:
+            # NEW vs the reference (off by default): the label matrix and the triplets span the GLOBAL batch.
+            # Only the (n, hidden) token means and the ids travel: 4 x 128 floats per pair over xGMI.
+            means = [dist_ops.all_gather_rows(m) for m in means]
+            meta = dist_ops.all_gather_meta(meta)
         pidx, didx, gt = label_matrix(meta, self.use_cm)
-        p_lats, d_lats = self.latents(prot, aug_prot, drug, aug_drug, pidx, didx)
+        p_lats, d_lats = self.latents_from_means(*means, pidx, didx)
         gt_dev = torch.from_numpy(gt).to(p_lats.device)
         return Fn.TripletSigCosFn.apply(p_lats, d_lats, gt_dev, float(self.m_sch_loss_fn.margin))

@@ -49,3 +49,36 @@ def test_gradient_allreduce_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from druglamp_amd import dist_ops
+    torch.manual_seed(rank)
+    x = torch.randn(3, 4, requires_grad=True)
+    full = dist_ops.all_gather_rows(x)
+    ok = tuple(full.shape) == (6, 4) and bool(torch.equal(full[rank * 3:(rank + 1) * 3], x.detach()))
+    # every rank evaluates the same "global" loss with rank-dependent upstream weights
+    w = torch.arange(24.0).view(6, 4) * (rank + 1)
+    (full * w).sum().backward()
+    expect = (torch.arange(24.0).view(6, 4) * 3.0)[rank * 3:(rank + 1) * 3]      # sum over ranks of w, local rows
+    ok &= bool(torch.allclose(x.grad, expect))
+    meta = dist_ops.all_gather_meta([{"Prot_ID": "p%d" % rank, "Drug_ID": rank, "Y": 1.0}])
+    ok &= [m["Prot_ID"] for m in meta] == ["p0", "p1"]
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_all_gather_rows_autograd_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
