@@ -739,3 +739,50 @@ class EmbeddingFn(torch.autograd.Function):
         if ctx.padding_idx is not None:
             dw[ctx.padding_idx].zero_()          # nn.Embedding(padding_idx=...) never updates that row
         return None, dw, None
+
+
+
+class BatchNormRowsFn(torch.autograd.Function):
+    """BatchNorm1d over the rows of a [R][C] matrix (training: batch statistics) on the dl_bn_* kernels.
+    Returns (y, mean, var) with biased variance; running-stat bookkeeping stays with the caller."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, eps):
+        R, C = x.shape
+        x = x.contiguous()
+        if training:
+            sums = ops.bn_stats(x, 0, 0, 0)
+            mean = sums[:C] / R
+            var = (sums[C:] / R - mean * mean).clamp_(min=0)
+        else:
+            mean, var = rmean.detach().float(), rvar.detach().float()
+        rstd = torch.rsqrt(var + eps)
+        g = gamma.detach().float()
+        y = ops.bn_apply_fwd(x, mean, rstd, g, beta.detach().float(), 0, 0, 0)
+        ctx.save_for_backward(x, mean, rstd, g)
+        ctx.training = training
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _m, _v):
+        x, mean, rstd, g = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("BatchNormRowsFn.backward: eval-mode backward is not implemented")
+        R, C = x.shape
+        dy = dy.contiguous()
+        sums = ops.bn_bwd_reduce(dy, x, mean, rstd, 0, 0, 0)
+        dx = ops.bn_bwd_apply(dy, x, mean, rstd, g, sums, 1.0 / R, False, 0, 0, 0)
+        return dx, sums[C:].clone(), sums[:C].clone(), None, None, None, None
+
+
+def batch_norm_rows(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor) -> torch.Tensor:
+    """nn.BatchNorm1d semantics (incl. running statistics, momentum, unbiased running variance)."""
+    y, mean, var = BatchNormRowsFn.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.eps)
+    if bn.training:
+        n = x2d.shape[0]
+        with torch.no_grad():
+            bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
+            bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
+            bn.num_batches_tracked += 1
+    return y

@@ -11,8 +11,7 @@ class DrugLAMP(DrugLAMPBase):
         super().__init__(n_drug_feature, n_prot_feature, n_hidden, **cfg)
 
     def forward(self, vd, vp, xd, xp, mode="train"):
-        with self._glue():
-            vd = self.drug_extractor(vd)
+        vd = self.drug_extractor(vd)
         fill_p = self._fill_bit(xp)
         xp = torch.cat((xp, fill_p.unsqueeze(-1)), dim=-1)
         xd = torch.cat((xd, self._fill_bit(xd).unsqueeze(-1)), dim=-1)

@@ -7,8 +7,7 @@ class DrugLAMPwoLLM(DrugLAMPBase):
         super().__init__(n_drug_feature, n_prot_feature, n_hidden, **cfg)
 
     def forward(self, vd, vp, xd, xp, mode="train"):
-        with self._glue():
-            vd = self.drug_extractor(vd)
+        vd = self.drug_extractor(vd)
         fill_p = self._fill_bit(xp)
         ssl = {"vp": vp, "xp": None, "fill_bit_p": fill_p, "vd": vd, "xd": None, "p_mode": "vp"}
         vpf = self._site_pool(self.protein_extractor(vp, fill_p))

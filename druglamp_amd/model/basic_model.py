@@ -58,8 +58,7 @@ class _GraphConvDense(nn.Module):
         agg = torch.bmm(adj.transpose(1, 2).to(fr.dtype), fr * dout.to(fr.dtype)) * din.to(fr.dtype)
         if Nr < feat.shape[1]:
             agg = torch.cat((agg, feat[:, Nr:]), dim=1)
-        rst = torch.matmul(agg, self.weight.to(agg.dtype)) + self.bias.to(agg.dtype)
-        return F.relu(rst)
+        return F.relu(Fn.dense(agg, self.weight.t(), self.bias))            # feature transform on the HIP GEMM path
 
 
 class _GCNLayerDense(nn.Module):
@@ -70,9 +69,9 @@ class _GCNLayerDense(nn.Module):
         self.bn_layer = nn.BatchNorm1d(out_feats)
 
     def forward(self, adj, feats):
-        new = self.graph_conv(adj, feats) + F.relu(self.res_connection(feats))
+        new = self.graph_conv(adj, feats) + F.relu(Fn.dense(feats, self.res_connection.weight, self.res_connection.bias))
         B, N, C = new.shape
-        return self.bn_layer(new.reshape(B * N, C)).reshape(B, N, C)
+        return Fn.batch_norm_rows(self.bn_layer, new.reshape(B * N, C)).reshape(B, N, C)
 
 
 class _GCNDense(nn.Module):
@@ -107,6 +106,7 @@ class MolecularGCN(nn.Module):
         self.gnn = _GCNDense(dim_embedding, hidden_feats)
         self.output_feats = hidden_feats[-1]
         self.in_feats = in_feats
+        self.compute_dtype = torch.float32
 
     def forward(self, batch_graph):
         if torch.is_tensor(batch_graph):
@@ -115,7 +115,9 @@ class MolecularGCN(nn.Module):
                                  % self.output_feats)
             return batch_graph
         node_feats, adj = batch_graph
-        return self.gnn(adj, self.init_transform(node_feats))
+        cdt = self.compute_dtype
+        h = Fn.cast(F.pad(node_feats.float(), (0, (-node_feats.shape[-1]) % 8)), cdt)   # 75 -> 80 columns
+        return self.gnn(adj, Fn.dense(h, self.init_transform.weight))
 
 
 class ProteinCNN(nn.Module):
@@ -246,7 +248,7 @@ class DrugLAMPBase(nn.Module):
             raise ValueError("compute dtype must be float32 or bfloat16")
         self.compute_dtype = dtype
         for m in self.modules():
-            if isinstance(m, (GuidedCrossAttention, MultiHeadLinearAttention, PairedMultimodelAttention, ProteinCNN)):
+            if isinstance(m, (GuidedCrossAttention, MultiHeadLinearAttention, PairedMultimodelAttention, ProteinCNN, MolecularGCN)):
                 m.compute_dtype = dtype
         return self
 
