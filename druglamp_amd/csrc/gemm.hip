@@ -522,7 +522,7 @@ namespace {
 // rows per workgroup are chosen per call so that the grid has >= ~1024 workgroups
 static inline int cs_rows_per_block(int64_t M, int64_t N) {
   const int64_t colgroups = (N + 255) / 256;
-  int64_t chunks = (1024 + colgroups - 1) / colgroups;
+  int64_t chunks = (512 + colgroups - 1) / colgroups;
   int64_t rows = (M + chunks - 1) / chunks;
   if (rows < 32) rows = 32;
   return (int)((rows + 3) / 4 * 4);

@@ -6,7 +6,7 @@ namespace {
 constexpr int LN_MAXV = 8;            // up to 8 x (64 lanes x 4 elems) = 2048 columns
 constexpr int LN_BWD_ROWS = 128;      // rows per workgroup in backward (32 per wave)
 
-template <typename T>
+template <typename T, int NV_>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
@@ -17,10 +17,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= M) return;
   const int nv = D >> 2;  // vec4 chunks per row
-  f32x4 v[LN_MAXV];
+  f32x4 v[NV_];
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
+  for (int j = 0; j < NV_; ++j) {
     const int c = lane + 64 * j;
     if (c < nv) {
       v[j] = load4<T>(x + row * ldx + c * 4);
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
+  for (int j = 0; j < NV_; ++j) {
     const int c = lane + 64 * j;
     if (c < nv) {
 #pragma unroll
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
   const float var = wave_sum(q) / (float)D;
   const float rstd = rsqrtf(var + eps);
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
+  for (int j = 0; j < NV_; ++j) {
     const int c = lane + 64 * j;
     if (c < nv) {
       const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c * 4);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
 }
 
 // partial layout: [nblocks][2][D]  (0: dgamma, 1: dbeta)
-template <typename T>
+template <typename T, int NV_>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int64_t lddy,
                                                      const T* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ mean,
@@ -71,9 +71,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
   float* sm = reinterpret_cast<float*>(ln_smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = D >> 2;
-  f32x4 gm[LN_MAXV], dg[LN_MAXV], db[LN_MAXV];
+  f32x4 gm[NV_], dg[NV_], db[NV_];
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
+  for (int j = 0; j < NV_; ++j) {
     const int c = lane + 64 * j;
     dg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -84,10 +84,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
     const int64_t row = r0 + rr;
     if (row >= M) break;
     const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[LN_MAXV], g[LN_MAXV];
+    f32x4 xh[NV_], g[NV_];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < NV_; ++j) {
       const int c = lane + 64 * j;
       if (c < nv) {
         const f32x4 xv = load4<T>(x + row * ldx + c * 4);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
     c1 = wave_sum(c1) / (float)D;
     c2 = wave_sum(c2) / (float)D;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < NV_; ++j) {
       const int c = lane + 64 * j;
       if (c < nv) {
         f32x4 o;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
   }
   // cross-wave reduction of dgamma/dbeta through LDS
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
+  for (int j = 0; j < NV_; ++j) {
     const int c = lane + 64 * j;
     if (c < nv) {
       *reinterpret_cast<f32x4*>(sm + (wave * 2 + 0) * D + c * 4) = dg[j];
@@ -160,12 +160,12 @@ extern "C" int dl_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, 
   DL_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0, DL_ERR_ALIGN, "dl_layernorm_fwd: ld must be multiple of 4");
   const uint32_t blocks = (uint32_t)((M + 3) / 4);
   dl_prof_before(3, s);
-  if (dtype == DL_BF16)
-    hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, ldx,
-                       gamma, beta, (bf16_t*)y, ldy, mean, rstd, M, (int)D, eps);
-  else
-    hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)x, ldx,
-                       gamma, beta, (float*)y, ldy, mean, rstd, M, (int)D, eps);
+#define LN_FWD(TT, NVV) hipLaunchKernelGGL((ln_fwd_kernel<TT, NVV>), dim3(blocks), dim3(256), 0, s, (const TT*)x, ldx, \
+                                          gamma, beta, (TT*)y, ldy, mean, rstd, M, (int)D, eps)
+  const int nvg = (int)((D + 255) / 256);
+  if (dtype == DL_BF16) { if (nvg <= 1) LN_FWD(bf16_t, 1); else if (nvg <= 2) LN_FWD(bf16_t, 2); else if (nvg <= 4) LN_FWD(bf16_t, 4); else LN_FWD(bf16_t, 8); }
+  else { if (nvg <= 1) LN_FWD(float, 1); else if (nvg <= 2) LN_FWD(float, 2); else if (nvg <= 4) LN_FWD(float, 4); else LN_FWD(float, 8); }
+#undef LN_FWD
   DL_CHECK_LAUNCH("dl_layernorm_fwd");
   dl_prof_after(3, s, 8.0 * M * D, 2.0 * M * D * dl_dtype_size(dtype));
   return DL_OK;
@@ -189,14 +189,13 @@ extern "C" int dl_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
                DL_ERR_WORKSPACE, "dl_layernorm_bwd: workspace too small");
   const int nb = (int)((M + LN_BWD_ROWS - 1) / LN_BWD_ROWS);
   const size_t smem = 4 * 2 * (size_t)D * sizeof(float);
-  if (dtype == DL_BF16)
-    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(nb), dim3(256), smem, s, (const bf16_t*)dy, lddy,
-                       (const bf16_t*)x, ldx, mean, rstd, gamma, (const bf16_t*)dres, lddres,
-                       (bf16_t*)dx, lddx, (float*)workspace, M, (int)D);
-  else
-    hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(nb), dim3(256), smem, s, (const float*)dy, lddy,
-                       (const float*)x, ldx, mean, rstd, gamma, (const float*)dres, lddres, (float*)dx,
-                       lddx, (float*)workspace, M, (int)D);
+#define LN_BWD(TT, NVV) hipLaunchKernelGGL((ln_bwd_kernel<TT, NVV>), dim3(nb), dim3(256), smem, s, (const TT*)dy, lddy, \
+                                          (const TT*)x, ldx, mean, rstd, gamma, (const TT*)dres, lddres, (TT*)dx, lddx, \
+                                          (float*)workspace, M, (int)D)
+  const int nvg = (int)((D + 255) / 256);
+  if (dtype == DL_BF16) { if (nvg <= 1) LN_BWD(bf16_t, 1); else if (nvg <= 2) LN_BWD(bf16_t, 2); else if (nvg <= 4) LN_BWD(bf16_t, 4); else LN_BWD(bf16_t, 8); }
+  else { if (nvg <= 1) LN_BWD(float, 1); else if (nvg <= 2) LN_BWD(float, 2); else if (nvg <= 4) LN_BWD(float, 4); else LN_BWD(float, 8); }
+#undef LN_BWD
   DL_CHECK_LAUNCH("dl_layernorm_bwd");
   if (dgamma)
     hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(256), 0, s,

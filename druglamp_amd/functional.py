@@ -214,8 +214,8 @@ class TransformerBlockFn(torch.autograd.Function):
                              out_dtype=torch.float32, split_k=0)
             dbqkv = ops.colsum(g)
             dxn = ops.gemm(g, qkv_w, M=M, N=d, K=3 * d)
-            dxs, dg1, dbt1 = ops.layernorm_bwd(dxn, x[s].reshape(M, d), mean1, rstd1, ln1w, dres=dx1_all[s])
-            dx[s].reshape(M, d).copy_(dxs)
+            _, dg1, dbt1 = ops.layernorm_bwd(dxn, x[s].reshape(M, d), mean1, rstd1, ln1w, dres=dx1_all[s],
+                                             out=dx[s].reshape(M, d))
             out_grads += [dg1, dbt1, dwqkv[0:d], dbqkv[0:d], dwqkv[d:2 * d], dbqkv[d:2 * d], dwqkv[2 * d:],
                           dbqkv[2 * d:]]
             out_grads += list(grads_tail[s])

@@ -13,9 +13,12 @@ class DrugLAMP(DrugLAMPBase):
     def forward(self, vd, vp, xd, xp, mode="train"):
         vd = self.drug_extractor(vd)
         fill_p = self._fill_bit(xp)
-        xp = torch.cat((xp, fill_p.unsqueeze(-1)), dim=-1)
         xd = torch.cat((xd, self._fill_bit(xd).unsqueeze(-1)), dim=-1)
-        ssl = {"vp": vp, "xp": xp, "fill_bit_p": fill_p, "vd": vd, "xd": xd}
+        # the reference concatenates the fill bit onto the (B, 2304, 640) ESM tensor here (DrugLAMP.py:14);
+        # that 641-wide copy is only consumed by the SSL head, so it is handed over as the pair
+        # (embeddings, fill bit) and materialised by SSL.forward on SSL epochs only
+        ssl = {"vp": vp, "xp": (xp, fill_p), "fill_bit_p": fill_p, "vd": vd, "xd": xd}
+        xp = torch.cat((self._site_pool(xp), self._site_pool(fill_p.unsqueeze(-1))), dim=-1)   # (B, 256, 641)
         vpf = self._site_pool(self.protein_extractor(vp, fill_p))
         xpf, xdf = self._llm_adaptors(xp, xd)
         vpf, vdf = vpf.float(), vd.float()

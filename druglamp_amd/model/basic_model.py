@@ -276,10 +276,11 @@ class DrugLAMPBase(nn.Module):
         return m, raw
 
     def _llm_adaptors(self, xp_cat, xd_cat):
-        """Protein / drug LLM adaptors (DrugLAMP.py:39-52) on the HIP GEMM path: 641- and 385-wide features
+        """xp_cat: SITE-POOLED protein LLM features with fill bit (B, 256, 641); xd_cat: (B, 512, 385).
+        Protein / drug LLM adaptors (DrugLAMP.py:39-52) on the HIP GEMM path: 641- and 385-wide features
         are zero-padded to 648 / 392 so that every product is an aligned MFMA GEMM."""
         cdt = self.compute_dtype
-        xps = self._site_pool(xp_cat)                                             # (B, 256, 641)
+        xps = xp_cat                                                              # site-pooled (B, 256, 641)
         xps = Fn.cast(F.pad(xps.float(), (0, (-xps.shape[-1]) % 8)), cdt)
         a = self.p_adaptor_wo_skip_connect
         h = Fn.dense(xps, a.lin1.weight, a.lin1.bias, act=True)

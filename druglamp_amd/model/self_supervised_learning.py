@@ -114,6 +114,8 @@ class SSL(nn.Module):
         return loss / 2 if mode == "double" else loss
 
     def forward(self, vp, xp, fill_bit_p, vd, xd, p_mode="double", mask=None, replace=None):
+        if isinstance(xp, (tuple, list)):          # (embeddings (B,S,640), fill bit (B,S)) -> (B,S,641)
+            xp = torch.cat((xp[0], xp[1].unsqueeze(-1).to(xp[0].dtype)), dim=-1)
         prot = self.prot_mlm(vp, self.extractor, xp, fill_bit_p, p_mode, mask=mask, replace=replace)
         if vd is None or xd is None:
             drug = 0

@@ -126,10 +126,10 @@ def layernorm_fwd(x2d, gamma, beta, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dres=None, need_param_grads=True):
+def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dres=None, need_param_grads=True, out=None):
     L = _lib.lib()
     M, D = x2d.shape
-    dx = torch.empty_like(x2d)
+    dx = torch.empty_like(x2d) if out is None else out
     dgamma = torch.empty(D, dtype=torch.float32, device=x2d.device) if need_param_grads else None
     dbeta = torch.empty(D, dtype=torch.float32, device=x2d.device) if need_param_grads else None
     ws = _ws.get(L.dl_layernorm_bwd_workspace_bytes(M, D), x2d.device)
