@@ -134,8 +134,11 @@ __device__ __forceinline__ u32x4 read_frag(const char* lds, int rb, int kf, int 
   }
 }
 
-template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA>
+// EPI: 0 bias only | 1 general (all runtime flags) | 2 bias+pre_out+GELU(+dropout) | 3 bias(+dropout)+residual |
+//      4 gelu'(dact_pre)(+dropout) | 5 bias+ReLU.   EPI != 1 need N % 8 == 0 and take 16-byte accesses only.
+template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
+  constexpr bool SIMPLE = (EPI == 0);
   constexpr bool XD = DMA && !XS, WD = DMA && !WS;   // operands staged by LDS-DMA
   constexpr int BKE = TileGeom<T>::BKE;
   constexpr int NFRAG = BKE / Mma<T>::KF;
@@ -242,6 +245,63 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
     const int m = cm0 + row, n = cn0 + cc;
     if (m >= p.M || n >= p.N) continue;
     if ((p.dbg & 1)) continue;
+    if constexpr (SIMPLE && !SPLIT) {
+      // bias-only epilogue, N % 8 == 0: straight LDS -> (bias) -> convert -> one 16-byte store
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4);
+      f32x4 a1 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4 + 16);
+      if (p.bias) {
+        a0 += *reinterpret_cast<const f32x4*>(p.bias + n);
+        a1 += *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+      }
+      TO* dst = reinterpret_cast<TO*>(p.C) + (int64_t)m * p.ldc + n;
+      if constexpr (sizeof(TO) == 2) {
+        u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
+        *reinterpret_cast<u32x4*>(dst) = o;
+      } else {
+        *reinterpret_cast<f32x4*>(dst) = a0;
+        *reinterpret_cast<f32x4*>(dst + 4) = a1;
+      }
+      continue;
+    }
+    if constexpr (!SPLIT && EPI >= 2) {
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4);
+      f32x4 a1 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4 + 16);
+      if (EPI != 4 && p.bias) {
+        a0 += *reinterpret_cast<const f32x4*>(p.bias + n);
+        a1 += *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+      }
+      if constexpr (EPI == 2) {
+        T* pd = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
+        store4<T>(pd, a0); store4<T>(pd + 4, a1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a0[r] = gelu_erf(a0[r]); a1[r] = gelu_erf(a1[r]); }
+      } else if constexpr (EPI == 5) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.f); a1[r] = fmaxf(a1[r], 0.f); }
+      } else if constexpr (EPI == 4) {
+        const T* src = reinterpret_cast<const T*>(p.dact_pre) + (int64_t)m * p.lddp + n;
+        const f32x4 q0 = load4<T>(src), q1 = load4<T>(src + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a0[r] *= gelu_erf_grad(q0[r]); a1[r] *= gelu_erf_grad(q1[r]); }
+      }
+      if (EPI != 5 && p.drop_thr16) {
+        a0 = dl_dropout4(a0, p.seed, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+        a1 = dl_dropout4(a1, p.seed, (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+      }
+      if constexpr (EPI == 3) {
+        const T* src = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n;
+        a0 += load4<T>(src); a1 += load4<T>(src + 4);
+      }
+      TO* dst = reinterpret_cast<TO*>(p.C) + (int64_t)m * p.ldc + n;
+      if constexpr (sizeof(TO) == 2) {
+        u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
+        *reinterpret_cast<u32x4*>(dst) = o;
+      } else {
+        *reinterpret_cast<f32x4*>(dst) = a0;
+        *reinterpret_cast<f32x4*>(dst + 4) = a1;
+      }
+      continue;
+    }
     float v[8];
     {
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4);
@@ -387,9 +447,32 @@ int resolve_split(const dl_gemm_args* a) {
 
 template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA>
 void launch(const GemmP& p, hipStream_t s) {
+  int epi = 1;
+  if (!SPLIT && (p.N % 8 == 0) && !p.accumulate && p.res_row_mod == 0 && !(p.res && p.res_before_dropout)) {
+    const bool drop = p.drop_thr16 != 0;
+    if (!p.res && !p.act && !p.pre_out && !p.dact_pre && !drop) epi = 0;
+    else if (p.act == 1 && p.pre_out && !p.res && !p.dact_pre) epi = 2;
+    else if (p.res && !p.act && !p.pre_out && !p.dact_pre) epi = 3;
+    else if (p.dact_pre && !p.res && !p.act && !p.pre_out && !p.bias) epi = 4;
+    else if (p.act == 2 && !p.res && !p.pre_out && !p.dact_pre && !drop) epi = 5;
+  }
   const uint32_t ntiles = (uint32_t)p.mt * p.nt * p.splits;
   const uint32_t nblocks = ntiles < 512u ? ntiles : 512u;      // 256 CUs x 2 resident workgroups (LDS-limited)
-  hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT, DMA>), dim3(nblocks), dim3(NTHREADS), 0, s, p);
+#define DL_LAUNCH(E) hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT, DMA, E>), dim3(nblocks), dim3(NTHREADS), 0, s, p)
+  if constexpr (SPLIT || !DMA) {
+    // split-K slabs and the register-staged layouts keep two variants only
+    if (epi == 0) DL_LAUNCH(0); else DL_LAUNCH(1);
+  } else {
+    switch (epi) {
+      case 0: DL_LAUNCH(0); break;
+      case 2: DL_LAUNCH(2); break;
+      case 3: DL_LAUNCH(3); break;
+      case 4: DL_LAUNCH(4); break;
+      case 5: DL_LAUNCH(5); break;
+      default: DL_LAUNCH(1); break;
+    }
+  }
+#undef DL_LAUNCH
 }
 
 template <typename T, typename TO, bool SPLIT>
