@@ -5,7 +5,7 @@
 namespace {
 static inline int bn_rows_per_block(int64_t R, int64_t C) {
   const int64_t colgroups = (C + 255) / 256;
-  int64_t chunks = (512 + colgroups - 1) / colgroups;
+  int64_t chunks = (1024 + colgroups - 1) / colgroups;
   int64_t rows = (R + chunks - 1) / chunks;
   if (rows < 32) rows = 32;
   return (int)((rows + 3) / 4 * 4);

@@ -16,13 +16,16 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BKB = 128;  // BKB: bytes of contraction per operand row per step
+constexpr int BKB = 128;  // bytes of contraction per operand row per step
+// TW = MFMA 16x16 tiles per wave per dimension: the workgroup tile is (32*TW)^2 — 128x128 (TW=4, default)
+// or 64x64 (TW=2, used for weight gradients with few output tiles so that split-K slabs stay small).
 constexpr int NTHREADS = 256;
 
-template <typename T> struct TileGeom {
+template <typename T, int TW> struct TileGeom {
+  static constexpr int BT = 32 * TW;                                // tile rows / cols
   static constexpr int BKE = BKB / (int)sizeof(T);                 // contraction elems per step
-  static constexpr int PITCH_KSLOW = 128 * (int)sizeof(T) + 32;     // bytes per k-row (padded)
-  static constexpr int TILE_KCONTIG = 128 * BKB;                    // 16384
+  static constexpr int PITCH_KSLOW = BT * (int)sizeof(T) + 32;      // bytes per k-row (padded)
+  static constexpr int TILE_KCONTIG = BT * BKB;                     // 16384 at TW=4
   static constexpr int TILE_KSLOW = BKE * PITCH_KSLOW;              // 18432 (bf16) / 17408 (f32)
   static constexpr int TILE_BYTES = TILE_KSLOW > TILE_KCONTIG ? TILE_KSLOW : TILE_KCONTIG;
 };
@@ -43,13 +46,13 @@ struct GemmP {
 };
 
 // ---- global -> registers (4 chunks of 16 B per thread per operand) ------------------------
-template <typename T, bool KSLOW>
+template <typename T, bool KSLOW, int TW>
 __device__ __forceinline__ void load_tile(const char* base, int64_t ld, int row0, int nrows, int k0,
-                                          int kend, u32x4 (&r)[4]) {
+                                          int kend, u32x4 (&r)[TW]) {
   constexpr int EPC = Mma<T>::EPC;
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TW; ++i) {
     const int c = tid + i * NTHREADS;
     u32x4 v = {0u, 0u, 0u, 0u};
     if constexpr (!KSLOW) {
@@ -58,7 +61,7 @@ __device__ __forceinline__ void load_tile(const char* base, int64_t ld, int row0
       if (gr < nrows && gk < kend)
         v = *reinterpret_cast<const u32x4*>(base + ((int64_t)gr * ld + gk) * (int64_t)sizeof(T));
     } else {
-      constexpr int CPR = 128 / EPC;  // chunks per k-row
+      constexpr int CPR = 32 * TW / EPC;  // chunks per k-row
       const int krow = c / CPR, cc = c % CPR;
       const int gk = k0 + krow, gr = row0 + cc * EPC;
       if (gk < kend && gr < nrows)
@@ -68,20 +71,20 @@ __device__ __forceinline__ void load_tile(const char* base, int64_t ld, int row0
   }
 }
 
-template <typename T, bool KSLOW>
-__device__ __forceinline__ void store_tile(char* lds, const u32x4 (&r)[4]) {
+template <typename T, bool KSLOW, int TW>
+__device__ __forceinline__ void store_tile(char* lds, const u32x4 (&r)[TW]) {
   constexpr int EPC = Mma<T>::EPC;
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TW; ++i) {
     const int c = tid + i * NTHREADS;
     if constexpr (!KSLOW) {
       const int row = c >> 3, kc = c & 7;
       lds_write16(lds, row * BKB + ((kc ^ (row & 7)) << 4), r[i]);
     } else {
-      constexpr int CPR = 128 / EPC;
+      constexpr int CPR = 32 * TW / EPC;
       const int krow = c / CPR, cc = c % CPR;
-      lds_write16(lds, krow * TileGeom<T>::PITCH_KSLOW + cc * 16, r[i]);
+      lds_write16(lds, krow * TileGeom<T, TW>::PITCH_KSLOW + cc * 16, r[i]);
     }
   }
 }
@@ -91,12 +94,12 @@ __device__ __forceinline__ void store_tile(char* lds, const u32x4 (&r)[4]) {
 // the XOR swizzle is applied on the SOURCE side: LDS slot (row, physical chunk pc) receives the row's
 // logical chunk pc ^ (row & 7).  Rows beyond the operand are clamped to its last row (their products
 // only reach output rows/columns that are never stored); the K range must be whole steps.
-template <typename T>
+template <typename T, int TW>
 __device__ __forceinline__ void dma_tile(const char* base, int64_t ld, int row0, int nrows, int k0, char* lds) {
   constexpr int EPC = Mma<T>::EPC;
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TW; ++i) {
     const int c = tid + i * NTHREADS;
     const int row = c >> 3, kc = (c & 7) ^ (row & 7);
     int gr = row0 + row;
@@ -109,13 +112,13 @@ __device__ __forceinline__ void dma_tile(const char* base, int64_t ld, int row0,
 }
 
 // fragment for 16 tile rows starting at rb, fragment index kf within the step
-template <typename T, bool KSLOW>
+template <typename T, bool KSLOW, int TW>
 __device__ __forceinline__ u32x4 read_frag(const char* lds, int rb, int kf, int il, int g) {
   if constexpr (!KSLOW) {
     const int row = rb + il;
     return lds_read16(lds, row * BKB + (((kf * 4 + g) ^ (row & 7)) << 4));
   } else if constexpr (sizeof(T) == 2) {
-    constexpr int P = TileGeom<T>::PITCH_KSLOW;
+    constexpr int P = TileGeom<T, TW>::PITCH_KSLOW;
     const int kidx = kf * 32 + g * 8 + (il >> 2);
     const int col = rb + (il & 3) * 4;
     const u32x2 a = lds_read_tr16(lds, kidx * P + col * 2);
@@ -123,7 +126,7 @@ __device__ __forceinline__ u32x4 read_frag(const char* lds, int rb, int kf, int 
     u32x4 r = {a[0], a[1], b[0], b[1]};
     return r;
   } else {
-    constexpr int P = TileGeom<T>::PITCH_KSLOW;
+    constexpr int P = TileGeom<T, TW>::PITCH_KSLOW;
     const int kidx = kf * 16 + g * 4;
     const int col = rb + il;
     u32x4 r;
@@ -136,13 +139,14 @@ __device__ __forceinline__ u32x4 read_frag(const char* lds, int rb, int kf, int 
 
 // EPI: 0 bias only | 1 general (all runtime flags) | 2 bias+pre_out+GELU(+dropout) | 3 bias(+dropout)+residual |
 //      4 gelu'(dact_pre)(+dropout) | 5 bias+ReLU.   EPI != 1 need N % 8 == 0 and take 16-byte accesses only.
-template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA, int EPI>
+template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA, int EPI, int TW>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   constexpr bool SIMPLE = (EPI == 0);
+  constexpr int BM = 32 * TW, BN = 32 * TW;
   constexpr bool XD = DMA && !XS, WD = DMA && !WS;   // operands staged by LDS-DMA
-  constexpr int BKE = TileGeom<T>::BKE;
+  constexpr int BKE = TileGeom<T, TW>::BKE;
   constexpr int NFRAG = BKE / Mma<T>::KF;
-  constexpr int TB = TileGeom<T>::TILE_BYTES;
+  constexpr int TB = TileGeom<T, TW>::TILE_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -167,52 +171,52 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
     kbeg = split * p.k_per_split;
     kend = min(p.K, kbeg + p.k_per_split);
   };
-  u32x4 rx[4], rw[4];
+  u32x4 rx[TW], rw[TW];
   uint32_t it = blockIdx.x;
   if (it >= ntiles) return;
   if ((p.dbg & 4) && (blockIdx.x & 8)) { for (int z = 0; z < (p.dbg >> 4); ++z) __builtin_amdgcn_s_sleep(127); }
   int split, m0, n0, kbeg, kend;
   locate(it, split, m0, n0, kbeg, kend);
-  if constexpr (!XD) load_tile<T, XS>(p.X, p.ldx, m0, p.M, kbeg, kend, rx);
-  if constexpr (!WD) load_tile<T, WS>(p.W, p.ldw, n0, p.N, kbeg, kend, rw);
+  if constexpr (!XD) load_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg, kend, rx);
+  if constexpr (!WD) load_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg, kend, rw);
   for (;;) {
-  f32x4 acc[4][4];
+  f32x4 acc[TW][TW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TW; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (kend - kbeg + BKE - 1) / BKE;
-  if constexpr (XD) dma_tile<T>(p.X, p.ldx, m0, p.M, kbeg, smem);
-  else store_tile<T, XS>(smem, rx);
-  if constexpr (WD) dma_tile<T>(p.W, p.ldw, n0, p.N, kbeg, smem + TB);
-  else store_tile<T, WS>(smem + TB, rw);
+  if constexpr (XD) dma_tile<T, TW>(p.X, p.ldx, m0, p.M, kbeg, smem);
+  else store_tile<T, XS, TW>(smem, rx);
+  if constexpr (WD) dma_tile<T, TW>(p.W, p.ldw, n0, p.N, kbeg, smem + TB);
+  else store_tile<T, WS, TW>(smem + TB, rw);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     char* cur = smem + (kt & 1) * 2 * TB;
     char* nxt = smem + ((kt + 1) & 1) * 2 * TB;
     const bool more = (kt + 1 < nk);
     if (more && !(p.dbg & 2)) {
-      if constexpr (XD) dma_tile<T>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, nxt);
-      else load_tile<T, XS>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, kend, rx);
-      if constexpr (WD) dma_tile<T>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, nxt + TB);
-      else load_tile<T, WS>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, kend, rw);
+      if constexpr (XD) dma_tile<T, TW>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, nxt);
+      else load_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, kend, rx);
+      if constexpr (WD) dma_tile<T, TW>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, nxt + TB);
+      else load_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, kend, rw);
     }
 #pragma unroll
     for (int kf = 0; kf < NFRAG; ++kf) {
-      u32x4 fx[4], fw[4];
+      u32x4 fx[TW], fw[TW];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fx[i] = read_frag<T, XS>(cur, wm * 64 + i * 16, kf, il, g);
+      for (int i = 0; i < TW; ++i) fx[i] = read_frag<T, XS, TW>(cur, wm * 16 * TW + i * 16, kf, il, g);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fw[j] = read_frag<T, WS>(cur + TB, wn * 64 + j * 16, kf, il, g);
+      for (int j = 0; j < TW; ++j) fw[j] = read_frag<T, WS, TW>(cur + TB, wn * 16 * TW + j * 16, kf, il, g);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(fw[j], fx[i], acc[i][j]);
+        for (int j = 0; j < TW; ++j) acc[i][j] = Mma<T>::mma(fw[j], fx[i], acc[i][j]);
     }
     if (more) {
-      if constexpr (!XD) store_tile<T, XS>(nxt, rx);
-      if constexpr (!WD) store_tile<T, WS>(nxt + TB, rw);
+      if constexpr (!XD) store_tile<T, XS, TW>(nxt, rx);
+      if constexpr (!WD) store_tile<T, WS, TW>(nxt + TB, rw);
     }
     __syncthreads();
   }
@@ -222,8 +226,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   const bool have_next = itn < ntiles;
   if (have_next) {
     locate(itn, split, m0, n0, kbeg, kend);
-    if constexpr (!XD) load_tile<T, XS>(p.X, p.ldx, m0, p.M, kbeg, kend, rx);
-    if constexpr (!WD) load_tile<T, WS>(p.W, p.ldw, n0, p.N, kbeg, kend, rw);
+    if constexpr (!XD) load_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg, kend, rx);
+    if constexpr (!WD) load_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg, kend, rw);
   }
 
   // ---- epilogue -------------------------------------------------------------------------------
@@ -232,16 +236,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   // CONSECUTIVE columns of one row: bias / residual / pre-activation traffic and the final store are
   // full 16-byte (bf16) or 2x16-byte (f32) accesses, 16 lanes per 256-byte row -> whole cache lines.
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TW; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(smem + (wm * 64 + i * 16 + il) * EP + (wn * 64 + j * 16 + 4 * g) * 4) = acc[i][j];
+    for (int j = 0; j < TW; ++j)
+      *reinterpret_cast<f32x4*>(smem + (wm * 16 * TW + i * 16 + il) * EP + (wn * 16 * TW + j * 16 + 4 * g) * 4) = acc[i][j];
   __syncthreads();
   const bool vec_ok = (p.N & 7) == 0;
 #pragma unroll 2
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < TW * TW / 2; ++it) {
     const int c = tid + it * NTHREADS;
-    const int row = c >> 4, cc = (c & 15) * 8;
+    const int row = c / (BN / 8), cc = (c % (BN / 8)) * 8;
     const int m = cm0 + row, n = cn0 + cc;
     if (m >= p.M || n >= p.N) continue;
     if ((p.dbg & 1)) continue;
@@ -423,8 +427,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, TO* __rest
   store4<TO>(dst, s);
 }
 
-int auto_split(int64_t M, int64_t N, int64_t K, int bke) {
-  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+// tile width (MFMA tiles per wave per dim): 64x64 workgroup tiles for weight gradients with few output tiles
+int pick_tw(const dl_gemm_args* a) {
+  if (a->x_kslow && a->w_kslow && a->split_k >= 0) {
+    const int64_t tiles128 = ((a->M + 127) / 128) * ((a->N + 127) / 128);
+    if (tiles128 <= 4) return 2;
+  }
+  return 4;
+}
+
+int auto_split(int64_t M, int64_t N, int64_t K, int bke, int bt) {
+  const int64_t tiles = ((M + bt - 1) / bt) * ((N + bt - 1) / bt);
   if (tiles >= 192) return 1;
   int64_t want = (512 + tiles - 1) / tiles;
   int64_t ksteps = (K + bke - 1) / bke;
@@ -442,11 +455,11 @@ int resolve_split(const dl_gemm_args* a) {
   // auto: only legal for plain f32 outputs
   const bool plain = !a->bias && !a->residual && !a->act && !a->pre_out && !a->dact_pre &&
                      a->dropout_p <= 0.f && a->out_dtype == DL_F32 && (a->N % 4 == 0);
-  return plain ? auto_split(a->M, a->N, a->K, bke) : 1;
+  return plain ? auto_split(a->M, a->N, a->K, bke, 32 * pick_tw(a)) : 1;
 }
 
 template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA>
-void launch(const GemmP& p, hipStream_t s) {
+void launch(const GemmP& p, hipStream_t s, int tw) {
   int epi = 1;
   if (!SPLIT && (p.N % 8 == 0) && !p.accumulate && p.res_row_mod == 0 && !(p.res && p.res_before_dropout)) {
     const bool drop = p.drop_thr16 != 0;
@@ -458,9 +471,17 @@ void launch(const GemmP& p, hipStream_t s) {
   }
   const uint32_t ntiles = (uint32_t)p.mt * p.nt * p.splits;
   const uint32_t nblocks = ntiles < 512u ? ntiles : 512u;      // 256 CUs x 2 resident workgroups (LDS-limited)
-#define DL_LAUNCH(E) hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT, DMA, E>), dim3(nblocks), dim3(NTHREADS), 0, s, p)
-  if constexpr (SPLIT || !DMA) {
-    // split-K slabs and the register-staged layouts keep two variants only
+#define DL_LAUNCH(E) hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT, DMA, E, 4>), dim3(nblocks), dim3(NTHREADS), 0, s, p)
+  if constexpr (SPLIT) {
+    if constexpr (XS && WS) {
+      if (tw == 2) {
+        hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT, DMA, 1, 2>), dim3(nblocks), dim3(NTHREADS), 0, s, p);
+        return;
+      }
+    }
+    DL_LAUNCH(1);
+  } else if constexpr (!DMA) {
+    // the register-staged layouts keep two variants only
     if (epi == 0) DL_LAUNCH(0); else DL_LAUNCH(1);
   } else {
     switch (epi) {
@@ -476,13 +497,13 @@ void launch(const GemmP& p, hipStream_t s) {
 }
 
 template <typename T, typename TO, bool SPLIT>
-int dispatch_layout(const dl_gemm_args* a, const GemmP& p, hipStream_t s) {
+int dispatch_layout(const dl_gemm_args* a, const GemmP& p, hipStream_t s, int tw) {
   // LDS-DMA staging needs whole K steps per split and at least one K-contiguous operand
   const int bke = BKB / (int)sizeof(T);
   const bool dma = (a->K % bke == 0) && (p.k_per_split % bke == 0) && !(p.dbg & 8);
-  if (!a->x_kslow && !a->w_kslow) { if (dma) launch<T, TO, false, false, SPLIT, true>(p, s); else launch<T, TO, false, false, SPLIT, false>(p, s); }
-  else if (!a->x_kslow && a->w_kslow) { if (dma) launch<T, TO, false, true, SPLIT, true>(p, s); else launch<T, TO, false, true, SPLIT, false>(p, s); }
-  else if (a->x_kslow && a->w_kslow) launch<T, TO, true, true, SPLIT, false>(p, s);
+  if (!a->x_kslow && !a->w_kslow) { if (dma) launch<T, TO, false, false, SPLIT, true>(p, s, tw); else launch<T, TO, false, false, SPLIT, false>(p, s, tw); }
+  else if (!a->x_kslow && a->w_kslow) { if (dma) launch<T, TO, false, true, SPLIT, true>(p, s, tw); else launch<T, TO, false, true, SPLIT, false>(p, s, tw); }
+  else if (a->x_kslow && a->w_kslow) launch<T, TO, true, true, SPLIT, false>(p, s, tw);
   else {
     dl_set_error("dl_gemm: layout x_kslow=1,w_kslow=0 is not instantiated");
     return DL_ERR_UNSUPPORTED;
@@ -548,7 +569,9 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   p.X = (const char*)a->X; p.W = (const char*)a->W; p.C = (char*)a->C;
   p.ldx = a->ldx; p.ldw = a->ldw; p.ldc = a->ldc;
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
-  p.mt = (int)((a->M + BM - 1) / BM); p.nt = (int)((a->N + BN - 1) / BN); p.splits = sp;
+  const int tw = sp > 1 ? pick_tw(a) : 4;
+  const int bt = 32 * tw;
+  p.mt = (int)((a->M + bt - 1) / bt); p.nt = (int)((a->N + bt - 1) / bt); p.splits = sp;
   const int bke = BKB / es;
   {
     const int64_t ksteps = (a->K + bke - 1) / bke;
@@ -571,12 +594,12 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   dl_prof_before(0, s);
   int rc = DL_OK;
   if (a->in_dtype == DL_BF16) {
-    if (sp > 1) rc = dispatch_layout<bf16_t, float, true>(a, p, s);
-    else if (a->out_dtype == DL_F32) rc = dispatch_layout<bf16_t, float, false>(a, p, s);
-    else rc = dispatch_layout<bf16_t, bf16_t, false>(a, p, s);
+    if (sp > 1) rc = dispatch_layout<bf16_t, float, true>(a, p, s, tw);
+    else if (a->out_dtype == DL_F32) rc = dispatch_layout<bf16_t, float, false>(a, p, s, tw);
+    else rc = dispatch_layout<bf16_t, bf16_t, false>(a, p, s, tw);
   } else {
-    if (sp > 1) rc = dispatch_layout<float, float, true>(a, p, s);
-    else rc = dispatch_layout<float, float, false>(a, p, s);
+    if (sp > 1) rc = dispatch_layout<float, float, true>(a, p, s, tw);
+    else rc = dispatch_layout<float, float, false>(a, p, s, tw);
   }
   if (rc != DL_OK) return rc;
   DL_CHECK_LAUNCH("dl_gemm");
@@ -605,7 +628,7 @@ namespace {
 // rows per workgroup are chosen per call so that the grid has >= ~1024 workgroups
 static inline int cs_rows_per_block(int64_t M, int64_t N) {
   const int64_t colgroups = (N + 255) / 256;
-  int64_t chunks = (512 + colgroups - 1) / colgroups;
+  int64_t chunks = (1024 + colgroups - 1) / colgroups;
   int64_t rows = (M + chunks - 1) / chunks;
   if (rows < 32) rows = 32;
   return (int)((rows + 3) / 4 * 4);
