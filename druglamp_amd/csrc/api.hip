@@ -83,24 +83,26 @@ extern "C" int dl_prof_collect(int32_t family, int64_t* launches, double* total_
 
 __global__ void dl_reduce_partials_kernel(const float* __restrict__ partial, int chunks, int64_t stride, int ncols,
                                           float* __restrict__ out, int accumulate) {
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // blockDim.x = 64 * NW waves; wave w takes chunks w, w+NW, ... (4 loads in flight per thread)
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (c < ncols) {
     int k = wave;
-    for (; k + 12 < chunks; k += 16) {
+    for (; k + 3 * nw < chunks; k += 4 * nw) {
       a0 += partial[(int64_t)k * stride + c];
-      a1 += partial[(int64_t)(k + 4) * stride + c];
-      a2 += partial[(int64_t)(k + 8) * stride + c];
-      a3 += partial[(int64_t)(k + 12) * stride + c];
+      a1 += partial[(int64_t)(k + nw) * stride + c];
+      a2 += partial[(int64_t)(k + 2 * nw) * stride + c];
+      a3 += partial[(int64_t)(k + 3 * nw) * stride + c];
     }
-    for (; k < chunks; k += 4) a0 += partial[(int64_t)k * stride + c];
+    for (; k < chunks; k += nw) a0 += partial[(int64_t)k * stride + c];
   }
   red[wave][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (wave == 0 && c < ncols) {
-    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += red[w][lane];
     out[c] = accumulate ? out[c] + s : s;
   }
 }

@@ -198,10 +198,10 @@ extern "C" int dl_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
 #undef LN_BWD
   DL_CHECK_LAUNCH("dl_layernorm_bwd");
   if (dgamma)
-    hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(256), 0, s,
+    hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(1024), 0, s,
                        (const float*)workspace, nb, (int64_t)(2 * D), (int)D, dgamma, accumulate);
   if (dbeta)
-    hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(256), 0, s,
+    hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(1024), 0, s,
                        (const float*)workspace + D, nb, (int64_t)(2 * D), (int)D, dbeta, accumulate);
   DL_CHECK_LAUNCH("dl_layernorm_bwd(final)");
   return DL_OK;
