@@ -152,9 +152,17 @@ def main():
         if timing and fam_stats["gemm"][0] > 0:
             n, ms, fl, by = fam_stats["gemm"]
             ach = fl / (ms * 1e-3) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+            if os.path.exists(pmc) and args.batch == 256 and args.dtype == "bf16" and args.model == "DrugLAMP":
+                # HBM bytes per dl_gemm launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+                # workload (tools/pmc_summary.py; x2 gfx950 read correction), committed under profiles/
+                traffic = round(json.load(open(pmc))["families"]["gemm"]["traffic_bytes_per_launch"])
             out["roofline"] = {"kernel": "dl_gemm (all layouts: fwd / dgrad / wgrad)", "bound": "mfma",
                                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": None, "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+                               "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                               "algorithmic_bytes_per_launch": round(by / n),
+                               "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                                "time_share_of_step": round(ms / (dt * 1e3), 3),
                                "algorithmic_hbm_GBps": round(by / (ms * 1e-3) / 1e9, 1)}
             for name in ("attn_fwd", "attn_bwd"):
