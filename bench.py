@@ -81,12 +81,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
+    # DL_DIST_BACKEND=gloo lets the N>1 path be smoke-tested on a 1-GPU box (ranks then share device 0)
+    backend = os.environ.get("DL_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert world == args.gpus, "launch with --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from druglamp_amd import _lib
     from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
@@ -94,8 +101,10 @@ def main():
     from druglamp_amd.synthetic import make_batch
     from druglamp_amd.trainer import Trainer
 
+    from druglamp_amd import ops
     L = _lib.lib()
     torch.manual_seed(1234)                       # identical initial weights on every rank
+    ops.manual_seed(1000 + rank)                  # ... but rank-specific dropout streams
     cfg = load_yaml_into(get_cfg_defaults(), args.model)
     model = MInterface(args.model, cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32

@@ -51,14 +51,6 @@ __global__ void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__
     *reinterpret_cast<f32x4*>(d0) = s0; *reinterpret_cast<f32x4*>(d1) = s1;
   }
 }
-__global__ void bn_final_kernel(const float* __restrict__ partial, int chunks, int C, float* __restrict__ sums) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * C) return;
-  float s = 0.f;
-  for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * 2 * C + i];
-  sums[i] = s;
-}
-
 template <typename T>
 __global__ void bn_apply_fwd_kernel(const T* __restrict__ y, T* __restrict__ z, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,

@@ -685,14 +685,6 @@ __global__ void colsum_partial_kernel(const T* __restrict__ X, int64_t ldx, int6
     for (int j = 0; j < 4 && n + j < N; ++j) dst[j] = s[j];
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int chunks, int N,
-                                    float* __restrict__ out, int accumulate) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += partial[(int64_t)c * N + n];
-  out[n] = accumulate ? out[n] + s : s;
-}
 }  // namespace
 
 extern "C" size_t dl_colsum_workspace_bytes(int64_t M, int64_t N) {

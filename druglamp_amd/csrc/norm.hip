@@ -136,18 +136,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
   }
 }
 
-__global__ void ln_bwd_final_kernel(const float* __restrict__ partial, int nblocks, int D,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                    int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * D) return;
-  const int which = i / D, col = i % D;
-  float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[((int64_t)b * 2 + which) * D + col];
-  float* dst = which == 0 ? dgamma : dbeta;
-  if (!dst) return;
-  dst[col] = accumulate ? dst[col] + s : s;
-}
 }  // namespace
 
 extern "C" int dl_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta,
