@@ -104,6 +104,60 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ 
   store4<T>(dx + i * 4, d);
 }
 
+// ---------------- LLM feature ingest: fill bit + site pooling in ONE pass -------------------------
+// x [B][S][F]; fill[b][s] = (sum_f x[b][s][f] == 0); pooled[b][j][f] = mean_c xcat[b][c*n_site + j][f] for
+// c < site_len, xcat = [x | fill]; pooled is Fp = ceil8(F + 1) wide, zero beyond column F.
+// One wave per (b, j); lane -> 8-element chunks.
+template <typename T, typename TO>
+__global__ void fill_pool_kernel(const T* __restrict__ x, T* __restrict__ fill, TO* __restrict__ pooled, int64_t BJ,
+                                 int n_site, int site_len, int F, int Fp) {
+  const int lane = threadIdx.x & 63;
+  const int64_t bj = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (bj >= BJ) return;
+  const int64_t b = bj / n_site;
+  const int j = (int)(bj % n_site);
+  const int S = n_site * site_len;
+  const int nch = F >> 3;                 // F % 8 == 0
+  float acc[2][8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[q][e] = 0.f;
+  float fillsum = 0.f;
+  for (int c = 0; c < site_len; ++c) {
+    const int srow = c * n_site + j;
+    const T* row = x + ((int64_t)b * S + srow) * F;
+    float rs = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int ch = lane + 64 * q;
+      if (ch < nch) {
+        const f32x4 v0 = load4<T>(row + ch * 8), v1 = load4<T>(row + ch * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[q][e] += v0[e]; acc[q][4 + e] += v1[e]; rs += v0[e] + v1[e]; }
+      }
+    }
+    rs = wave_sum(rs);
+    const float fb = (rs == 0.f) ? 1.f : 0.f;
+    fillsum += fb;
+    if (lane == 0) fill[(int64_t)b * S + srow] = from_f32<T>(fb);
+  }
+  const float inv = 1.0f / (float)site_len;
+  TO* out = pooled + bj * Fp;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int ch = lane + 64 * q;
+    if (ch < nch) {
+      store4<TO>(out + ch * 8, f32x4{acc[q][0] * inv, acc[q][1] * inv, acc[q][2] * inv, acc[q][3] * inv});
+      store4<TO>(out + ch * 8 + 4, f32x4{acc[q][4] * inv, acc[q][5] * inv, acc[q][6] * inv, acc[q][7] * inv});
+    }
+  }
+  if (lane == 0) {
+    out[F] = from_f32<TO>(fillsum * inv);
+    for (int e = F + 1; e < Fp; ++e) out[e] = from_f32<TO>(0.f);
+  }
+}
+
 template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
   const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -248,6 +302,33 @@ extern "C" int dl_dropout_apply(const void* x, void* y, int64_t n_rows, int64_t 
     hipLaunchKernelGGL((dropout_apply_kernel<float>), dim3(nblk(n4)), dim3(256), 0, s, (const float*)x, (float*)y,
                        n_rows, (int)D, ldx, ldy, dl_dropout_thr16(p), 1.0f / (1.0f - p), seed);
   DL_CHECK_LAUNCH("dl_dropout_apply");
+  return DL_OK;
+}
+
+extern "C" int dl_fill_pool(const void* x, void* fill, void* pooled, int64_t B, int64_t S, int64_t F, int32_t site_len,
+                            int32_t in_dtype, int32_t out_dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(x && fill && pooled && B > 0 && S > 0 && F > 0 && site_len > 0, DL_ERR_ARG, "dl_fill_pool: bad args");
+  DL_CHECK_ARG(S % site_len == 0 && F % 8 == 0 && F <= 1024, DL_ERR_SHAPE,
+               "dl_fill_pool: need S %% site_len == 0, F %% 8 == 0, F <= 1024");
+  const int n_site = (int)(S / site_len);
+  const int Fp = (int)((F + 1 + 7) / 8 * 8);
+  const int64_t BJ = B * n_site;
+  const uint32_t blocks = (uint32_t)((BJ + 3) / 4);
+  if (in_dtype == DL_BF16 && out_dtype == DL_BF16)
+    hipLaunchKernelGGL((fill_pool_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)fill,
+                       (bf16_t*)pooled, BJ, n_site, site_len, (int)F, Fp);
+  else if (in_dtype == DL_F32 && out_dtype == DL_F32)
+    hipLaunchKernelGGL((fill_pool_kernel<float, float>), dim3(blocks), dim3(256), 0, s, (const float*)x, (float*)fill,
+                       (float*)pooled, BJ, n_site, site_len, (int)F, Fp);
+  else if (in_dtype == DL_F32 && out_dtype == DL_BF16)
+    hipLaunchKernelGGL((fill_pool_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, s, (const float*)x, (float*)fill,
+                       (bf16_t*)pooled, BJ, n_site, site_len, (int)F, Fp);
+  else if (in_dtype == DL_BF16 && out_dtype == DL_F32)
+    hipLaunchKernelGGL((fill_pool_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)fill,
+                       (float*)pooled, BJ, n_site, site_len, (int)F, Fp);
+  else { dl_set_error("dl_fill_pool: bad dtypes"); return DL_ERR_ARG; }
+  DL_CHECK_LAUNCH("dl_fill_pool");
   return DL_OK;
 }
 

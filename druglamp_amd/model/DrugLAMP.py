@@ -1,6 +1,7 @@
 """DrugLAMP (reference: model/DrugLAMP.py:8-78): forward(vd, vp, xd, xp, mode) -> 5-tuple / 4-tuple."""
 import torch
 
+from .. import ops
 from .basic_model import DrugLAMPBase
 
 
@@ -12,13 +13,16 @@ class DrugLAMP(DrugLAMPBase):
 
     def forward(self, vd, vp, xd, xp, mode="train"):
         vd = self.drug_extractor(vd)
-        fill_p = self._fill_bit(xp)
-        xd = torch.cat((xd, self._fill_bit(xd).unsqueeze(-1)), dim=-1)
-        # the reference concatenates the fill bit onto the (B, 2304, 640) ESM tensor here (DrugLAMP.py:14);
-        # that 641-wide copy is only consumed by the SSL head, so it is handed over as the pair
-        # (embeddings, fill bit) and materialised by SSL.forward on SSL epochs only
-        ssl = {"vp": vp, "xp": (xp, fill_p), "fill_bit_p": fill_p, "vd": vd, "xd": xd}
-        xp = torch.cat((self._site_pool(xp), self._site_pool(fill_p.unsqueeze(-1))), dim=-1)   # (B, 256, 641)
+        # one pass over each LLM tensor: fill bit + (site-pooled) fill-bit-augmented features, already padded
+        # to the GEMM alignment (641 -> 648, 385 -> 392 columns)
+        cdt = self.compute_dtype
+        fill_p, xps = ops.fill_pool(xp, self.site_len, cdt)
+        fill_d, xdp = ops.fill_pool(xd, 1, cdt)
+        # the reference concatenates the fill bits onto the raw tensors here (DrugLAMP.py:11-19); those copies
+        # are only consumed by the SSL head, so they are handed over as (tensor, fill bit) pairs and
+        # materialised by SSL.forward on SSL epochs only
+        ssl = {"vp": vp, "xp": (xp, fill_p), "fill_bit_p": fill_p, "vd": vd, "xd": (xd, fill_d)}
+        xp, xd = xps, xdp
         vpf = self._site_pool(self.protein_extractor(vp, fill_p))
         xpf, xdf = self._llm_adaptors(xp, xd)
         vpf, vdf = vpf.float(), vd.float()

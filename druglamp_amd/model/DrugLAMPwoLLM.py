@@ -1,4 +1,5 @@
 """DrugLAMPwoLLM (reference: model/DrugLAMPwoLLM.py:8-51): no LLM branch; pmma(mv, mv)."""
+from .. import ops
 from .basic_model import DrugLAMPBase
 
 
@@ -8,7 +9,7 @@ class DrugLAMPwoLLM(DrugLAMPBase):
 
     def forward(self, vd, vp, xd, xp, mode="train"):
         vd = self.drug_extractor(vd)
-        fill_p = self._fill_bit(xp)
+        fill_p, _ = ops.fill_pool(xp, self.site_len, self.compute_dtype)
         ssl = {"vp": vp, "xp": None, "fill_bit_p": fill_p, "vd": vd, "xd": None, "p_mode": "vp"}
         vpf = self._site_pool(self.protein_extractor(vp, fill_p))
         vpf, vdf = vpf.float(), vd.float()

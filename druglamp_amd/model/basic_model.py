@@ -276,12 +276,11 @@ class DrugLAMPBase(nn.Module):
         return m, raw
 
     def _llm_adaptors(self, xp_cat, xd_cat):
-        """xp_cat: SITE-POOLED protein LLM features with fill bit (B, 256, 641); xd_cat: (B, 512, 385).
+        """xp_cat: site-pooled protein LLM features + fill bit, zero-padded (B, 256, 648); xd_cat: drug LLM
+        features + fill bit, zero-padded (B, 512, 392) — both straight from ops.fill_pool, compute dtype.
         Protein / drug LLM adaptors (DrugLAMP.py:39-52) on the HIP GEMM path: 641- and 385-wide features
         are zero-padded to 648 / 392 so that every product is an aligned MFMA GEMM."""
-        cdt = self.compute_dtype
-        xps = xp_cat                                                              # site-pooled (B, 256, 641)
-        xps = Fn.cast(F.pad(xps.float(), (0, (-xps.shape[-1]) % 8)), cdt)
+        xps = xp_cat                                   # site-pooled, fill-augmented, padded (B, 256, 648)
         a = self.p_adaptor_wo_skip_connect
         h = Fn.dense(xps, a.lin1.weight, a.lin1.bias, act=True)
         h = Fn.layer_norm(h, a.norm.weight, a.norm.bias, a.norm.eps)
@@ -289,7 +288,7 @@ class DrugLAMPBase(nn.Module):
         h = Fn.dense(t, self.lin_p1.weight, self.lin_p1.bias, act=True)
         h = Fn.layer_norm(h, self.p_norm.weight, self.p_norm.bias, self.p_norm.eps)
         xpf = Fn.dense(h, self.lin_p2.weight, self.lin_p2.bias)
-        xd = Fn.cast(F.pad(xd_cat.float(), (0, (-xd_cat.shape[-1]) % 8)), cdt)
+        xd = xd_cat                                    # fill-augmented, padded (B, 512, 392)
         h = Fn.dense(xd, self.lin_d1.weight, self.lin_d1.bias, act=True)
         h = Fn.layer_norm(h, self.d_norm.weight, self.d_norm.bias, self.d_norm.eps)
         xdf = Fn.dense(h, self.lin_d2.weight, self.lin_d2.bias)

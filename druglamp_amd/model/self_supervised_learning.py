@@ -116,6 +116,8 @@ class SSL(nn.Module):
     def forward(self, vp, xp, fill_bit_p, vd, xd, p_mode="double", mask=None, replace=None):
         if isinstance(xp, (tuple, list)):          # (embeddings (B,S,640), fill bit (B,S)) -> (B,S,641)
             xp = torch.cat((xp[0], xp[1].unsqueeze(-1).to(xp[0].dtype)), dim=-1)
+        if isinstance(xd, (tuple, list)):
+            xd = torch.cat((xd[0], xd[1].unsqueeze(-1).to(xd[0].dtype)), dim=-1)
         prot = self.prot_mlm(vp, self.extractor, xp, fill_bit_p, p_mode, mask=mask, replace=replace)
         if vd is None or xd is None:
             drug = 0

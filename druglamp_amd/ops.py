@@ -364,3 +364,16 @@ def gelu_bwd(dy2d, pre2d):
     check(_lib.lib().dl_gelu_bwd(dy2d.data_ptr(), pre2d.data_ptr(), dx.data_ptr(), dy2d.numel(), _dt(dy2d), _stream()),
           "dl_gelu_bwd")
     return dx
+
+
+def fill_pool(x: torch.Tensor, site_len: int, out_dtype: torch.dtype):
+    """x (B, S, F) -> (fill (B, S) in x.dtype, pooled (B, S // site_len, ceil8(F + 1)) in out_dtype)."""
+    _need_gpu(x)
+    x = x.contiguous()
+    B, S, F = x.shape
+    Fp = (F + 1 + 7) // 8 * 8
+    fill = torch.empty((B, S), dtype=x.dtype, device=x.device)
+    pooled = torch.empty((B, S // site_len, Fp), dtype=out_dtype, device=x.device)
+    check(_lib.lib().dl_fill_pool(x.data_ptr(), fill.data_ptr(), pooled.data_ptr(), B, S, F, site_len, _dt(x),
+                                  _DT[out_dtype], _stream()), "dl_fill_pool")
+    return fill, pooled

@@ -202,6 +202,14 @@ int dl_add_rowmod_dropout(const void* x, const void* pe, void* y, int64_t M, int
 /* y = dropout_mask(seed)(x) / (1-p) — regenerates a forward mask for the backward pass. */
 int dl_dropout_apply(const void* x, void* y, int64_t n_rows, int64_t D, int64_t ldx, int64_t ldy,
                      float p, uint64_t seed, int32_t dtype, dl_stream s);
+/* LLM feature ingest (input side of the path): ONE pass over the pre-extracted embedding tensor
+ * x [B][S][F] produces the reference's fill bit (1 where the embedding row sums to exactly 0,
+ * model/DrugLAMP.py:11-19) and the fill-bit-augmented, site-pooled features
+ * pooled[b][j][:] = mean over the site_len chunks c of [x | fill][b][c*(S/site_len) + j][:]
+ * (DrugLAMP.py:39-40; site_len = 1 just appends the fill bit), zero-padded to ceil8(F+1) columns so that
+ * the adaptor GEMMs are aligned.  fill has x's dtype, pooled has out_dtype. */
+int dl_fill_pool(const void* x, void* fill, void* pooled, int64_t B, int64_t S, int64_t F, int32_t site_len,
+                 int32_t in_dtype, int32_t out_dtype, dl_stream s);
 /* dx = dy * gelu'(pre) (exact-erf GELU): backward of the GELU that sits between a Linear and a LayerNorm in
  * the LLM adaptors (model/basic_model.py:189-193, DrugLAMP.py:46-52). */
 int dl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dtype, dl_stream s);

@@ -130,3 +130,49 @@ def test_flat_params_runs_cpu():
     assert float(flat.grads[:15].sum()) == 15.0 and float(flat.grads[16:23].sum()) == 14.0
     ps[0].data.add_(1.0)                                  # views write through to the arena
     assert torch.equal(flat.arena[:15].view(3, 5), ps[0].detach())
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """Every entry point validates shapes / alignment / workspaces BEFORE launching anything and reports
+    through the status code + dl_last_error(); none of this needs a device."""
+    import ctypes as C
+    from druglamp_amd import _lib
+    L = _lib.lib()
+    buf = (C.c_char * 4096)()
+    p = C.addressof(buf)
+    p16 = (p + 15) // 16 * 16
+    a = _lib.GemmArgs()
+    a.X, a.W, a.C = p16, p16, p16
+    a.M, a.N, a.K = 64, 64, 0                       # bad shape
+    a.ldx = a.ldw = a.ldc = 64
+    assert L.dl_gemm(C.byref(a), None) == -2 and b"bad shape" in L.dl_last_error()
+    a.K = 60                                        # bf16 needs K % 8 == 0
+    a.in_dtype = a.out_dtype = _lib.DL_BF16
+    a.ldx = a.ldw = 64
+    assert L.dl_gemm(C.byref(a), None) == -3
+    a.K = 64
+    a.X = p16 + 2                                   # misaligned operand
+    assert L.dl_gemm(C.byref(a), None) == -3 and b"aligned" in L.dl_last_error()
+    a.X = p16
+    a.split_k, a.out_dtype = 4, _lib.DL_F32         # split-K without workspace
+    assert L.dl_gemm(C.byref(a), None) == -4 and b"workspace" in L.dl_last_error()
+    assert L.dl_gemm_workspace_bytes(C.byref(a)) == 4 * 64 * 64 * 4
+    f = _lib.AttnFwdArgs()
+    f.Q = f.K = f.V = f.O = p16
+    f.n_problems, f.n_heads, f.n_segments, f.Lq, f.Lk, f.head_dim, f.dtype = 1, 1, 1, 16, 16, 48, _lib.DL_BF16
+    assert L.dl_attn_fwd(C.byref(f), None) == -6 and b"head_dim" in L.dl_last_error()
+    f.head_dim, f.q_rs = 64, 3                      # stride not a multiple of 16 bytes
+    assert L.dl_attn_fwd(C.byref(f), None) == -3
+    assert L.dl_layernorm_fwd(p16, 6, p16, p16, p16, 6, None, None, 4, 6, 1e-6, 0, None) == -2
+    assert L.dl_ntxent_fwd(p16, p16, 8, 48, 0.1, p16, p16, p16, 4096, None) == -6
+    assert L.dl_cast(p16, 0, p16, 7, 16, None) == -1
+    assert L.dl_adamw_step(p16, p16, p16, p16, 16, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0, 1.0, None, 0, None) == -1
+
+
+def test_ops_reject_cpu_tensors():
+    from druglamp_amd import ops
+    x = torch.randn(8, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm(x, x, M=8, N=8, K=8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.layernorm_fwd(x, torch.ones(8), torch.zeros(8), 1e-6)

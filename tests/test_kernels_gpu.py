@@ -5,6 +5,7 @@ import importlib.util
 import os
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,3 +25,29 @@ def test_kernel_group(group):
     {"gemm": p.gemm_cases, "ln": p.ln_cases, "attn": p.attn_cases, "misc": p.misc_cases, "loss": p.loss_cases}[group]()
     bad = [r for r in p.RESULTS if not r[3]]
     assert len(p.RESULTS) > 5 and not bad, bad[:5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,odt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                       (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("site_len,S,F", [(9, 2304, 640), (1, 512, 384), (3, 12, 8)])
+def test_fill_pool_matches_reference_formulation(dtype, odt, site_len, S, F):
+    """fill bit + site pooling in one pass == reference DrugLAMP.py:11-19,39-40 (cat fill bit, view, mean)."""
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B = 3
+    x = torch.randn(B, S, F, generator=g)
+    x[0, S // 2:] = 0                      # padded tail -> fill bit 1
+    x[2, 1] = 0
+    x = x.to(dtype).cuda()
+    fill, pooled = ops.fill_pool(x, site_len, odt)
+    xf = x.float()
+    ref_fill = (xf.sum(-1) == 0).float()
+    cat = torch.cat((xf, ref_fill.unsqueeze(-1)), -1)
+    ref = cat.view(B, site_len, S // site_len, F + 1).mean(1)
+    assert torch.equal(fill.float(), ref_fill)
+    Fp = (F + 1 + 7) // 8 * 8
+    assert pooled.shape == (B, S // site_len, Fp) and pooled.dtype == odt
+    tol = 1e-6 if odt == torch.float32 else 8e-3
+    torch.testing.assert_close(pooled[..., :F + 1].float(), ref, rtol=tol, atol=tol)
+    assert torch.count_nonzero(pooled[..., F + 1:]) == 0
