@@ -183,14 +183,76 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+// Packed-math erf for the bf16 pipelines: odd rational minimax on [-4, 4] (|err| <= 4.5e-7 absolute, two
+// orders below bf16 rounding), evaluated two lanes at a time with v_pk_fma_f32; ~1/3 of libm erff's
+// instruction count, which otherwise dominates the fused GELU epilogues of the small-K GEMMs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 bc2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 erf_fast2(f32x2 x) {
+  x = __builtin_elementwise_max(__builtin_elementwise_min(x, bc2(4.f)), bc2(-4.f));
+  const f32x2 x2 = x * x;
+  f32x2 p = fma2(bc2(-2.72614225801306e-10f), x2, bc2(2.77068142495902e-08f));
+  p = fma2(p, x2, bc2(-2.10102402082508e-06f));
+  p = fma2(p, x2, bc2(-5.69250639462346e-05f));
+  p = fma2(p, x2, bc2(-7.34990630326855e-04f));
+  p = fma2(p, x2, bc2(-2.95459980854025e-03f));
+  p = fma2(p, x2, bc2(-1.60960333262415e-02f));
+  f32x2 q = fma2(bc2(-1.45660718464996e-05f), x2, bc2(-2.13374055278905e-04f));
+  q = fma2(q, x2, bc2(-1.68282697438203e-03f));
+  q = fma2(q, x2, bc2(-7.37332916720468e-03f));
+  q = fma2(q, x2, bc2(-1.42647390514189e-02f));
+  const f32x2 r = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
+  return x * p * r;
+}
+// 4-wide GELU / GELU' keyed on the pipeline's storage type: fp32 pipelines keep libm erff (parity runs),
+// bf16 pipelines take the packed rational form.
+template <typename T> __device__ __forceinline__ f32x4 gelu4(f32x4 v) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    return v;
+  } else {
+    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    const f32x2 ga = bc2(0.5f) * a * (bc2(1.f) + erf_fast2(a * bc2(0.70710678118654752440f)));
+    const f32x2 gb = bc2(0.5f) * b * (bc2(1.f) + erf_fast2(b * bc2(0.70710678118654752440f)));
+    return f32x4{ga[0], ga[1], gb[0], gb[1]};
+  }
+}
+template <typename T> __device__ __forceinline__ f32x4 gelu_grad4(f32x4 v) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_grad(v[e]);
+    return v;
+  } else {
+    f32x4 o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x2 a = {v[2 * h], v[2 * h + 1]};
+      const f32x2 cdf = fma2(bc2(0.5f), erf_fast2(a * bc2(0.70710678118654752440f)), bc2(0.5f));
+      const f32x2 t = a * a * bc2(-0.5f * 1.44269504088896340736f);
+      const f32x2 pdf = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} * bc2(0.39894228040143267794f);
+      const f32x2 g = fma2(a, pdf, cdf);
+      o[2 * h] = g[0]; o[2 * h + 1] = g[1];
+    }
+    return o;
+  }
+}
 
-// ---- dropout RNG: splitmix64 keyed by (seed, group index); one draw serves 4 consecutive
-// elements (16 bits each).  keep[j] = bits16[j] >= thr16 with thr16 = round(p * 65536).
+// ---- dropout RNG: counter hash keyed by (seed, group index); one draw of 64 bits serves 4 consecutive
+// elements (16 bits each).  keep[j] = bits16[j] >= thr16 with thr16 = round(p * 65536).  Two murmur3
+// finalisers on decorrelated 32-bit keys (4 integer multiplies per 4 elements); the mask is regenerated
+// from the same (seed, index) in backward, never stored.
+__device__ __forceinline__ uint32_t dl_fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
 __device__ __forceinline__ uint64_t dl_splitmix(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
+  const uint32_t x = (uint32_t)idx + (uint32_t)seed;
+  const uint32_t hi = (uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32);
+  const uint32_t a = dl_fmix32(x ^ hi);
+  const uint32_t b = dl_fmix32((x + 0x9E3779B9u) ^ __builtin_rotateleft32(hi, 13) ^ 0x7F4A7C15u);
+  return ((uint64_t)a << 32) | b;
 }
 __host__ __device__ __forceinline__ uint32_t dl_dropout_thr16(float p) {
   float t = p * 65536.0f + 0.5f;

@@ -100,7 +100,7 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ 
   f32x4 d = load4<T>(dy + i * 4);
   const f32x4 q = load4<T>(pre + i * 4);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) d[e] *= gelu_erf_grad(q[e]);
+  for (int e = 0; e < 4; ++e) d[e] *= gelu_erf_grad(q[e]);  // standalone kernel is HBM-bound: exact form
   store4<T>(dx + i * 4, d);
 }
 

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   u32x4 rx[TW], rw[TW];
   uint32_t it = blockIdx.x;
   if (it >= ntiles) return;
-  if ((p.dbg & 4) && (blockIdx.x & 8)) { for (int z = 0; z < (p.dbg >> 4); ++z) __builtin_amdgcn_s_sleep(127); }
+  if ((p.dbg & 4) && (blockIdx.x >= gridDim.x / 2)) { for (int z = 0; z < (p.dbg >> 4); ++z) __builtin_amdgcn_s_sleep(127); }
   int split, m0, n0, kbeg, kend;
   locate(it, split, m0, n0, kbeg, kend);
   if constexpr (!XD) load_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg, kend, rx);
@@ -290,16 +290,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
       if constexpr (EPI == 2) {
         T* pd = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
         store4<T>(pd, a0); store4<T>(pd + 4, a1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { a0[r] = gelu_erf(a0[r]); a1[r] = gelu_erf(a1[r]); }
+        a0 = gelu4<T>(a0); a1 = gelu4<T>(a1);
       } else if constexpr (EPI == 5) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.f); a1[r] = fmaxf(a1[r], 0.f); }
       } else if constexpr (EPI == 4) {
         const T* src = reinterpret_cast<const T*>(p.dact_pre) + (int64_t)m * p.lddp + n;
         const f32x4 q0 = load4<T>(src), q1 = load4<T>(src + 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { a0[r] *= gelu_erf_grad(q0[r]); a1[r] *= gelu_erf_grad(q1[r]); }
+        a0 *= gelu_grad4<T>(q0); a1 *= gelu_grad4<T>(q1);
       }
       if (EPI != 5 && p.drop_thr16) {
         a0 = dl_dropout4(a0, p.seed, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
@@ -426,6 +424,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   }
 }
 
+#include "gemm_big.cuh"
+
 // out[idx] (+)= sum_z slabs[z][idx]
 template <typename TO>
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, TO* __restrict__ out,
@@ -480,10 +480,10 @@ int resolve_split(const dl_gemm_args* a) {
   return plain ? auto_split(a->M, a->N, a->K, bke, 32 * pick_tw(a)) : 1;
 }
 
-template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA>
-void launch(const GemmP& p, hipStream_t s, int tw) {
+// specialised epilogue id (see gemm_kernel), 1 = general
+int pick_epi(const GemmP& p, bool split) {
   int epi = 1;
-  if (!SPLIT && (p.N % 8 == 0) && !p.accumulate && p.res_row_mod == 0 && !(p.res && p.res_before_dropout)) {
+  if (!split && (p.N % 8 == 0) && !p.accumulate && p.res_row_mod == 0 && !(p.res && p.res_before_dropout)) {
     const bool drop = p.drop_thr16 != 0;
     if (!p.res && !p.act && !p.pre_out && !p.dact_pre && !drop) epi = 0;
     else if (p.act == 1 && p.pre_out && !p.res && !p.dact_pre) epi = 2;
@@ -491,6 +491,40 @@ void launch(const GemmP& p, hipStream_t s, int tw) {
     else if (p.dact_pre && !p.res && !p.act && !p.pre_out && !p.bias) epi = 4;
     else if (p.act == 2 && !p.res && !p.pre_out && !p.dact_pre && !drop) epi = 5;
   }
+  return epi;
+}
+
+// Large-tile path (gemm_big.cuh): bf16 in/out, both operands K-contiguous, specialised epilogue, whole k-steps,
+// N wide enough for a 256-column tile and enough tiles to give every CU one.  Measured against the
+// alternatives the template allows (64-byte rows x 4 stages; 256x128 tiles, two workgroups per CU) the
+// 128-byte x 2-stage 256x256 form won on every shape of the path; narrow outputs (N <= 128) stay on
+// gemm_kernel.  DL_GEMM_BIG=0 disables the path (tile studies).
+bool big_eligible(const dl_gemm_args* a, const GemmP& p, int sp) {
+  const char* e = getenv("DL_GEMM_BIG");
+  if (e && atoi(e) == 0) return false;
+  if (sp > 1 || a->in_dtype != DL_BF16 || a->out_dtype != DL_BF16 || a->x_kslow || a->w_kslow) return false;
+  if (pick_epi(p, false) == 1) return false;
+  if (a->K % 64 != 0 || a->N <= 128) return false;
+  const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+  return tiles >= 192;
+}
+void launch_big(const GemmP& p, hipStream_t s) {
+  const uint32_t ntiles = (uint32_t)p.mt * p.nt;
+  const uint32_t nblocks = ntiles < 256u ? ntiles : 256u;       // one 128 KB workgroup per CU
+#define DL_BIG(E) hipLaunchKernelGGL((gemm_big_kernel<8, 2, 4, 128, 2, E>), dim3(nblocks), dim3(512), 0, s, p)
+  switch (pick_epi(p, false)) {
+    case 0: DL_BIG(0); break;
+    case 2: DL_BIG(2); break;
+    case 3: DL_BIG(3); break;
+    case 4: DL_BIG(4); break;
+    default: DL_BIG(5); break;
+  }
+#undef DL_BIG
+}
+
+template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA>
+void launch(const GemmP& p, hipStream_t s, int tw) {
+  const int epi = pick_epi(p, SPLIT);
   const uint32_t ntiles = (uint32_t)p.mt * p.nt * p.splits;
   const uint32_t nblocks = ntiles < 512u ? ntiles : 512u;      // 256 CUs x 2 resident workgroups (LDS-limited)
 #define DL_LAUNCH(E) hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT, DMA, E, 4>), dim3(nblocks), dim3(NTHREADS), 0, s, p)
@@ -615,7 +649,10 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
 
   dl_prof_before(0, s);
   int rc = DL_OK;
-  if (a->in_dtype == DL_BF16) {
+  if (big_eligible(a, p, sp)) {
+    p.mt = (int)((a->M + 255) / 256); p.nt = (int)((a->N + 255) / 256);
+    launch_big(p, s);
+  } else if (a->in_dtype == DL_BF16) {
     if (sp > 1) rc = dispatch_layout<bf16_t, float, true>(a, p, s, tw);
     else if (a->out_dtype == DL_F32) rc = dispatch_layout<bf16_t, float, false>(a, p, s, tw);
     else rc = dispatch_layout<bf16_t, bf16_t, false>(a, p, s, tw);

@@ -1,0 +1,214 @@
+// gemm_big.cuh — large-tile bf16 GEMM for the forward / data-gradient shapes of the path (both operands
+// K-contiguous, M in the tens of thousands, K a few hundred to a few thousand).  Included by gemm.hip.
+//
+// Why a second kernel: at 128x128 the operand stream from L2 (64 FLOP per byte) caps the main loop near
+// 800 TFLOP/s; a 256x256 tile halves that traffic (128 FLOP/B) and a wave tile of 128x64 lowers the LDS
+// fragment traffic per MFMA by a quarter.
+//
+//   workgroup : 512 threads = 8 waves; 256(m) x 256(n) tile as 2 x 4 waves of 128 x 64, or 256 x 128 as 4 x 2
+//               waves of 64 x 64 (narrow outputs).  One workgroup per CU (LDS-limited), persistent over
+//               the tile list with the same XCD-aware order as gemm_kernel.
+//   pipeline  : NSTAGE LDS buffers of [BM + BN rows][ROWB bytes] filled by LDS-DMA (global_load_lds,
+//               source-side XOR swizzle), prefetch distance NSTAGE-1 k-steps, ONE s_barrier per k-step and
+//               counted s_waitcnt vmcnt(n) so that later stages stay in flight across the barrier.
+//   epilogue  : the first stages of the NEXT tile are requested before the epilogue; accumulators go
+//               through a 4 KB (or 2 KB) wave-private, XOR-swizzled fp32 slice of the stage buffer that was consumed
+//               last (no workgroup barrier inside the epilogue) and leave as 16-byte stores, 8 lanes per
+//               128-byte line.
+#pragma once
+
+template <int EPI>
+__device__ __forceinline__ void big_epilogue8(const GemmP& p, int m, int n, f32x4 a0, f32x4 a1) {
+  typedef bf16_t T;
+  if (EPI != 4 && p.bias) {
+    a0 += *reinterpret_cast<const f32x4*>(p.bias + n);
+    a1 += *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+  }
+  if constexpr (EPI == 2) {
+    T* pd = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
+    u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
+    *reinterpret_cast<u32x4*>(pd) = o;
+    a0 = gelu4<T>(a0); a1 = gelu4<T>(a1);
+  } else if constexpr (EPI == 5) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.f); a1[r] = fmaxf(a1[r], 0.f); }
+  } else if constexpr (EPI == 4) {
+    const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.dact_pre) + (int64_t)m * p.lddp + n);
+    a0 *= gelu_grad4<T>(f32x4{bf16lo(q[0]), bf16hi(q[0]), bf16lo(q[1]), bf16hi(q[1])});
+    a1 *= gelu_grad4<T>(f32x4{bf16lo(q[2]), bf16hi(q[2]), bf16lo(q[3]), bf16hi(q[3])});
+  }
+  if (EPI != 5 && EPI != 0 && p.drop_thr16) {
+    a0 = dl_dropout4(a0, p.seed, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+    a1 = dl_dropout4(a1, p.seed, (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+  }
+  if constexpr (EPI == 3) {
+    const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n);
+    a0 += f32x4{bf16lo(q[0]), bf16hi(q[0]), bf16lo(q[1]), bf16hi(q[1])};
+    a1 += f32x4{bf16lo(q[2]), bf16hi(q[2]), bf16lo(q[3]), bf16hi(q[3])};
+  }
+  u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
+  *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n) = o;
+}
+
+// own DMA of the awaited step has landed (counted: younger steps stay in flight) and own LDS reads retired
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+// wave-level ordering point for cross-lane traffic through LDS (no instruction: the LDS queue is in order)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// XF / WF: MFMA 16x16 tiles per wave along m / n (WF is fixed at 4: 64 columns per wave, see the epilogue);
+// NWM x NWN waves; ROWB: bytes of contraction per operand row per k-step (128 or 64); NSTAGE LDS buffers.
+template <int XF, int NWM, int NWN, int ROWB, int NSTAGE, int EPI>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_kernel(const GemmP p) {
+  typedef bf16_t T;
+  constexpr int WF = 4;
+  constexpr int NT = 64 * NWM * NWN, BM = 16 * XF * NWM, BN = 16 * WF * NWN;
+  constexpr int KCH = ROWB / 16, NKF = ROWB / 64, BKE = ROWB / 2;
+  constexpr int XB = BM * ROWB, WB = BN * ROWB, STAGE = XB + WB;
+  constexpr int XCH = BM * KCH / NT, WCH = BN * KCH / NT, PER = XCH + WCH;
+  constexpr int D = NSTAGE - 1;
+  static_assert(BM * KCH % NT == 0 && BN * KCH % NT == 0, "whole DMA instructions per thread");
+  constexpr int SR = (STAGE >= 4096 * NWM * NWN) ? 16 : 8;     // rows per epilogue staging pass
+  static_assert(STAGE >= SR * 256 * NWM * NWN, "epilogue slices must fit one stage buffer");
+  static_assert(D >= 1 && D <= 3 && PER * D < 64, "prefetch distance");
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 15, g = lane >> 4;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int swz = (ROWB == 128) ? (il & 7) : ((il >> 1) & 3);
+  const int xoff = (wm * 16 * XF + il) * ROWB, woff = XB + (wn * 16 * WF + il) * ROWB;
+
+  const uint32_t ntiles = (uint32_t)p.mt * p.nt;
+  const uint32_t G = gridDim.x;
+  auto locate = [&](uint32_t it, int& m0, int& n0) {
+    const uint32_t round0 = (it / G) * G;
+    const uint32_t span = min(G, ntiles - round0);
+    const uint32_t t = round0 + xcd_remap(it - round0, span);
+    m0 = (int)(t / p.nt) * BM; n0 = (int)(t % p.nt) * BN;
+  };
+  const char* xs[XCH];
+  const char* ws[WCH];
+  auto point = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const int c = tid + i * NT, row = c / KCH, pc = c % KCH;
+      const int kc = pc ^ ((ROWB == 128) ? (row & 7) : ((row >> 1) & 3));
+      int gr = m0 + row; gr = gr < p.M ? gr : p.M - 1;
+      xs[i] = p.X + ((int64_t)gr * p.ldx) * 2 + kc * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int c = tid + i * NT, row = c / KCH, pc = c % KCH;
+      const int kc = pc ^ ((ROWB == 128) ? (row & 7) : ((row >> 1) & 3));
+      int gr = n0 + row; gr = gr < p.N ? gr : p.N - 1;
+      ws[i] = p.W + ((int64_t)gr * p.ldw) * 2 + kc * 16;
+    }
+  };
+  auto issue = [&](int kt, uint32_t buf) {
+    char* xb = smem + buf * STAGE;
+    const int64_t kb = (int64_t)kt * ROWB;
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((wave * 64 + i * NT) * 16));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs[i] + kb),
+                                       (__attribute__((address_space(3))) void*)(xb + off), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)(XB + (wave * 64 + i * NT) * 16));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws[i] + kb),
+                                       (__attribute__((address_space(3))) void*)(xb + off), 16, 0, 0);
+    }
+  };
+
+  const int nk = p.K / BKE;            // whole steps (checked by the host)
+  uint32_t it = blockIdx.x;
+  if (it >= ntiles) return;
+  int m0, n0;
+  locate(it, m0, n0);
+  point(m0, n0);
+  uint32_t gs = 0;                     // global step counter: stage buffer = gs % NSTAGE
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < nk) issue(s, (gs + s) % NSTAGE);
+
+  for (;;) {
+    f32x4 acc[XF][WF];
+#pragma unroll
+    for (int i = 0; i < XF; ++i)
+#pragma unroll
+      for (int j = 0; j < WF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      // step kt has landed once at most `later` younger steps' DMA instructions are outstanding
+      const int later = (kt == 0) ? 0 : min(D - 1, nk - 1 - kt);
+      if (later <= 0) wait_vmcnt<0>();
+      else if (later == 1) wait_vmcnt<PER>();
+      else wait_vmcnt<(D >= 3 ? 2 * PER : PER)>();
+      wg_barrier();
+      // every wave is past step kt-1: its buffer takes step kt+D
+      if (kt + D < nk) issue(kt + D, (gs + D) % NSTAGE);
+      const char* cur = smem + (gs % NSTAGE) * STAGE;
+#pragma unroll
+      for (int kf = 0; kf < NKF; ++kf) {
+        const int ch = ((kf * 4 + g) ^ swz) << 4;
+        u32x4 fx[XF], fw[WF];
+#pragma unroll
+        for (int i = 0; i < XF; ++i) fx[i] = lds_read16(cur, xoff + i * 16 * ROWB + ch);
+#pragma unroll
+        for (int j = 0; j < WF; ++j) fw[j] = lds_read16(cur, woff + j * 16 * ROWB + ch);
+#pragma unroll
+        for (int i = 0; i < XF; ++i)
+#pragma unroll
+          for (int j = 0; j < WF; ++j) acc[i][j] = Mma<T>::mma(fw[j], fx[i], acc[i][j]);
+      }
+      ++gs;
+    }
+
+    // ---- tile end: request the next tile's first stages, then the epilogue --------------------
+    const int cm0 = m0, cn0 = n0;
+    const uint32_t itn = it + G;
+    const bool have_next = itn < ntiles;
+    if (have_next) {
+      locate(itn, m0, n0);
+      point(m0, n0);
+#pragma unroll
+      for (int s = 0; s < D; ++s)
+        if (s < nk) issue(s, (gs + s) % NSTAGE);   // every buffer but the one consumed last is free
+    }
+    wg_barrier();                                   // all waves are done reading the last stage buffer
+    char* st = smem + ((gs + NSTAGE - 1) % NSTAGE) * STAGE + wave * (SR * 256);
+#pragma unroll
+    for (int i = 0; i < XF; ++i) {
+#pragma unroll
+      for (int hp = 0; hp < 16 / SR; ++hp) {
+        if (SR == 16 || (il >> 3) == hp) {
+          const int wr = il & (SR - 1);
+#pragma unroll
+          for (int j = 0; j < WF; ++j) lds_write16(st, wr * 256 + (((j * 4 + g) ^ wr) << 4), __builtin_bit_cast(u32x4, acc[i][j]));
+        }
+        // lanes exchange rows through the slice: keep the reads out of the (possibly divergent) write region
+        wave_sync();
+#pragma unroll
+        for (int h = 0; h < SR / 8; ++h) {
+          const int r = (lane >> 3) + 8 * h, c8 = lane & 7;
+          const f32x4 a0 = __builtin_bit_cast(f32x4, lds_read16(st, r * 256 + (((2 * c8) ^ r) << 4)));
+          const f32x4 a1 = __builtin_bit_cast(f32x4, lds_read16(st, r * 256 + (((2 * c8 + 1) ^ r) << 4)));
+          const int m = cm0 + wm * 16 * XF + i * 16 + hp * SR + r, n = cn0 + wn * 16 * WF + c8 * 8;
+          if (m < p.M && n < p.N && !(p.dbg & 1)) big_epilogue8<EPI>(p, m, n, a0, a1);
+        }
+        wave_sync();
+      }
+    }
+    if (!have_next) break;
+    it = itn;
+  }
+}

@@ -51,3 +51,46 @@ def test_fill_pool_matches_reference_formulation(dtype, odt, site_len, S, F):
     tol = 1e-6 if odt == torch.float32 else 8e-3
     torch.testing.assert_close(pooled[..., :F + 1].float(), ref, rtol=tol, atol=tol)
     assert torch.count_nonzero(pooled[..., F + 1:]) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(49152, 512, 256), (49000, 520, 192)])
+def test_large_tile_gemm_is_bitwise_equal_to_the_128_tile_path(M, N, K, monkeypatch):
+    """The 256x256 persistent kernel (gemm_big.cuh) and gemm_kernel accumulate every output element in the same
+    k order and share epilogue math and dropout counters: outputs must be identical bit for bit, for every
+    specialised epilogue, including ragged M / N edges."""
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(11)
+    dt = torch.bfloat16
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dt).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.1).to(dt).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to(dt).cuda()
+    pre_in = torch.randn(M, N, generator=g).to(dt).cuda()
+    cases = {
+        "plain": dict(), "bias": dict(bias=b), "relu": dict(bias=b, act=2),
+        "gelu+pre+drop": dict(bias=b, act=1, pre_out=True, dropout_p=0.1, seed=5),
+        "dgelu+drop": dict(dact_pre=pre_in, dropout_p=0.1, seed=5),
+        "res+drop": dict(bias=b, residual=res, dropout_p=0.1, seed=7),
+    }
+    for name, kw in cases.items():
+        got = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("DL_GEMM_BIG", mode)
+            k2 = dict(kw)
+            pre = None
+            if k2.get("pre_out"):
+                pre = torch.zeros(M, N, device="cuda", dtype=dt)
+                k2["pre_out"] = pre
+            out = torch.full((M, N), 7.0, device="cuda", dtype=dt)
+            ops.gemm(x, w, M=M, N=N, K=K, out=out, **k2)
+            torch.cuda.synchronize()
+            got[mode] = (out, pre)
+        assert torch.equal(got["0"][0], got["1"][0]), name
+        if got["0"][1] is not None:
+            assert torch.equal(got["0"][1], got["1"][1]), name
+    # and against an fp64 reference for the plain case
+    ref = x[:512].double() @ w.double().t()
+    monkeypatch.setenv("DL_GEMM_BIG", "1")
+    out = ops.gemm(x, w, M=M, N=N, K=K)
+    assert (out[:512].double() - ref).abs().max() <= 2e-2 * ref.abs().max()

@@ -1,0 +1,63 @@
+"""Per-shape GEMM table for one training step: wraps ops.gemm with HIP-event timing (serialised) and
+aggregates by (M, N, K, layout, epilogue).  usage: python tools/gemm_shapes.py [--batch 256]"""
+import argparse
+import os
+import sys
+from collections import defaultdict
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from druglamp_amd import ops  # noqa: E402
+from druglamp_amd.configs import get_cfg_defaults, load_yaml_into  # noqa: E402
+from druglamp_amd.model import MInterface  # noqa: E402
+from druglamp_amd.synthetic import make_batch  # noqa: E402
+from druglamp_amd.trainer import Trainer  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=256)
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP")
+model = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
+trainer = Trainer(model, cfg, device=dev, compute_dtype=torch.bfloat16)
+batch, meta = make_batch(args.batch, dev, seed=100, with_graph=True, llm_dtype=torch.bfloat16)
+for _ in range(3):
+    trainer.training_step(batch, meta=meta, cur_epoch=1)
+torch.cuda.synchronize()
+
+recs = []
+orig = ops.gemm
+
+
+def timed(x, w, **kw):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = orig(x, w, **kw)
+    b.record()
+    epi = ("b" if kw.get("bias") is not None else "") + ("r" if kw.get("residual") is not None else "") + \
+          ("g" if kw.get("act") else "") + ("p" if kw.get("pre_out") is not None else "") + \
+          ("G" if kw.get("dact_pre") is not None else "") + ("d" if kw.get("dropout_p", 0) > 0 else "") + \
+          ("+" if kw.get("accumulate") else "")
+    lay = ("T" if kw.get("x_kslow") else "N") + ("T" if kw.get("w_kslow") else "N")
+    recs.append(((kw["M"], kw["N"], kw["K"], lay, epi, str(out.dtype)[6:]), a, b))
+    return out
+
+
+ops.gemm = timed
+import druglamp_amd.functional as Fn  # noqa: E402
+if hasattr(Fn, "ops"):
+    Fn.ops.gemm = timed
+trainer.training_step(batch, meta=meta, cur_epoch=1)
+torch.cuda.synchronize()
+agg = defaultdict(lambda: [0.0, 0])
+for key, a, b in recs:
+    agg[key][0] += a.elapsed_time(b)
+    agg[key][1] += 1
+tot = sum(v[0] for v in agg.values())
+print("total gemm %.2f ms in %d calls" % (tot, len(recs)))
+print("%9s %6s %8s %3s %-6s %-8s %4s %9s %8s %7s" % ("M", "N", "K", "lay", "epi", "out", "n", "us/call", "TF/s", "ms"))
+for key, (ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    M, N, K, lay, epi, od = key
+    tf = 2.0 * M * N * K * n / (ms * 1e-3) / 1e12
+    print("%9d %6d %8d %3s %-6s %-8s %4d %9.1f %8.1f %7.3f" % (M, N, K, lay, epi, od, n, ms / n * 1e3, tf, ms))
