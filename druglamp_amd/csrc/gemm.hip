@@ -470,7 +470,9 @@ int auto_split(int64_t M, int64_t N, int64_t K, int bke, int bt) {
   return (int)(want < 1 ? 1 : want);
 }
 
+int big_tt_plan(const dl_gemm_args* a, int* bm_out);
 int resolve_split(const dl_gemm_args* a) {
+  { const int sp = big_tt_plan(a, nullptr); if (sp > 0) return sp; }
   const int bke = BKB / (int)dl_dtype_size(a->in_dtype);
   if (a->split_k > 0) return a->split_k;
   if (a->split_k < 0) return 1;
@@ -520,6 +522,35 @@ void launch_big(const GemmP& p, hipStream_t s) {
     default: DL_BIG(5); break;
   }
 #undef DL_BIG
+}
+
+// Large-tile weight-gradient path (gemm_big_tt_kernel): bf16 operands, both K-slow, plain fp32 output through
+// split-K slabs.  Returns the slab count (0 = not eligible); *bm_out is the tile height (256 or 128).
+int big_tt_plan(const dl_gemm_args* a, int* bm_out) {
+  const char* e = getenv("DL_GEMM_BIG");
+  if (e && atoi(e) == 0) return 0;
+  if (a->in_dtype != DL_BF16 || !a->x_kslow || !a->w_kslow || a->split_k != 0) return 0;
+  const bool plain = !a->bias && !a->residual && !a->act && !a->pre_out && !a->dact_pre && a->dropout_p <= 0.f;
+  if (!plain || a->M % 8 != 0 || a->N % 8 != 0 || a->N < 192 || a->M < 96 || a->K < 4096) return 0;
+  const int bm = a->M > 128 ? 256 : 128;
+  const int64_t tiles = ((a->M + bm - 1) / bm) * ((a->N + 255) / 256);
+  if (tiles > 256) return 0;
+  // One round of 256 workgroups writes 256 fp32 tiles of slabs (67 MB at 256x256) whatever the problem, so the
+  // large tile only pays when the operand stream dwarfs that: measured win for 1536x512x65536 (244 -> 155 us) and
+  // the 128 x {768, 1152} x 591864 conv gradients (293 -> 260, 443 -> 368 us); break-even or worse below.
+  if (bm == 256 ? (a->M * a->N < 640 * 1024) : (a->N < 640 || a->K < 262144)) return 0;
+  int64_t sp = 256 / tiles;                          // one round of at most 256 workgroups
+  const int64_t ksteps = (a->K + 63) / 64;
+  if (sp > ksteps / 4) sp = ksteps / 4;
+  if (sp < 1) sp = 1;
+  if (bm_out) *bm_out = bm;
+  return (int)sp;
+}
+void launch_big_tt(const GemmP& p, hipStream_t s, int bm) {
+  const uint32_t ntiles = (uint32_t)p.mt * p.nt * p.splits;
+  const uint32_t nblocks = ntiles < 256u ? ntiles : 256u;
+  if (bm == 256) hipLaunchKernelGGL((gemm_big_tt_kernel<8, 2, 4>), dim3(nblocks), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((gemm_big_tt_kernel<4, 2, 4>), dim3(nblocks), dim3(512), 0, s, p);
 }
 
 template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA>
@@ -572,6 +603,7 @@ int dispatch_layout(const dl_gemm_args* a, const GemmP& p, hipStream_t s, int tw
 extern "C" size_t dl_gemm_workspace_bytes(const dl_gemm_args* a) {
   if (!a) return 0;
   const int sp = resolve_split(a);
+  if (big_tt_plan(a, nullptr) > 0) return (size_t)sp * (size_t)a->M * (size_t)a->N * sizeof(float);
   return sp > 1 ? (size_t)sp * (size_t)a->M * (size_t)a->N * sizeof(float) : 0;
 }
 
@@ -612,7 +644,9 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   DL_CHECK_ARG(a->dropout_p == 0.f || a->N % 8 == 0, DL_ERR_SHAPE, "dl_gemm: dropout needs N %% 8 == 0");
 
   const int sp = resolve_split(a);
-  if (sp > 1) {
+  int tt_bm = 0;
+  const bool big_tt = big_tt_plan(a, &tt_bm) > 0;
+  if (sp > 1 || big_tt) {
     DL_CHECK_ARG(!a->bias && !a->residual && !a->act && !a->pre_out && !a->dact_pre &&
                      a->dropout_p == 0.f && (a->N % 4 == 0),
                  DL_ERR_UNSUPPORTED, "dl_gemm: split_k supports only the plain epilogue, N %% 4 == 0");
@@ -649,7 +683,12 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
 
   dl_prof_before(0, s);
   int rc = DL_OK;
-  if (big_eligible(a, p, sp)) {
+  if (big_tt) {
+    p.mt = (int)((a->M + tt_bm - 1) / tt_bm); p.nt = (int)((a->N + 255) / 256);
+    const int64_t ksteps = (a->K + 63) / 64;
+    p.k_per_split = (int)(((ksteps + sp - 1) / sp) * 64);
+    launch_big_tt(p, s, tt_bm);
+  } else if (big_eligible(a, p, sp)) {
     p.mt = (int)((a->M + 255) / 256); p.nt = (int)((a->N + 255) / 256);
     launch_big(p, s);
   } else if (a->in_dtype == DL_BF16) {
@@ -668,7 +707,7 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
     const double bytes = ((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * oes;
     dl_prof_after(0, s, flops, bytes);
   }
-  if (sp > 1) {
+  if (sp > 1 || big_tt) {
     const int64_t mn = a->M * a->N;
     const int threads = 256;
     const int64_t blocks = (mn / 4 + threads - 1) / threads;

@@ -157,18 +157,29 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_kernel(const GemmP
       // every wave is past step kt-1: its buffer takes step kt+D
       if (kt + D < nk) issue(kt + D, (gs + D) % NSTAGE);
       const char* cur = smem + (gs % NSTAGE) * STAGE;
+      // Software-pipelined fragment stream: item u = (kf, i) needs X fragment fx[u] and the four W fragments of
+      // its kf.  X fragments are read two items ahead, the next kf's W fragments during the last four items of kf 0,
+      // and sched_group_barrier pins "reads of this item, then its 4 MFMAs" so that LDS latency hides under
+      // the matrix pipe instead of in front of it.
+      constexpr int U = NKF * XF;
+      auto rd_fx = [&](int u) { return lds_read16(cur, xoff + (u % XF) * 16 * ROWB + ((((u / XF) * 4 + g) ^ swz) << 4)); };
+      auto rd_fw = [&](int kf, int j) { return lds_read16(cur, woff + j * 16 * ROWB + (((kf * 4 + g) ^ swz) << 4)); };
+      u32x4 fx[U], fw[NKF][WF];
 #pragma unroll
-      for (int kf = 0; kf < NKF; ++kf) {
-        const int ch = ((kf * 4 + g) ^ swz) << 4;
-        u32x4 fx[XF], fw[WF];
+      for (int j = 0; j < WF; ++j) fw[0][j] = rd_fw(0, j);
+      fx[0] = rd_fx(0);
+      fx[1] = rd_fx(1);
+      __builtin_amdgcn_sched_group_barrier(0x100, WF + 2, 0);
 #pragma unroll
-        for (int i = 0; i < XF; ++i) fx[i] = lds_read16(cur, xoff + i * 16 * ROWB + ch);
+      for (int u = 0; u < U; ++u) {
+        int nread = 0;
+        if (u + 2 < U) { fx[u + 2] = rd_fx(u + 2); ++nread; }
+        if (NKF == 2 && u >= XF - WF && u < XF) { fw[1][u - (XF - WF)] = rd_fw(1, u - (XF - WF)); ++nread; }
 #pragma unroll
-        for (int j = 0; j < WF; ++j) fw[j] = lds_read16(cur, woff + j * 16 * ROWB + ch);
-#pragma unroll
-        for (int i = 0; i < XF; ++i)
-#pragma unroll
-          for (int j = 0; j < WF; ++j) acc[i][j] = Mma<T>::mma(fw[j], fx[i], acc[i][j]);
+        for (int j = 0; j < WF; ++j) acc[u % XF][j] = Mma<T>::mma(fw[u / XF][j], fx[u], acc[u % XF][j]);
+        if (nread == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        else if (nread == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, WF, 0);
       }
       ++gs;
     }
@@ -207,6 +218,175 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_kernel(const GemmP
         }
         wave_sync();
       }
+    }
+    if (!have_next) break;
+    it = itn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight-gradient form: C[m][n] = sum_k X[k][m] W[k][n], both operands K-SLOW (rows of dY and of the layer
+// input), tens of thousands of k-rows, a small output.  Same 8-wave large tile and LDS-DMA ring as above;
+// operand tiles are [64 k-rows][BM or BN columns] with the 16-byte chunks of a k-row XOR-swizzled by
+// swz(k) = (k & 3) | ((k >> 3) & 3) << 2 so that the 16 k-rows one ds_read_b64_tr_b16 touches land on 16
+// different chunk columns.  The K range is cut into `splits` slabs (fp32 partial outputs, reduced by
+// splitk_reduce_kernel in a fixed order); k-rows past the end of a slab's range are fed from a zero page,
+// so K needs no alignment.
+__device__ __attribute__((aligned(16))) const uint32_t dl_zero_page[4] = {0u, 0u, 0u, 0u};
+
+template <int XF, int NWM, int NWN>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const GemmP p) {
+  typedef bf16_t T;
+  constexpr int WF = 4, KS = 64, NSTAGE = 2;
+  constexpr int NT = 64 * NWM * NWN, BM = 16 * XF * NWM, BN = 16 * WF * NWN;
+  constexpr int PX = BM * 2, PW = BN * 2;                    // bytes per k-row
+  constexpr int CPX = PX / 16, CPW = PW / 16;                // 16-byte chunks per k-row
+  constexpr int XB = KS * PX, WB = KS * PW, STAGE = XB + WB;
+  constexpr int XCH = KS * CPX / NT, WCH = KS * CPW / NT;
+  static_assert(KS * CPX % NT == 0 && KS * CPW % NT == 0, "whole DMA instructions per thread");
+  static_assert(STAGE >= 4096 * NWM * NWN, "epilogue slices must fit one stage buffer");
+  static_assert(CPX >= 16 && CPW >= 16, "swizzle needs 16 chunk columns");
+  static_assert(XF >= WF, "W fragments of the second half-step are fetched during the last WF items of the first");
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 15, g = lane >> 4;
+  const int wm = wave / NWN, wn = wave % NWN;
+  auto swz = [](int k) { return (k & 3) | (((k >> 3) & 3) << 2); };
+
+  const uint32_t per_split = (uint32_t)p.mt * p.nt;
+  const uint32_t ntiles = per_split * p.splits;
+  const uint32_t G = gridDim.x;
+  auto locate = [&](uint32_t it, int& split, int& m0, int& n0, int& kbeg, int& kend) {
+    const uint32_t round0 = (it / G) * G;
+    const uint32_t span = min(G, ntiles - round0);
+    const uint32_t t = round0 + xcd_remap(it - round0, span);
+    split = (int)(t / per_split);
+    const uint32_t tile = t % per_split;
+    m0 = (int)(tile / p.nt) * BM; n0 = (int)(tile % p.nt) * BN;
+    kbeg = split * p.k_per_split;
+    kend = min(p.K, kbeg + p.k_per_split);
+  };
+  const char* xs[XCH];
+  const char* ws[WCH];
+  int xk[XCH], wk[WCH];                                       // k-row (within a step) each DMA lane serves
+  auto point = [&](int m0, int n0, int kbeg) {
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const int c = tid + i * NT, krow = c / CPX, pc = c % CPX;
+      int col = m0 + ((pc ^ swz(krow)) << 3);
+      col = col < p.M ? col : p.M - 8;
+      xk[i] = kbeg + krow;
+      xs[i] = p.X + ((int64_t)(kbeg + krow) * p.ldx + col) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int c = tid + i * NT, krow = c / CPW, pc = c % CPW;
+      int col = n0 + ((pc ^ swz(krow)) << 3);
+      col = col < p.N ? col : p.N - 8;
+      wk[i] = kbeg + krow;
+      ws[i] = p.W + ((int64_t)(kbeg + krow) * p.ldw + col) * 2;
+    }
+  };
+  auto issue = [&](int kt, int kend, uint32_t buf) {
+    char* xb = smem + buf * STAGE;
+    const char* zero = reinterpret_cast<const char*>(dl_zero_page);
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const char* src = (xk[i] + kt * KS < kend) ? xs[i] + (int64_t)kt * KS * p.ldx * 2 : zero;
+      const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((wave * 64 + i * NT) * 16));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(xb + off), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const char* src = (wk[i] + kt * KS < kend) ? ws[i] + (int64_t)kt * KS * p.ldw * 2 : zero;
+      const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)(XB + (wave * 64 + i * NT) * 16));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(xb + off), 16, 0, 0);
+    }
+  };
+  // transposing fragment read: 16 tile columns starting at cb0 (bytes), k-rows kf*32 + g*8 + (il>>2) (+4)
+  auto frag = [&](const char* tile, int pitch, int col0, int kf) -> u32x4 {
+    const int k0 = kf * 32 + g * 8 + (il >> 2), k1 = k0 + 4;
+    const int cb = (col0 + (il & 3) * 4) * 2;
+    const u32x2 a = lds_read_tr16(tile, k0 * pitch + (((cb >> 4) ^ swz(k0)) << 4) + (cb & 15));
+    const u32x2 b = lds_read_tr16(tile, k1 * pitch + (((cb >> 4) ^ swz(k1)) << 4) + (cb & 15));
+    return u32x4{a[0], a[1], b[0], b[1]};
+  };
+
+  uint32_t it = blockIdx.x;
+  if (it >= ntiles) return;
+  int split, m0, n0, kbeg, kend;
+  locate(it, split, m0, n0, kbeg, kend);
+  point(m0, n0, kbeg);
+  uint32_t gs = 0;
+  issue(0, kend, gs % NSTAGE);
+
+  for (;;) {
+    f32x4 acc[XF][WF];
+#pragma unroll
+    for (int i = 0; i < XF; ++i)
+#pragma unroll
+      for (int j = 0; j < WF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = (kend - kbeg + KS - 1) / KS;
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_vmcnt<0>();
+      wg_barrier();
+      if (kt + 1 < nk) issue(kt + 1, kend, (gs + 1) % NSTAGE);
+      const char* cur = smem + (gs % NSTAGE) * STAGE;
+      // same software pipeline as gemm_big_kernel (each fragment is two transposing reads)
+      constexpr int NKF = KS / 32, U = NKF * XF;
+      auto rd_fx = [&](int u) { return frag(cur, PX, wm * 16 * XF + (u % XF) * 16, u / XF); };
+      auto rd_fw = [&](int kf, int j) { return frag(cur + XB, PW, wn * 16 * WF + j * 16, kf); };
+      u32x4 fx[U], fw[NKF][WF];
+#pragma unroll
+      for (int j = 0; j < WF; ++j) fw[0][j] = rd_fw(0, j);
+      fx[0] = rd_fx(0);
+      fx[1] = rd_fx(1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (WF + 2), 0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int nread = 0;
+        if (u + 2 < U) { fx[u + 2] = rd_fx(u + 2); ++nread; }
+        if (u >= XF - WF && u < XF) { fw[1][u - (XF - WF)] = rd_fw(1, u - (XF - WF)); ++nread; }
+#pragma unroll
+        for (int j = 0; j < WF; ++j) acc[u % XF][j] = Mma<T>::mma(fw[u / XF][j], fx[u], acc[u % XF][j]);
+        if (nread == 2) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        else if (nread == 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, WF, 0);
+      }
+      ++gs;
+    }
+
+    const int cm0 = m0, cn0 = n0, csplit = split;
+    const uint32_t itn = it + G;
+    const bool have_next = itn < ntiles;
+    if (have_next) {
+      locate(itn, split, m0, n0, kbeg, kend);
+      point(m0, n0, kbeg);
+      issue(0, kend, gs % NSTAGE);
+    }
+    wg_barrier();
+    char* st = smem + ((gs + NSTAGE - 1) % NSTAGE) * STAGE + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < XF; ++i) {
+#pragma unroll
+      for (int j = 0; j < WF; ++j) lds_write16(st, il * 256 + (((j * 4 + g) ^ il) << 4), __builtin_bit_cast(u32x4, acc[i][j]));
+      wave_sync();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = (lane >> 3) + 8 * h, c8 = lane & 7;
+        const u32x4 a0 = lds_read16(st, r * 256 + (((2 * c8) ^ r) << 4));
+        const u32x4 a1 = lds_read16(st, r * 256 + (((2 * c8 + 1) ^ r) << 4));
+        const int m = cm0 + wm * 16 * XF + i * 16 + r, n = cn0 + wn * 16 * WF + c8 * 8;
+        if (m < p.M && n < p.N) {
+          float* dst = p.slabs + ((int64_t)csplit * p.M + m) * p.N + n;
+          *reinterpret_cast<u32x4*>(dst) = a0;
+          *reinterpret_cast<u32x4*>(dst + 4) = a1;
+        }
+      }
+      wave_sync();
     }
     if (!have_next) break;
     it = itn;

@@ -94,3 +94,26 @@ def test_large_tile_gemm_is_bitwise_equal_to_the_128_tile_path(M, N, K, monkeypa
     monkeypatch.setenv("DL_GEMM_BIG", "1")
     out = ops.gemm(x, w, M=M, N=N, K=K)
     assert (out[:512].double() - ref).abs().max() <= 2e-2 * ref.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(1536, 512, 16384), (128, 768, 262147), (1280, 520, 9000)])
+def test_large_tile_weight_gradient_matches_fp64_and_the_128_tile_path(M, N, K, monkeypatch):
+    """gemm_big_tt_kernel (both operands K-slow, split-K slabs, zero-page K tail) against an fp64 reference on a
+    row sample and against the 128-tile split-K path (different slab count -> fp32 summation order only)."""
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(3)
+    dt = torch.bfloat16
+    dy = (torch.randn(K, M, generator=g) * 0.5).to(dt).cuda()
+    x = (torch.randn(K, N, generator=g) * 0.5).to(dt).cuda()
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DL_GEMM_BIG", mode)
+        outs[mode] = ops.gemm(dy, x, M=M, N=N, K=K, x_kslow=True, w_kslow=True, ldx=M, ldw=N,
+                              out_dtype=torch.float32, split_k=0).clone()
+        torch.cuda.synchronize()
+    ref = dy[:, :96].double().t() @ x.double()
+    scale = ref.abs().max()
+    for mode in ("0", "1"):
+        assert (outs[mode][:96].double() - ref).abs().max() <= 5e-6 * scale, mode
+    assert (outs["0"] - outs["1"]).abs().max() <= 1e-5 * scale
