@@ -13,10 +13,15 @@
 // LDS tiles are [rows][head_dim] with 16-byte chunks XOR-swizzled by (row & 7); the same image
 // serves ds_read_b128 (K-contiguous fragments) and ds_read_b64_tr_b16 / ds_read_b32 (transposed
 // fragments).
+#include <stdlib.h>
 #include "tiles.cuh"
 
 namespace {
 using namespace dltile;
+
+// v_exp_f32 without libm's denormal-range fix-up (arguments here are <= 0 and results below 2^-126 may flush);
+// exp2(-inf) = 0 as the online softmax needs
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 struct AttnP {
   const char *Q, *K, *V, *O, *dO;
@@ -30,7 +35,7 @@ struct AttnP {
 
 // =================================== forward ===================================================
 template <typename T, int HD, int QT>
-__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnP p) {
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnP p) {
   using TL = ATile<T, HD>;
   constexpr int KF = Mma<T>::KF, NKF = HD / KF, NDT = HD / 16, CT = KF / 16;
   constexpr int KVB = 64, NKT = KVB / 16, NKP = KVB / KF;
@@ -134,14 +139,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnP p) {
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][kt][r]);
       mx = group4_max(mx);
       const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = exp2f((m_run[qt] - m_new) * c);
+      const float alpha = fast_exp2((m_run[qt] - m_new) * c);
       const float mc = m_new * c;
       float rs = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = exp2f(s[qt][kt][r] * c - mc);
+          const float e = fast_exp2(s[qt][kt][r] * c - mc);
           s[qt][kt][r] = e;
           rs += e;
         }
@@ -180,6 +185,205 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnP p) {
   }
 }
 
+// =================================== forward, K/V resident ======================================
+// Short-key problems (Lk <= LKMAX = 256: PMMA paired and self attention): the whole K and V of one (problem,
+// head) are brought into LDS ONCE by LDS-DMA (64 KB at head_dim 64, 128 KB at 128; rows past Lk come from a zero
+// page), after which every wave walks its query tiles of BOTH segments over all key tiles with no workgroup
+// barrier and no further K/V traffic; the next unit's Q fragments are requested before the current unit's
+// math.  Same transposed-score math as attn_fwd_kernel.
+__device__ __attribute__((aligned(16))) const uint32_t attn_zero_page[4] = {0u, 0u, 0u, 0u};
+
+// LDS-DMA of `total_rows` (a multiple of 64) rows of head_dim elements into an ATile image: source-side XOR
+// swizzle, rows >= valid_rows read a zero page.  NT threads; completes at the next __syncthreads().
+template <typename T, int HD, int NT>
+__device__ __forceinline__ void dma_rows(char* lds, const T* base, int64_t row_stride, int valid_rows, int total_rows) {
+  using TL = ATile<T, HD>;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int nchunks = total_rows * TL::CPR;
+  const char* zero = reinterpret_cast<const char*>(attn_zero_page);
+  for (int c0 = 0; c0 < nchunks; c0 += NT) {
+    const int c = c0 + tid;
+    const int row = c / TL::CPR, ch = (c % TL::CPR) ^ (row & 7);
+    const char* src = (c < nchunks && row < valid_rows) ? reinterpret_cast<const char*>(base + (int64_t)row * row_stride + ch * TL::EPC) : zero;
+    const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((c0 + wave * 64) * 16));
+    if (c0 + wave * 64 < nchunks)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
+  }
+}
+// sum_d a[d] * b[d] over the 8 bf16 of one fragment
+__device__ __forceinline__ float dot8_bf16(u32x4 a, u32x4 b) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += bf16lo(a[i]) * bf16lo(b[i]) + bf16hi(a[i]) * bf16hi(b[i]);
+  return s;
+}
+
+template <typename T, int HD, int QT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_res_kernel(const AttnP p) {
+  using TL = ATile<T, HD>;
+  constexpr int KF = Mma<T>::KF, NKF = HD / KF, NDT = HD / 16, CT = KF / 16;
+  constexpr int KVB = 64, NKT = KVB / 16, NKP = KVB / KF;
+  constexpr int LKMAX = 256, NT = 64 * NW;
+  __shared__ __attribute__((aligned(16))) char smem[2 * LKMAX * TL::RB];
+  char* Ks = smem;
+  char* Vs = smem + LKMAX * TL::RB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x, pr = blockIdx.y;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)pr * p.k_ps + (int64_t)h * p.k_hs;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + (int64_t)pr * p.v_ps + (int64_t)h * p.v_hs;
+  const int nt = (p.Lk + KVB - 1) / KVB;
+  {
+    const int nchunks = nt * KVB * TL::CPR;          // whole key tiles; rows >= Lk are zero
+    const char* zero = reinterpret_cast<const char*>(attn_zero_page);
+    for (int c0 = 0; c0 < nchunks; c0 += NT) {
+      const int c = c0 + tid;
+      const int row = c / TL::CPR, ch = (c % TL::CPR) ^ (row & 7);
+      const bool ok = c < nchunks && row < p.Lk;
+      const char* ksrc = ok ? reinterpret_cast<const char*>(Kb + (int64_t)row * p.k_rs + ch * TL::EPC) : zero;
+      const char* vsrc = ok ? reinterpret_cast<const char*>(Vb + (int64_t)row * p.v_rs + ch * TL::EPC) : zero;
+      const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((c0 + wave * 64) * 16));
+      if (c0 + wave * 64 < nchunks) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ksrc,
+                                         (__attribute__((address_space(3))) void*)(Ks + off), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc,
+                                         (__attribute__((address_space(3))) void*)(Vs + off), 16, 0, 0);
+      }
+    }
+  }
+  const int nqt = (p.Lq + 16 * QT - 1) / (16 * QT);   // query units per segment
+  const int nunits = p.S * nqt;
+  const float c = p.scale * LOG2E;
+  auto load_q = [&](int unit, u32x4 (&qf)[QT][NKF]) {
+    const int seg = unit / nqt, q0 = (unit % nqt) * 16 * QT;
+    const int qprob = seg == 0 ? pr : (pr + p.shift) % p.P;
+    const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)qprob * p.q_ps + (int64_t)h * p.q_hs;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int q = q0 + qt * 16 + il;
+#pragma unroll
+      for (int kf = 0; kf < NKF; ++kf) qf[qt][kf] = frag_global<T>(Qb + (int64_t)q * p.q_rs, q < p.Lq, kf, g);
+    }
+  };
+  u32x4 qf[QT][NKF], qn[QT][NKF];
+  if (wave < nunits) load_q(wave, qf);
+  __syncthreads();                                    // fence + barrier: every wave's DMA has landed
+
+  for (int unit = wave; unit < nunits; unit += NW) {
+    if (unit + NW < nunits) load_q(unit + NW, qn);
+    const int seg = unit / nqt, qw0 = (unit % nqt) * 16 * QT;
+    f32x4 o[NDT][QT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) o[d][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
+
+    for (int t = 0; t < nt; ++t) {
+      const int k0 = t * KVB;
+      const char* Kt = Ks + k0 * TL::RB;
+      const char* Vt = Vs + k0 * TL::RB;
+      f32x4 s[QT][NKT];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kf = 0; kf < NKF; ++kf) {
+          const u32x4 ka = frag_kc<T, HD>(Kt, kt * 16, kf, il, g);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) s[qt][kt] = Mma<T>::mma(ka, qf[qt][kf], s[qt][kt]);
+        }
+      }
+      if (p.raw && seg == 0) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          const int q = qw0 + qt * 16 + il;
+          if (q < p.Lq) {
+            float* rrow = p.raw + (((int64_t)pr * p.H + h) * p.Lq + q) * p.Lk;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+              const int key = k0 + kt * 16 + 4 * g;
+              if (key + 4 <= p.Lk && (p.Lk & 3) == 0)
+                *reinterpret_cast<f32x4*>(rrow + key) = s[qt][kt] * p.scale;
+              else
+                for (int r = 0; r < 4; ++r)
+                  if (key + r < p.Lk) rrow[key + r] = s[qt][kt][r] * p.scale;
+            }
+          }
+        }
+      }
+      if (k0 + KVB > p.Lk) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + kt * 16 + 4 * g + r >= p.Lk) {
+#pragma unroll
+              for (int qt = 0; qt < QT; ++qt) s[qt][kt][r] = -INFINITY;
+            }
+      }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][kt][r]);
+        mx = group4_max(mx);
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = fast_exp2((m_run[qt] - m_new) * c);
+        const float mc = m_new * c;
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = fast_exp2(s[qt][kt][r] * c - mc);
+            s[qt][kt][r] = e;
+            rs += e;
+          }
+        l_run[qt] = l_run[qt] * alpha + rs;
+        m_run[qt] = m_new;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) o[d][qt] *= alpha;
+      }
+#pragma unroll
+      for (int kp = 0; kp < NKP; ++kp) {
+        u32x4 pb[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) pb[qt] = frag_from_acc<T>(&s[qt][kp * CT]);
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+          const u32x4 va = frag_tr<T, HD>(Vt, kp * KF, d * 16, il, g);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) o[d][qt] = Mma<T>::mma(va, pb[qt], o[d][qt]);
+        }
+      }
+    }
+    T* Ob = reinterpret_cast<T*>(p.Out) + (int64_t)seg * p.o_ss + (int64_t)pr * p.o_ps + (int64_t)h * p.o_hs;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int q = qw0 + qt * 16 + il;
+      const float l = group4_sum(l_run[qt]);
+      const float inv = 1.0f / l;
+      if (q < p.Lq) {
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) store4<T>(Ob + (int64_t)q * p.o_rs + d * 16 + 4 * g, o[d][qt] * inv);
+        if (p.LSE && g == 0)
+          p.LSE[(((int64_t)seg * p.P + pr) * p.H + h) * p.Lq + q] = m_run[qt] * p.scale + logf(l);
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int kf = 0; kf < NKF; ++kf) qf[qt][kf] = qn[qt][kf];
+  }
+}
+
 // =================================== backward: Delta ===========================================
 // Delta(seg,p,h,q) = sum_d dO*O ; 16 lanes per row
 template <typename T, int HD>
@@ -208,15 +412,19 @@ __global__ void attn_delta_kernel(const AttnP p) {
 
 // =================================== backward: dQ ==============================================
 // work item: (q tensor of problem pq, head, q block); loops over the attentions that used it.
-template <typename T, int HD, int QT>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnP p) {
+// RES (bf16, Lk <= 256): the whole K and V of the attention are brought into LDS once per segment by LDS-DMA and
+// the key-tile loop runs without workgroup barriers; Delta = sum_d dO * O is computed here from the dO fragments
+// the kernel holds anyway (and written out for the dK/dV kernel), so no separate Delta launch is needed.
+template <typename T, int HD, int QT, bool RES>
+__global__ __launch_bounds__(ATT_THREADS, (HD == 64 ? 2 : 1)) void attn_bwd_dq_kernel(const AttnP p) {
   using TL = ATile<T, HD>;
   constexpr int KF = Mma<T>::KF, NKF = HD / KF, NDT = HD / 16, CT = KF / 16;
   constexpr int KVB = 64, NKT = KVB / 16, NKP = KVB / KF;
   constexpr int QB = 4 * QT * 16;
-  __shared__ __attribute__((aligned(16))) char smem[2 * KVB * TL::RB];
+  constexpr int LROWS = RES ? 256 : KVB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * LROWS * TL::RB];
   char* Ks = smem;
-  char* Vs = smem + KVB * TL::RB;
+  char* Vs = smem + LROWS * TL::RB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 15, g = lane >> 4;
   const int qb = blockIdx.x, h = blockIdx.y, pq = blockIdx.z;
   const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)pq * p.q_ps + (int64_t)h * p.q_hs;
@@ -243,6 +451,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnP p)
     const T* dOb = reinterpret_cast<const T*>(p.dO) + (int64_t)seg * p.do_ss + (int64_t)pa * p.do_ps +
                    (int64_t)h * p.do_hs;
     const int64_t statbase = (((int64_t)seg * p.P + pa) * p.H + h) * p.Lq;
+    const int nt = (p.Lk + KVB - 1) / KVB;
+    if constexpr (RES) {
+      dma_rows<T, HD, ATT_THREADS>(Ks, Kb, p.k_rs, p.Lk, nt * KVB);
+      dma_rows<T, HD, ATT_THREADS>(Vs, Vb, p.v_rs, p.Lk, nt * KVB);
+    }
     u32x4 dof[QT][NKF];
     float lse2[QT], delta[QT];
 #pragma unroll
@@ -252,21 +465,37 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnP p)
 #pragma unroll
       for (int kf = 0; kf < NKF; ++kf) dof[qt][kf] = frag_global<T>(dOb + (int64_t)q * p.do_rs, ok, kf, g);
       lse2[qt] = ok ? p.LSE[statbase + q] * LOG2E : INFINITY;
-      delta[qt] = ok ? p.Delta[statbase + q] : 0.f;
+      if constexpr (RES && sizeof(T) == 2) {
+        const T* Ob = reinterpret_cast<const T*>(p.O) + (int64_t)seg * p.o_ss + (int64_t)pa * p.o_ps + (int64_t)h * p.o_hs;
+        float part = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < NKF; ++kf) part += dot8_bf16(dof[qt][kf], frag_global<T>(Ob + (int64_t)q * p.o_rs, ok, kf, g));
+        delta[qt] = group4_sum(part);
+        if (ok && g == 0) p.Delta[statbase + q] = delta[qt];
+      } else {
+        delta[qt] = ok ? p.Delta[statbase + q] : 0.f;
+      }
     }
     Stager<T, HD, KVB> sk, sv;
-    const int nt = (p.Lk + KVB - 1) / KVB;
-    sk.load(Kb, p.k_rs, 0, p.Lk);
-    sv.load(Vb, p.v_rs, 0, p.Lk);
+    if constexpr (RES) {
+      __syncthreads();                                  // fence + barrier: the K/V image has landed
+    } else {
+      sk.load(Kb, p.k_rs, 0, p.Lk);
+      sv.load(Vb, p.v_rs, 0, p.Lk);
+    }
     for (int t = 0; t < nt; ++t) {
       const int k0 = t * KVB;
-      sk.store(Ks);
-      sv.store(Vs);
-      __syncthreads();
-      if (t + 1 < nt) {
-        sk.load(Kb, p.k_rs, k0 + KVB, p.Lk);
-        sv.load(Vb, p.v_rs, k0 + KVB, p.Lk);
+      if constexpr (!RES) {
+        sk.store(Ks);
+        sv.store(Vs);
+        __syncthreads();
+        if (t + 1 < nt) {
+          sk.load(Kb, p.k_rs, k0 + KVB, p.Lk);
+          sv.load(Vb, p.v_rs, k0 + KVB, p.Lk);
+        }
       }
+      const char* Kt = RES ? Ks + k0 * TL::RB : Ks;
+      const char* Vt = RES ? Vs + k0 * TL::RB : Vs;
       f32x4 s[QT][NKT], dp[QT][NKT];
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
@@ -274,8 +503,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnP p)
         for (int qt = 0; qt < QT; ++qt) { s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int kf = 0; kf < NKF; ++kf) {
-          const u32x4 ka = frag_kc<T, HD>(Ks, kt * 16, kf, il, g);
-          const u32x4 va = frag_kc<T, HD>(Vs, kt * 16, kf, il, g);
+          const u32x4 ka = frag_kc<T, HD>(Kt, kt * 16, kf, il, g);
+          const u32x4 va = frag_kc<T, HD>(Vt, kt * 16, kf, il, g);
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) {
             s[qt][kt] = Mma<T>::mma(ka, qf[qt][kf], s[qt][kt]);
@@ -290,7 +519,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnP p)
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = exp2f(s[qt][kt][r] * c - lse2[qt]);
+            const float pv = fast_exp2(s[qt][kt][r] * c - lse2[qt]);
             s[qt][kt][r] = pv * (dp[qt][kt][r] - delta[qt]);
           }
       // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
@@ -301,13 +530,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnP p)
         for (int qt = 0; qt < QT; ++qt) db[qt] = frag_from_acc<T>(&s[qt][kp * CT]);
 #pragma unroll
         for (int d = 0; d < NDT; ++d) {
-          const u32x4 kta = frag_tr<T, HD>(Ks, kp * KF, d * 16, il, g);
+          const u32x4 kta = frag_tr<T, HD>(Kt, kp * KF, d * 16, il, g);
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) dq[d][qt] = Mma<T>::mma(kta, db[qt], dq[d][qt]);
         }
       }
-      __syncthreads();
+      if constexpr (!RES) __syncthreads();
     }
+    if constexpr (RES) { if (seg + 1 < p.S) __syncthreads(); }   // before the next segment's image overwrites this one
   }
   T* dQb = reinterpret_cast<T*>(p.dQ) + (int64_t)pq * p.dq_ps + (int64_t)h * p.dq_hs;
 #pragma unroll
@@ -323,19 +553,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnP p)
 
 // =================================== backward: dK, dV ==========================================
 // work item: (attention problem pa, head, kv block of 4 waves x KT x 16 keys)
-template <typename T, int HD, int KT>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnP p) {
+// RES (bf16, Lq <= 256): Q, dO, LSE and Delta of one segment are LDS-resident (LDS-DMA, one barrier per segment).
+template <typename T, int HD, int KT, bool RES>
+__global__ __launch_bounds__(ATT_THREADS, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_kernel(const AttnP p) {
   using TL = ATile<T, HD>;
   constexpr int KF = Mma<T>::KF, NKF = HD / KF, NDT = HD / 16, CT = KF / 16;
   constexpr int QSB = 64;                // q rows staged per step
   constexpr int NQT = QSB / 16;          // q tiles per staged block
   constexpr int NQP = QSB / KF;          // contraction fragments per staged block
   constexpr int KVB = 4 * KT * 16;
-  __shared__ __attribute__((aligned(16))) char smem[2 * QSB * TL::RB + 2 * QSB * sizeof(float)];
+  constexpr int LROWS = RES ? 256 : QSB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * LROWS * TL::RB + 2 * LROWS * sizeof(float)];
   char* Qs = smem;
-  char* dOs = smem + QSB * TL::RB;
-  float* lse_s = reinterpret_cast<float*>(smem + 2 * QSB * TL::RB);
-  float* del_s = lse_s + QSB;
+  char* dOs = smem + LROWS * TL::RB;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * LROWS * TL::RB);
+  float* del_s = lse_s + LROWS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 15, g = lane >> 4;
   const int kb = blockIdx.x, h = blockIdx.y, pa = blockIdx.z;
   const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)pa * p.k_ps + (int64_t)h * p.k_hs;
@@ -368,22 +600,39 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnP p
     const T* dOb = reinterpret_cast<const T*>(p.dO) + (int64_t)seg * p.do_ss + (int64_t)pa * p.do_ps +
                    (int64_t)h * p.do_hs;
     const int64_t statbase = (((int64_t)seg * p.P + pa) * p.H + h) * p.Lq;
-    sq.load(Qb, p.q_rs, 0, p.Lq);
-    sdo.load(dOb, p.do_rs, 0, p.Lq);
-    for (int qb = 0; qb < nqb; ++qb) {
-      const int q0 = qb * QSB;
-      sq.store(Qs);
-      sdo.store(dOs);
-      if (threadIdx.x < QSB) {
-        const int q = q0 + threadIdx.x;
-        lse_s[threadIdx.x] = q < p.Lq ? p.LSE[statbase + q] * LOG2E : INFINITY;
-        del_s[threadIdx.x] = q < p.Lq ? p.Delta[statbase + q] : 0.f;
+    if constexpr (RES) {
+      if (seg > 0) __syncthreads();                     // everyone is done with the previous segment's image
+      dma_rows<T, HD, ATT_THREADS>(Qs, Qb, p.q_rs, p.Lq, nqb * QSB);
+      dma_rows<T, HD, ATT_THREADS>(dOs, dOb, p.do_rs, p.Lq, nqb * QSB);
+      for (int q = threadIdx.x; q < nqb * QSB; q += ATT_THREADS) {
+        lse_s[q] = q < p.Lq ? p.LSE[statbase + q] * LOG2E : INFINITY;
+        del_s[q] = q < p.Lq ? p.Delta[statbase + q] : 0.f;
       }
       __syncthreads();
-      if (qb + 1 < nqb) {
-        sq.load(Qb, p.q_rs, q0 + QSB, p.Lq);
-        sdo.load(dOb, p.do_rs, q0 + QSB, p.Lq);
+    } else {
+      sq.load(Qb, p.q_rs, 0, p.Lq);
+      sdo.load(dOb, p.do_rs, 0, p.Lq);
+    }
+    for (int qb = 0; qb < nqb; ++qb) {
+      const int q0 = qb * QSB;
+      if constexpr (!RES) {
+        sq.store(Qs);
+        sdo.store(dOs);
+        if (threadIdx.x < QSB) {
+          const int q = q0 + threadIdx.x;
+          lse_s[threadIdx.x] = q < p.Lq ? p.LSE[statbase + q] * LOG2E : INFINITY;
+          del_s[threadIdx.x] = q < p.Lq ? p.Delta[statbase + q] : 0.f;
+        }
+        __syncthreads();
+        if (qb + 1 < nqb) {
+          sq.load(Qb, p.q_rs, q0 + QSB, p.Lq);
+          sdo.load(dOb, p.do_rs, q0 + QSB, p.Lq);
+        }
       }
+      const char* Qt = RES ? Qs + q0 * TL::RB : Qs;
+      const char* dOt = RES ? dOs + q0 * TL::RB : dOs;
+      const float* lse_t = RES ? lse_s + q0 : lse_s;
+      const float* del_t = RES ? del_s + q0 : del_s;
       // S[q][key] = Q K^T and dP[q][key] = dO V^T for the staged 64 rows; lane: q = 4g+r, key = il
       f32x4 s[KT][NQT], dp[KT][NQT];
 #pragma unroll
@@ -392,21 +641,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnP p
         for (int kt = 0; kt < KT; ++kt) { s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int kf = 0; kf < NKF; ++kf) {
-          const u32x4 qa = frag_kc<T, HD>(Qs, qt * 16, kf, il, g);
-          const u32x4 da = frag_kc<T, HD>(dOs, qt * 16, kf, il, g);
+          const u32x4 qa = frag_kc<T, HD>(Qt, qt * 16, kf, il, g);
+          const u32x4 da = frag_kc<T, HD>(dOt, qt * 16, kf, il, g);
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt) {
             s[kt][qt] = Mma<T>::mma(qa, kfr[kt][kf], s[kt][qt]);
             dp[kt][qt] = Mma<T>::mma(da, vfr[kt][kf], dp[kt][qt]);
           }
         }
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + 4 * g);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qt * 16 + 4 * g);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_t + qt * 16 + 4 * g);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_t + qt * 16 + 4 * g);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = exp2f(s[kt][qt][r] * c - l4[r]);
+            const float pv = fast_exp2(s[kt][qt][r] * c - l4[r]);
             s[kt][qt][r] = pv;                              // P
             dp[kt][qt][r] = pv * (dp[kt][qt][r] - d4[r]);  // dS
           }
@@ -422,8 +671,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnP p
         }
 #pragma unroll
         for (int d = 0; d < NDT; ++d) {
-          const u32x4 dota = frag_tr<T, HD>(dOs, qp * KF, d * 16, il, g);
-          const u32x4 qta = frag_tr<T, HD>(Qs, qp * KF, d * 16, il, g);
+          const u32x4 dota = frag_tr<T, HD>(dOt, qp * KF, d * 16, il, g);
+          const u32x4 qta = frag_tr<T, HD>(Qt, qp * KF, d * 16, il, g);
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt) {
             dv[d][kt] = Mma<T>::mma(dota, pb[kt], dv[d][kt]);
@@ -431,7 +680,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnP p
           }
         }
       }
-      __syncthreads();
+      if constexpr (!RES) __syncthreads();
     }
   }
   T* dKb = reinterpret_cast<T*>(p.dK) + (int64_t)pa * p.dk_ps + (int64_t)h * p.dk_hs;
@@ -466,6 +715,16 @@ int check_common(const char* who, int dtype, int head_dim, int nseg, int P, int 
 
 template <typename T, int HD>
 int launch_fwd(const AttnP& p, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    // K/V-resident form for short key sequences (DL_ATTN_RES=0 disables it for A/B studies)
+    const char* e = getenv("DL_ATTN_RES");
+    // (measured: at head_dim 128 the 128 KB image leaves one workgroup per CU and ties with the streaming form)
+    if (HD == 64 && p.Lk <= 256 && !(e && atoi(e) == 0)) {
+      constexpr int NW = HD == 64 ? 4 : 8;            // 64 KB -> two workgroups per CU; 128 KB -> one of 8 waves
+      hipLaunchKernelGGL((attn_fwd_res_kernel<T, HD, 2, NW>), dim3((uint32_t)p.H, (uint32_t)p.P), dim3(64 * NW), 0, s, p);
+      return DL_OK;
+    }
+  }
   constexpr int QT = fwd_qt<T>();
   constexpr int QB = 4 * QT * 16;
   dim3 grid((uint32_t)(p.S * ((p.Lq + QB - 1) / QB)), (uint32_t)p.H, (uint32_t)p.P);
@@ -475,22 +734,27 @@ int launch_fwd(const AttnP& p, hipStream_t s) {
 
 template <typename T, int HD>
 int launch_bwd(const AttnP& p, hipStream_t s) {
+  constexpr int QT = fwd_qt<T>();
+  constexpr int QB = 4 * QT * 16;
+  constexpr int KT = (sizeof(T) == 2 && HD == 64) ? 2 : 1;
+  constexpr int KVB = 4 * KT * 16;
+  const dim3 gq((uint32_t)((p.Lq + QB - 1) / QB), (uint32_t)p.H, (uint32_t)p.P);
+  const dim3 gk((uint32_t)((p.Lk + KVB - 1) / KVB), (uint32_t)p.H, (uint32_t)p.P);
+  if constexpr (sizeof(T) == 2 && HD == 64) {
+    // LDS-resident forms (64 KB images, two workgroups per CU); Delta comes out of the dQ kernel
+    const char* e = getenv("DL_ATTN_RES");
+    if (p.Lk <= 256 && p.Lq <= 256 && !(e && atoi(e) == 0)) {
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, QT, true>), gq, dim3(ATT_THREADS), 0, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD, KT, true>), gk, dim3(ATT_THREADS), 0, s, p);
+      return DL_OK;
+    }
+  }
   {
     const int64_t rows = (int64_t)p.S * p.P * p.H * p.Lq;
     hipLaunchKernelGGL((attn_delta_kernel<T, HD>), dim3((uint32_t)((rows + 15) / 16)), dim3(256), 0, s, p);
   }
-  {
-    constexpr int QT = fwd_qt<T>();
-    constexpr int QB = 4 * QT * 16;
-    dim3 grid((uint32_t)((p.Lq + QB - 1) / QB), (uint32_t)p.H, (uint32_t)p.P);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, QT>), grid, dim3(ATT_THREADS), 0, s, p);
-  }
-  {
-    constexpr int KT = (sizeof(T) == 2 && HD == 64) ? 2 : 1;
-    constexpr int KVB = 4 * KT * 16;
-    dim3 grid((uint32_t)((p.Lk + KVB - 1) / KVB), (uint32_t)p.H, (uint32_t)p.P);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD, KT>), grid, dim3(ATT_THREADS), 0, s, p);
-  }
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, QT, false>), gq, dim3(ATT_THREADS), 0, s, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD, KT, false>), gk, dim3(ATT_THREADS), 0, s, p);
   return DL_OK;
 }
 

@@ -331,32 +331,34 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
         Lk = key.shape[0]
         cdt = query.dtype
         hd = E // H
-        q2 = query.reshape(Lq * B, E).contiguous()
-        k2 = key.reshape(Lk * B, E).contiguous()
+        # The callers hand over seq-first VIEWS of batch-first tensors (x.permute(1, 0, 2)); attention is
+        # independent per batch element, so the rows are kept in (b, l) order: no transposed copies, and
+        # every problem's Q / K / V rows are contiguous in HBM (problem stride L * width, row stride width).
+        q2 = query.transpose(0, 1).contiguous().view(B * Lq, E)
+        k2 = key.transpose(0, 1).contiguous().view(B * Lk, E)
         w = lowp((in_w,), cdt)
         b = _f32(in_b)
-        # rows of q/k/v are (l, b) pairs: problem stride = row width, row stride = B * row width
-        qp = ops.gemm(q2, w[:E], M=Lq * B, N=E, K=E, bias=None if b is None else b[:E])
-        kv = ops.gemm(k2, w[E:], M=Lk * B, N=2 * E, K=E, bias=None if b is None else b[E:])
-        o = torch.empty((Lq * B, E), dtype=cdt, device=query.device)
+        qp = ops.gemm(q2, w[:E], M=B * Lq, N=E, K=E, bias=None if b is None else b[:E])
+        kv = ops.gemm(k2, w[E:], M=B * Lk, N=2 * E, K=E, bias=None if b is None else b[E:])
+        o = torch.empty((B * Lq, E), dtype=cdt, device=query.device)
         raw = torch.empty((B, H, Lq, Lk), dtype=torch.float32, device=query.device) if need_raw else None
         scale = float(hd) ** -0.5
         lse = ops.attn_fwd(qp, kv, kv[:, E:], n_problems=B, n_heads=H, n_segments=1, partner_shift=0, Lq=Lq, Lk=Lk,
-                           head_dim=hd, scale=scale, q_strides=(E, hd, B * E), k_strides=(2 * E, hd, B * 2 * E),
-                           v_strides=(2 * E, hd, B * 2 * E), out=o, o_strides=(E, hd, B * E), o_ss=0, raw_logits=raw)
+                           head_dim=hd, scale=scale, q_strides=(Lq * E, hd, E), k_strides=(Lk * 2 * E, hd, 2 * E),
+                           v_strides=(Lk * 2 * E, hd, 2 * E), out=o, o_strides=(Lq * E, hd, E), o_ss=0, raw_logits=raw)
         ow = lowp((out_w,), cdt)
-        y = ops.gemm(o, ow, M=Lq * B, N=E, K=E, bias=_f32(out_b))
+        y = ops.gemm(o, ow, M=B * Lq, N=E, K=E, bias=_f32(out_b))
         ctx.save_for_backward(q2, k2, w, qp, kv, o, lse, ow)
         ctx.cfg = (Lq, Lk, B, E, H, scale, in_b is not None, out_b is not None)
         ctx.mark_non_differentiable(*([raw] if raw is not None else []))
-        return y.reshape(Lq, B, E), raw
+        return y.view(B, Lq, E).transpose(0, 1), raw
 
     @staticmethod
     def backward(ctx, dy, _draw):
         q2, k2, w, qp, kv, o, lse, ow = ctx.saved_tensors
         Lq, Lk, B, E, H, scale, has_inb, has_outb = ctx.cfg
         hd = E // H
-        g = dy.reshape(Lq * B, E).contiguous()
+        g = dy.transpose(0, 1).contiguous().view(B * Lq, E)
         dwo = ops.gemm(g, o, M=E, N=E, K=Lq * B, x_kslow=True, w_kslow=True, ldx=E, ldw=E, out_dtype=torch.float32,
                        split_k=0)
         dbo = ops.colsum(g) if has_outb else None
@@ -364,18 +366,18 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
         dqp = torch.empty_like(qp)
         dkv = torch.empty_like(kv)
         ops.attn_bwd(qp, kv, kv[:, E:], o, do, lse, n_problems=B, n_heads=H, n_segments=1, partner_shift=0, Lq=Lq,
-                     Lk=Lk, head_dim=hd, scale=scale, q_strides=(E, hd, B * E), k_strides=(2 * E, hd, B * 2 * E),
-                     v_strides=(2 * E, hd, B * 2 * E), o_strides=(E, hd, B * E), o_ss=0, do_strides=(E, hd, B * E),
-                     do_ss=0, dq=dqp, dq_strides=(E, hd, B * E), dk=dkv, dk_strides=(2 * E, hd, B * 2 * E),
-                     dv=dkv[:, E:], dv_strides=(2 * E, hd, B * 2 * E))
+                     Lk=Lk, head_dim=hd, scale=scale, q_strides=(Lq * E, hd, E), k_strides=(Lk * 2 * E, hd, 2 * E),
+                     v_strides=(Lk * 2 * E, hd, 2 * E), o_strides=(Lq * E, hd, E), o_ss=0, do_strides=(Lq * E, hd, E),
+                     do_ss=0, dq=dqp, dq_strides=(Lq * E, hd, E), dk=dkv, dk_strides=(Lk * 2 * E, hd, 2 * E),
+                     dv=dkv[:, E:], dv_strides=(Lk * 2 * E, hd, 2 * E))
         dwq = ops.gemm(dqp, q2, M=E, N=E, K=Lq * B, x_kslow=True, w_kslow=True, ldx=E, ldw=E, out_dtype=torch.float32,
                        split_k=0)
         dwkv = ops.gemm(dkv, k2, M=2 * E, N=E, K=Lk * B, x_kslow=True, w_kslow=True, ldx=2 * E, ldw=E,
                         out_dtype=torch.float32, split_k=0)
         din_w = torch.cat((dwq, dwkv), dim=0)
         din_b = torch.cat((ops.colsum(dqp), ops.colsum(dkv))) if has_inb else None
-        dquery = ops.gemm(dqp, w[:E], M=Lq * B, N=E, K=E, w_kslow=True, ldw=E).reshape(Lq, B, E)
-        dkey = ops.gemm(dkv, w[E:], M=Lk * B, N=E, K=2 * E, w_kslow=True, ldw=E).reshape(Lk, B, E)
+        dquery = ops.gemm(dqp, w[:E], M=Lq * B, N=E, K=E, w_kslow=True, ldw=E).view(B, Lq, E).transpose(0, 1)
+        dkey = ops.gemm(dkv, w[E:], M=Lk * B, N=E, K=2 * E, w_kslow=True, ldw=E).view(B, Lk, E).transpose(0, 1)
         return dquery, dkey, din_w, din_b, dwo, dbo, None, None
 
 
@@ -422,15 +424,30 @@ class TokenGateFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # dtype cast as an autograd node; attention maps for vis=True
 # ------------------------------------------------------------------------------------------------
+def _cast_keep_layout(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """dtype conversion that keeps a permuted-but-dense layout (e.g. the seq-first views of batch-first
+    tensors the PGCA callers pass) instead of materialising the permutation."""
+    if x.is_contiguous():
+        return ops.cast(x, dtype)
+    perm = sorted(range(x.dim()), key=lambda i: -x.stride(i))
+    xp = x.permute(perm)
+    if not xp.is_contiguous():
+        return ops.cast(x.contiguous(), dtype)
+    inv = [0] * len(perm)
+    for i, d in enumerate(perm):
+        inv[d] = i
+    return ops.cast(xp, dtype).permute(inv)
+
+
 class CastFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dtype):
         ctx.src = x.dtype
-        return ops.cast(x.contiguous(), dtype)
+        return _cast_keep_layout(x, dtype)
 
     @staticmethod
     def backward(ctx, dy):
-        return ops.cast(dy.contiguous(), ctx.src), None
+        return _cast_keep_layout(dy, ctx.src), None
 
 
 def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

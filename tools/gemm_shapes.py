@@ -44,10 +44,32 @@ def timed(x, w, **kw):
     return out
 
 
+arecs = []
+def wrap_attn(name):
+    f = getattr(ops, name)
+    def g(*a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); out = f(*a, **kw); e1.record()
+        arecs.append(((name, kw["n_problems"], kw["n_heads"], kw["n_segments"], kw["Lq"], kw["Lk"], kw["head_dim"],
+                       str(kw.get("q_strides")), str(kw.get("k_strides")), kw.get("raw_logits") is not None), e0, e1))
+        return out
+    setattr(ops, name, g)
+wrap_attn("attn_fwd"); wrap_attn("attn_bwd")
 ops.gemm = timed
 import druglamp_amd.functional as Fn  # noqa: E402
 if hasattr(Fn, "ops"):
-    Fn.ops.gemm = timed
+    Fn.arecs = []
+def wrap_attn(name):
+    f = getattr(ops, name)
+    def g(*a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); out = f(*a, **kw); e1.record()
+        arecs.append(((name, kw["n_problems"], kw["n_heads"], kw["n_segments"], kw["Lq"], kw["Lk"], kw["head_dim"],
+                       str(kw.get("q_strides")), str(kw.get("k_strides")), kw.get("raw_logits") is not None), e0, e1))
+        return out
+    setattr(ops, name, g)
+wrap_attn("attn_fwd"); wrap_attn("attn_bwd")
+ops.gemm = timed
 trainer.training_step(batch, meta=meta, cur_epoch=1)
 torch.cuda.synchronize()
 agg = defaultdict(lambda: [0.0, 0])
@@ -61,3 +83,9 @@ for key, (ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     M, N, K, lay, epi, od = key
     tf = 2.0 * M * N * K * n / (ms * 1e-3) / 1e12
     print("%9d %6d %8d %3s %-6s %-8s %4d %9.1f %8.1f %7.3f" % (M, N, K, lay, epi, od, n, ms / n * 1e3, tf, ms))
+
+agg = defaultdict(lambda: [0.0, 0])
+for key, a, b in arecs:
+    agg[key][0] += a.elapsed_time(b); agg[key][1] += 1
+for key, (ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    print("%-90s n=%d  %.1f us/call" % (key, n, ms / n * 1e3))
