@@ -36,6 +36,7 @@ class GemmArgs(C.Structure):
         ("dropout_p", c_f32), ("dropout_seed", c_u64),
         ("accumulate", c_i32),
         ("split_k", c_i32), ("workspace", c_vp), ("workspace_bytes", c_sz),
+        ("x_colsum", c_vp),
     ]
 
 

@@ -122,6 +122,24 @@ template <> struct Mma<float> {
   }
 };
 
+// sum of the contraction slots a lane holds in one fragment (bf16: four v_dot2c_f32_bf16 against 1.0; f32: adds)
+template <typename T> __device__ __forceinline__ float frag_slot_sum(u32x4 f, float acc);
+template <> __device__ __forceinline__ float frag_slot_sum<bf16_t>(u32x4 f, float acc) {
+  // NOTE: pairs are taken by shufflevector from ONE bf16x8 view — indexing the u32x4 per element inside an
+  // unrolled loop and bit-casting each word made hipcc (ROCm 7.2) use word 0 four times (cf. Mma<float>).
+  const bf16x2 one = __builtin_bit_cast(bf16x2, 0x3F803F80u);
+  const bf16x8 v = __builtin_bit_cast(bf16x8, f);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 0, 1), one, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 2, 3), one, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 4, 5), one, acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(v, v, 6, 7), one, acc, false);
+  return acc;
+}
+template <> __device__ __forceinline__ float frag_slot_sum<float>(u32x4 f, float acc) {
+  const f32x4 v = __builtin_bit_cast(f32x4, f);
+  return acc + ((v[0] + v[1]) + (v[2] + v[3]));
+}
+
 // Accumulator tiles -> fragment in the CTILE slot map.
 //   bf16: two 16-row tiles (t0: indices 0..15, t1: 16..31) -> 8 bf16
 //   f32 : one 16-row tile -> 4 floats

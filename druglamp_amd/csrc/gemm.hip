@@ -43,6 +43,7 @@ struct GemmP {
   uint32_t drop_thr16; float drop_inv_keep; uint64_t seed;
   int accumulate;
   float* slabs;   // split mode: [splits][M][N] f32
+  float* cs_slabs; // split mode, optional: [splits][M] partial column sums of the K-slow X operand
   int dbg;
 };
 
@@ -198,6 +199,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   for (int i = 0; i < TW; ++i)
 #pragma unroll
     for (int j = 0; j < TW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // weight-gradient form: the waves that own output columns 0..63 of the first column tile also sum their X
+  // fragments over k (bias gradient), one float per 16-row fragment
+  float cs[TW];
+#pragma unroll
+  for (int i = 0; i < TW; ++i) cs[i] = 0.f;
+  const bool do_cs = SPLIT && XS && p.cs_slabs && n0 == 0 && wn == 0;
 
   const int nk = (kend - kbeg + BKE - 1) / BKE;
   if constexpr (XD) dma_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg, smem);
@@ -226,6 +233,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
       for (int i = 0; i < TW; ++i)
 #pragma unroll
         for (int j = 0; j < TW; ++j) acc[i][j] = Mma<T>::mma(fw[j], fx[i], acc[i][j]);
+      if constexpr (SPLIT && XS) {
+        if (do_cs) {
+#pragma unroll
+          for (int i = 0; i < TW; ++i) cs[i] = frag_slot_sum<T>(fx[i], cs[i]);
+        }
+      }
     }
     if (more) {
       if constexpr (!XD) store_tile<T, XS, TW>(nxt, rx);
@@ -243,6 +256,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
     if constexpr (!WD) load_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg, kend, rw);
   }
 
+  if constexpr (SPLIT && XS) {
+    if (do_cs) {
+#pragma unroll
+      for (int i = 0; i < TW; ++i) {
+        const float v = group4_sum(cs[i]);
+        const int m = cm0 + wm * 16 * TW + i * 16 + il;
+        if (g == 0 && m < p.M) p.cs_slabs[(int64_t)csplit * p.M + m] = v;
+      }
+    }
+  }
   // ---- epilogue -------------------------------------------------------------------------------
   // The accumulators (lane: row il, 4 consecutive columns 4g..4g+3 per tile) are first parked in LDS
   // as an fp32 [128][128] tile (the operand buffers are free now), then every thread takes 8
@@ -603,8 +626,9 @@ int dispatch_layout(const dl_gemm_args* a, const GemmP& p, hipStream_t s, int tw
 extern "C" size_t dl_gemm_workspace_bytes(const dl_gemm_args* a) {
   if (!a) return 0;
   const int sp = resolve_split(a);
-  if (big_tt_plan(a, nullptr) > 0) return (size_t)sp * (size_t)a->M * (size_t)a->N * sizeof(float);
-  return sp > 1 ? (size_t)sp * (size_t)a->M * (size_t)a->N * sizeof(float) : 0;
+  const size_t cs = a->x_colsum ? (size_t)sp * (size_t)a->M * sizeof(float) : 0;
+  if (big_tt_plan(a, nullptr) > 0 || sp > 1 || a->x_colsum) return (size_t)sp * (size_t)a->M * (size_t)a->N * sizeof(float) + cs;
+  return 0;
 }
 
 extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
@@ -646,11 +670,15 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   const int sp = resolve_split(a);
   int tt_bm = 0;
   const bool big_tt = big_tt_plan(a, &tt_bm) > 0;
-  if (sp > 1 || big_tt) {
+  if (a->x_colsum)
+    DL_CHECK_ARG(a->x_kslow && a->w_kslow && a->split_k == 0, DL_ERR_UNSUPPORTED,
+                 "dl_gemm: x_colsum needs the weight-gradient form (x_kslow, w_kslow, split_k = 0)");
+  const bool slab_path = sp > 1 || big_tt || a->x_colsum != nullptr;
+  if (slab_path) {
     DL_CHECK_ARG(!a->bias && !a->residual && !a->act && !a->pre_out && !a->dact_pre &&
                      a->dropout_p == 0.f && (a->N % 4 == 0),
                  DL_ERR_UNSUPPORTED, "dl_gemm: split_k supports only the plain epilogue, N %% 4 == 0");
-    const size_t need = (size_t)sp * a->M * a->N * sizeof(float);
+    const size_t need = dl_gemm_workspace_bytes(a);
     DL_CHECK_ARG(a->workspace && a->workspace_bytes >= need, DL_ERR_WORKSPACE,
                  "dl_gemm: split_k=%d needs %zu workspace bytes, got %zu", sp, need, a->workspace_bytes);
   }
@@ -659,7 +687,7 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   p.X = (const char*)a->X; p.W = (const char*)a->W; p.C = (char*)a->C;
   p.ldx = a->ldx; p.ldw = a->ldw; p.ldc = a->ldc;
   p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
-  const int tw = sp > 1 ? pick_tw(a) : 4;
+  const int tw = slab_path ? pick_tw(a) : 4;
   const int bt = 32 * tw;
   p.mt = (int)((a->M + bt - 1) / bt); p.nt = (int)((a->N + bt - 1) / bt); p.splits = sp;
   const int bke = BKB / es;
@@ -679,6 +707,7 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   p.seed = a->dropout_seed;
   p.accumulate = a->accumulate;
   p.slabs = (float*)a->workspace;
+  p.cs_slabs = a->x_colsum ? (float*)a->workspace + (size_t)sp * a->M * a->N : nullptr;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DL_GEMM_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
 
   dl_prof_before(0, s);
@@ -692,11 +721,11 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
     p.mt = (int)((a->M + 255) / 256); p.nt = (int)((a->N + 255) / 256);
     launch_big(p, s);
   } else if (a->in_dtype == DL_BF16) {
-    if (sp > 1) rc = dispatch_layout<bf16_t, float, true>(a, p, s, tw);
+    if (slab_path) rc = dispatch_layout<bf16_t, float, true>(a, p, s, tw);
     else if (a->out_dtype == DL_F32) rc = dispatch_layout<bf16_t, float, false>(a, p, s, tw);
     else rc = dispatch_layout<bf16_t, bf16_t, false>(a, p, s, tw);
   } else {
-    if (sp > 1) rc = dispatch_layout<float, float, true>(a, p, s, tw);
+    if (slab_path) rc = dispatch_layout<float, float, true>(a, p, s, tw);
     else rc = dispatch_layout<float, float, false>(a, p, s, tw);
   }
   if (rc != DL_OK) return rc;
@@ -707,7 +736,11 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
     const double bytes = ((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * oes;
     dl_prof_after(0, s, flops, bytes);
   }
-  if (sp > 1 || big_tt) {
+  if (slab_path) {
+    if (a->x_colsum) {
+      hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((a->M + 63) / 64)), dim3(1024), 0, s,
+                         (const float*)p.cs_slabs, sp, (int64_t)a->M, (int)a->M, a->x_colsum, 0);
+    }
     const int64_t mn = a->M * a->N;
     const int threads = 256;
     const int64_t blocks = (mn / 4 + threads - 1) / threads;

@@ -329,6 +329,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
     for (int i = 0; i < XF; ++i)
 #pragma unroll
       for (int j = 0; j < WF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float cs[XF];
+#pragma unroll
+    for (int i = 0; i < XF; ++i) cs[i] = 0.f;
+    const bool do_cs = p.cs_slabs && n0 == 0 && wn == 0;   // bias gradient: sum of the X fragments over k
     const int nk = (kend - kbeg + KS - 1) / KS;
     for (int kt = 0; kt < nk; ++kt) {
       wait_vmcnt<0>();
@@ -355,6 +359,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
         if (nread == 2) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         else if (nread == 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, WF, 0);
+        if (do_cs) cs[u % XF] = frag_slot_sum<T>(fx[u], cs[u % XF]);
       }
       ++gs;
     }
@@ -368,6 +373,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
       issue(0, kend, gs % NSTAGE);
     }
     wg_barrier();
+    if (do_cs) {
+#pragma unroll
+      for (int i = 0; i < XF; ++i) {
+        const float v = group4_sum(cs[i]);
+        const int m = cm0 + wm * 16 * XF + i * 16 + il;
+        if (g == 0 && m < p.M) p.cs_slabs[(int64_t)csplit * p.M + m] = v;
+      }
+    }
     char* st = smem + ((gs + NSTAGE - 1) % NSTAGE) * STAGE + wave * 4096;
 #pragma unroll
     for (int i = 0; i < XF; ++i) {

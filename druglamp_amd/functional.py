@@ -173,23 +173,15 @@ class TransformerBlockFn(torch.autograd.Function):
             dy = dout[s].reshape(M, d)
             s1, s2 = seeds[s]
             g2 = ops.dropout_apply(dy, p_eff, s2) if p_eff > 0 else dy
-            dw2 = ops.gemm(g2, act, M=d, N=4 * d, K=M, x_kslow=True, w_kslow=True, ldx=d, ldw=4 * d,
-                           out_dtype=torch.float32, split_k=0)
-            db2 = ops.colsum(g2)
+            dw2, db2 = _wgrad(g2, act, d, 4 * d, M, d, 4 * d)
             g1 = ops.gemm(g2, w2, M=M, N=4 * d, K=d, dact_pre=pre, dropout_p=p_eff, seed=s1)
-            dw1 = ops.gemm(g1, hn, M=4 * d, N=d, K=M, x_kslow=True, w_kslow=True, ldx=4 * d, ldw=d,
-                           out_dtype=torch.float32, split_k=0)
-            db1 = ops.colsum(g1)
+            dw1, db1 = _wgrad(g1, hn, 4 * d, d, M, 4 * d, d)
             dhn = ops.gemm(g1, w1, M=M, N=d, K=4 * d)
             dx1, dg2, dbt2 = ops.layernorm_bwd(dhn, x1, mean2, rstd2, ln2w, dres=dy)
-            dwo = ops.gemm(dx1, f, M=d, N=d, K=M, x_kslow=True, w_kslow=True, ldx=d, ldw=d, out_dtype=torch.float32,
-                           split_k=0)
-            dbo = ops.colsum(dx1)
+            dwo, dbo = _wgrad(dx1, f, d, d, M, d, d)
             if paired:
                 df = ops.gemm(dx1, out_w, M=M, N=d, K=d)
-                dwf = ops.gemm(df, a[s], M=d, N=2 * d, K=M, x_kslow=True, w_kslow=True, ldx=d, ldw=2 * d,
-                               out_dtype=torch.float32, split_k=0)
-                dbf = ops.colsum(df)
+                dwf, dbf = _wgrad(df, a[s], d, 2 * d, M, d, 2 * d)
                 ops.gemm(df, fc_w, M=M, N=2 * d, K=d, out=da[s])
                 grads_tail.append((dwf, dbf, dwo, dbo, dg2, dbt2, dw1, db1, dw2, db2))
             else:
@@ -210,9 +202,7 @@ class TransformerBlockFn(torch.autograd.Function):
             (xn, mean1, rstd1, f, x1, hn, mean2, rstd2, pre, act, qkv_w, out_w, w1, w2, fc_w, ln1w, ln2w) = \
                 sv[4 + s * per: 4 + (s + 1) * per]
             g = dqkv[s]
-            dwqkv = ops.gemm(g, xn, M=3 * d, N=d, K=M, x_kslow=True, w_kslow=True, ldx=3 * d, ldw=d,
-                             out_dtype=torch.float32, split_k=0)
-            dbqkv = ops.colsum(g)
+            dwqkv, dbqkv = _wgrad(g, xn, 3 * d, d, M, 3 * d, d)
             dxn = ops.gemm(g, qkv_w, M=M, N=d, K=3 * d)
             _, dg1, dbt1 = ops.layernorm_bwd(dxn, x[s].reshape(M, d), mean1, rstd1, ln1w, dres=dx1_all[s],
                                              out=dx[s].reshape(M, d))
@@ -260,9 +250,11 @@ class LinearFn(torch.autograd.Function):
         if p_eff > 0:
             g = ops.dropout_apply(g, p_eff, seed)
         dx = ops.gemm(g, w, M=M, N=K, K=N, w_kslow=True, ldw=K).reshape(xshape) if ctx.needs_input_grad[0] else None
-        dw = ops.gemm(g, x2, M=N, N=K, K=M, x_kslow=True, w_kslow=True, ldx=N, ldw=K, out_dtype=torch.float32,
-                      split_k=0) if ctx.needs_input_grad[1] else None
-        db = ops.colsum(g) if (has_bias and ctx.needs_input_grad[2]) else None
+        want_b = has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            dw, db = _wgrad(g, x2, N, K, M, N, K, want_bias=want_b)
+        else:
+            dw, db = None, (ops.colsum(g) if want_b else None)
         dpe = None
         if pe_shape is not None and ctx.needs_input_grad[3]:
             dpe = ops.rowmod_sum(g, pe_shape[-2]).reshape(pe_shape)
@@ -359,9 +351,7 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
         Lq, Lk, B, E, H, scale, has_inb, has_outb = ctx.cfg
         hd = E // H
         g = dy.transpose(0, 1).contiguous().view(B * Lq, E)
-        dwo = ops.gemm(g, o, M=E, N=E, K=Lq * B, x_kslow=True, w_kslow=True, ldx=E, ldw=E, out_dtype=torch.float32,
-                       split_k=0)
-        dbo = ops.colsum(g) if has_outb else None
+        dwo, dbo = _wgrad(g, o, E, E, Lq * B, E, E, want_bias=has_outb)
         do = ops.gemm(g, ow, M=Lq * B, N=E, K=E, w_kslow=True, ldw=E)
         dqp = torch.empty_like(qp)
         dkv = torch.empty_like(kv)
@@ -370,12 +360,10 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
                      v_strides=(Lk * 2 * E, hd, 2 * E), o_strides=(Lq * E, hd, E), o_ss=0, do_strides=(Lq * E, hd, E),
                      do_ss=0, dq=dqp, dq_strides=(Lq * E, hd, E), dk=dkv, dk_strides=(Lk * 2 * E, hd, 2 * E),
                      dv=dkv[:, E:], dv_strides=(Lk * 2 * E, hd, 2 * E))
-        dwq = ops.gemm(dqp, q2, M=E, N=E, K=Lq * B, x_kslow=True, w_kslow=True, ldx=E, ldw=E, out_dtype=torch.float32,
-                       split_k=0)
-        dwkv = ops.gemm(dkv, k2, M=2 * E, N=E, K=Lk * B, x_kslow=True, w_kslow=True, ldx=2 * E, ldw=E,
-                        out_dtype=torch.float32, split_k=0)
+        dwq, dbq = _wgrad(dqp, q2, E, E, Lq * B, E, E, want_bias=has_inb)
+        dwkv, dbkv = _wgrad(dkv, k2, 2 * E, E, Lk * B, 2 * E, E, want_bias=has_inb)
         din_w = torch.cat((dwq, dwkv), dim=0)
-        din_b = torch.cat((ops.colsum(dqp), ops.colsum(dkv))) if has_inb else None
+        din_b = torch.cat((dbq, dbkv)) if has_inb else None
         dquery = ops.gemm(dqp, w[:E], M=Lq * B, N=E, K=E, w_kslow=True, ldw=E).view(B, Lq, E).transpose(0, 1)
         dkey = ops.gemm(dkv, w[E:], M=Lk * B, N=E, K=2 * E, w_kslow=True, ldw=E).view(B, Lk, E).transpose(0, 1)
         return dquery, dkey, din_w, din_b, dwo, dbo, None, None
@@ -414,9 +402,7 @@ class TokenGateFn(torch.autograd.Function):
                        split_k=0)
         db2 = ops.colsum(dl2)
         dpre = ops.gemm(dl2, lw2, M=M, N=dd, K=H, w_kslow=True, ldw=dd, dact_pre=pre)
-        dw1 = ops.gemm(dpre, v2, M=dd, N=D, K=M, x_kslow=True, w_kslow=True, ldx=dd, ldw=D, out_dtype=torch.float32,
-                       split_k=0)
-        db1 = ops.colsum(dpre)
+        dw1, db1 = _wgrad(dpre, v2, dd, D, M, dd, D)
         dv = ops.gemm(dpre, lw1, M=M, N=D, K=dd, w_kslow=True, ldw=D, residual=dv_gate.reshape(M, D))
         return dv.reshape(B, L, D), dw1, db1, dw2, db2, None, None
 
@@ -488,6 +474,14 @@ def attention_maps(x, blk, H: int, paired: bool):
 # ------------------------------------------------------------------------------------------------
 # loss Functions (fp32)
 # ------------------------------------------------------------------------------------------------
+def _wgrad(g, x, M, N, K, ldx, ldw, want_bias=True):
+    """dW[M][N] = g^T x over the K rows (fp32) and, from the same pass over g, db[M] = column sums of g."""
+    db = torch.empty(M, dtype=torch.float32, device=g.device) if want_bias else None
+    dw = ops.gemm(g, x, M=M, N=N, K=K, x_kslow=True, w_kslow=True, ldx=ldx, ldw=ldw, out_dtype=torch.float32,
+                  split_k=0, x_colsum=db)
+    return dw, db
+
+
 class CosRowLossFn(torch.autograd.Function):
     """mean over rows of 2 - 2 cos(x, y); y is a detached target (SimSiam, self_supervised_learning.py:184-187)."""
 
@@ -713,10 +707,13 @@ class DenseFn(torch.autograd.Function):
             g = ops.gelu_bwd(g, pre)
         dx = ops.gemm(g, w, M=M, N=Kp, K=Np, w_kslow=True, ldw=Kp).reshape(xshape) if ctx.needs_input_grad[0] else None
         dw = None
+        want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm(g, x2, M=Np, N=Kp, K=M, x_kslow=True, w_kslow=True, ldx=Np, ldw=Kp, out_dtype=torch.float32,
-                          split_k=0)[:N, :K]
-        db = ops.colsum(g)[:N] if (has_bias and ctx.needs_input_grad[2]) else None
+            dw, db = _wgrad(g, x2, Np, Kp, M, Np, Kp, want_bias=want_b)
+            dw = dw[:N, :K]
+            db = db[:N] if want_b else None
+        else:
+            db = ops.colsum(g)[:N] if want_b else None
         return dx, dw, db, dres, None
 
 

@@ -64,7 +64,7 @@ _ws2 = _Workspace()  # second buffer so that two scratch users can be live insid
 def gemm(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_kslow=False, w_kslow=False,
          ldx: Optional[int] = None, ldw: Optional[int] = None, bias=None, residual=None, res_row_mod=0,
          res_before_dropout=False, act=0, pre_out=None, dact_pre=None, dropout_p=0.0, seed=0, out=None,
-         out_dtype=None, accumulate=False, split_k=-1) -> torch.Tensor:
+         out_dtype=None, accumulate=False, split_k=-1, x_colsum=None) -> torch.Tensor:
     """C[M,N] = epilogue(sum_k X[m,k] W[n,k]); see include/druglamp_hip.h (dl_gemm)."""
     _need_gpu(x, w)
     L = _lib.lib()
@@ -93,6 +93,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_kslow=Fa
     a.dropout_seed = int(seed)
     a.accumulate = int(accumulate)
     a.split_k = split_k
+    a.x_colsum = _ptr(x_colsum)
     nbytes = L.dl_gemm_workspace_bytes(C.byref(a))
     if nbytes:
         ws = _ws.get(nbytes, x.device)

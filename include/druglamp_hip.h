@@ -77,6 +77,10 @@ typedef struct {
   float dropout_p; uint64_t dropout_seed;
   int32_t accumulate;
   int32_t split_k; void* workspace; size_t workspace_bytes;
+  float* x_colsum;                   /* weight-gradient form only (x_kslow && w_kslow, plain epilogue): also writes
+                                        x_colsum[m] = sum_k X[k][m], m < M (the bias gradient that accompanies
+                                        dW = dY^T x, reference nn.Linear backward) from the X fragments the kernel
+                                        streams anyway; fp32 [M] or NULL.  Counted in dl_gemm_workspace_bytes. */
 } dl_gemm_args;
 
 size_t dl_gemm_workspace_bytes(const dl_gemm_args* a);

@@ -117,3 +117,23 @@ def test_large_tile_weight_gradient_matches_fp64_and_the_128_tile_path(M, N, K, 
     for mode in ("0", "1"):
         assert (outs[mode][:96].double() - ref).abs().max() <= 5e-6 * scale, mode
     assert (outs["0"] - outs["1"]).abs().max() <= 1e-5 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,dt", [(1536, 512, 16384, torch.bfloat16), (256, 128, 8192, torch.bfloat16),
+                                      (768, 256, 4100, torch.bfloat16), (128, 80, 3000, torch.float32),
+                                      (128, 768, 262147, torch.bfloat16)])
+def test_weight_gradient_gemm_emits_bias_gradient(M, N, K, dt):
+    """x_colsum: the column sums of the K-slow X operand (bias gradient) come out of the same launch, for the
+    128-tile split-K kernel (DMA and register-staged, f32 and bf16) and the large-tile kernel."""
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(9)
+    dy = (torch.randn(K, M, generator=g) * 0.5).to(dt).cuda()
+    x = (torch.randn(K, N, generator=g) * 0.5).to(dt).cuda()
+    db = torch.full((M,), 123.0, device="cuda")
+    dw = ops.gemm(dy, x, M=M, N=N, K=K, x_kslow=True, w_kslow=True, ldx=M, ldw=N, out_dtype=torch.float32, split_k=0,
+                  x_colsum=db)
+    ref_db = dy.double().sum(0)
+    assert (db.double() - ref_db).abs().max() <= 2e-6 * max(1.0, float(ref_db.abs().max())) + 1e-3 * (dt == torch.bfloat16) * 0
+    ref = dy[:, :64].double().t() @ x.double()
+    assert (dw[:64].double() - ref).abs().max() <= 5e-6 * ref.abs().max()
