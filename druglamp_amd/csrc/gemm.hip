@@ -12,6 +12,7 @@
 // The MFMA is issued "swapped" (A = W fragment, B = X fragment) so each lane ends up holding 4
 // CONSECUTIVE output columns of one output row: 8-byte (bf16) / 16-byte (f32) stores.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.cuh"
 
 namespace {
@@ -151,7 +152,7 @@ __device__ __forceinline__ u32x4 read_frag(const char* lds, int rb, int kf, int 
 
 // EPI: 0 bias only | 1 general (all runtime flags) | 2 bias+pre_out+GELU(+dropout) | 3 bias(+dropout)+residual |
 //      4 gelu'(dact_pre)(+dropout) | 5 bias+ReLU.   EPI != 1 need N % 8 == 0 and take 16-byte accesses only.
-template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA, int EPI, int TW>
+template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA, int EPI, int TW, bool CS = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   constexpr bool SIMPLE = (EPI == 0);
   constexpr int BM = 32 * TW, BN = 32 * TW;
@@ -199,12 +200,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   for (int i = 0; i < TW; ++i)
 #pragma unroll
     for (int j = 0; j < TW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // weight-gradient form: the waves that own output columns 0..63 of the first column tile also sum their X
-  // fragments over k (bias gradient), one float per 16-row fragment
+  // CS (weight-gradient form with bias gradient): the waves that own columns 0..63 of the first column tile also
+  // sum their X fragments over k, one float per 16-row fragment.  The k loop exists in two copies selected by a
+  // wave-uniform branch OUTSIDE it, so the other waves' schedule is untouched (a branch inside the loop cost
+  // the plain kernel 60%, summing in every wave 20%).
   float cs[TW];
 #pragma unroll
   for (int i = 0; i < TW; ++i) cs[i] = 0.f;
-  const bool do_cs = SPLIT && XS && p.cs_slabs && n0 == 0 && wn == 0;
+  const bool do_cs = CS && n0 == 0 && wn == 0;
 
   const int nk = (kend - kbeg + BKE - 1) / BKE;
   if constexpr (XD) dma_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg, smem);
@@ -212,39 +215,45 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   if constexpr (WD) dma_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg, smem + TB);
   else store_tile<T, WS, TW>(smem + TB, rw);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    char* cur = smem + (kt & 1) * 2 * TB;
-    char* nxt = smem + ((kt + 1) & 1) * 2 * TB;
-    const bool more = (kt + 1 < nk);
-    if (more && !(p.dbg & 2)) {
-      if constexpr (XD) dma_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, nxt);
-      else load_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, kend, rx);
-      if constexpr (WD) dma_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, nxt + TB);
-      else load_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, kend, rw);
-    }
+  auto kloop = [&](auto with_cs) {
+    constexpr bool WCS = decltype(with_cs)::value;
+    for (int kt = 0; kt < nk; ++kt) {
+      char* cur = smem + (kt & 1) * 2 * TB;
+      char* nxt = smem + ((kt + 1) & 1) * 2 * TB;
+      const bool more = (kt + 1 < nk);
+      if (more && !(p.dbg & 2)) {
+        if constexpr (XD) dma_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, nxt);
+        else load_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, kend, rx);
+        if constexpr (WD) dma_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, nxt + TB);
+        else load_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, kend, rw);
+      }
 #pragma unroll
-    for (int kf = 0; kf < NFRAG; ++kf) {
-      u32x4 fx[TW], fw[TW];
+      for (int kf = 0; kf < NFRAG; ++kf) {
+        u32x4 fx[TW], fw[TW];
 #pragma unroll
-      for (int i = 0; i < TW; ++i) fx[i] = read_frag<T, XS, TW>(cur, wm * 16 * TW + i * 16, kf, il, g);
+        for (int i = 0; i < TW; ++i) fx[i] = read_frag<T, XS, TW>(cur, wm * 16 * TW + i * 16, kf, il, g);
 #pragma unroll
-      for (int j = 0; j < TW; ++j) fw[j] = read_frag<T, WS, TW>(cur + TB, wn * 16 * TW + j * 16, kf, il, g);
+        for (int j = 0; j < TW; ++j) fw[j] = read_frag<T, WS, TW>(cur + TB, wn * 16 * TW + j * 16, kf, il, g);
 #pragma unroll
-      for (int i = 0; i < TW; ++i)
+        for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < TW; ++j) acc[i][j] = Mma<T>::mma(fw[j], fx[i], acc[i][j]);
-      if constexpr (SPLIT && XS) {
-        if (do_cs) {
+          for (int j = 0; j < TW; ++j) acc[i][j] = Mma<T>::mma(fw[j], fx[i], acc[i][j]);
+        if constexpr (WCS) {
 #pragma unroll
           for (int i = 0; i < TW; ++i) cs[i] = frag_slot_sum<T>(fx[i], cs[i]);
         }
       }
+      if (more) {
+        if constexpr (!XD) store_tile<T, XS, TW>(nxt, rx);
+        if constexpr (!WD) store_tile<T, WS, TW>(nxt + TB, rw);
+      }
+      __syncthreads();
     }
-    if (more) {
-      if constexpr (!XD) store_tile<T, XS, TW>(nxt, rx);
-      if constexpr (!WD) store_tile<T, WS, TW>(nxt + TB, rw);
-    }
-    __syncthreads();
+  };
+  if constexpr (CS) {
+    if (do_cs) kloop(std::true_type{}); else kloop(std::false_type{});
+  } else {
+    kloop(std::false_type{});
   }
   // request the next output tile's first operand tiles now (registers only)
   const int cm0 = m0, cn0 = n0, csplit = split;
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
     if constexpr (!WD) load_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg, kend, rw);
   }
 
-  if constexpr (SPLIT && XS) {
+  if constexpr (CS) {
     if (do_cs) {
 #pragma unroll
       for (int i = 0; i < TW; ++i) {
@@ -572,8 +581,13 @@ int big_tt_plan(const dl_gemm_args* a, int* bm_out) {
 void launch_big_tt(const GemmP& p, hipStream_t s, int bm) {
   const uint32_t ntiles = (uint32_t)p.mt * p.nt * p.splits;
   const uint32_t nblocks = ntiles < 256u ? ntiles : 256u;
-  if (bm == 256) hipLaunchKernelGGL((gemm_big_tt_kernel<8, 2, 4>), dim3(nblocks), dim3(512), 0, s, p);
-  else hipLaunchKernelGGL((gemm_big_tt_kernel<4, 2, 4>), dim3(nblocks), dim3(512), 0, s, p);
+  if (p.cs_slabs) {
+    if (bm == 256) hipLaunchKernelGGL((gemm_big_tt_kernel<8, 2, 4, true>), dim3(nblocks), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemm_big_tt_kernel<4, 2, 4, true>), dim3(nblocks), dim3(512), 0, s, p);
+  } else {
+    if (bm == 256) hipLaunchKernelGGL((gemm_big_tt_kernel<8, 2, 4, false>), dim3(nblocks), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemm_big_tt_kernel<4, 2, 4, false>), dim3(nblocks), dim3(512), 0, s, p);
+  }
 }
 
 template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA>
@@ -584,6 +598,11 @@ void launch(const GemmP& p, hipStream_t s, int tw) {
 #define DL_LAUNCH(E) hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT, DMA, E, 4>), dim3(nblocks), dim3(NTHREADS), 0, s, p)
   if constexpr (SPLIT) {
     if constexpr (XS && WS) {
+      if (p.cs_slabs) {
+        if (tw == 2) hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT, DMA, 1, 2, true>), dim3(nblocks), dim3(NTHREADS), 0, s, p);
+        else hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT, DMA, 1, 4, true>), dim3(nblocks), dim3(NTHREADS), 0, s, p);
+        return;
+      }
       if (tw == 2) {
         hipLaunchKernelGGL((gemm_kernel<T, TO, XS, WS, SPLIT, DMA, 1, 2>), dim3(nblocks), dim3(NTHREADS), 0, s, p);
         return;

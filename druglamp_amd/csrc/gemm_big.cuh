@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_kernel(const GemmP
 // so K needs no alignment.
 __device__ __attribute__((aligned(16))) const uint32_t dl_zero_page[4] = {0u, 0u, 0u, 0u};
 
-template <int XF, int NWM, int NWN>
+template <int XF, int NWM, int NWN, bool CS>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const GemmP p) {
   typedef bf16_t T;
   constexpr int WF = 4, KS = 64, NSTAGE = 2;
@@ -332,8 +332,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
     float cs[XF];
 #pragma unroll
     for (int i = 0; i < XF; ++i) cs[i] = 0.f;
-    const bool do_cs = p.cs_slabs && n0 == 0 && wn == 0;   // bias gradient: sum of the X fragments over k
+    const bool do_cs = CS && n0 == 0 && wn == 0;           // bias gradient: sum of the X fragments over k (two copies of the k loop, wave-uniform choice)
     const int nk = (kend - kbeg + KS - 1) / KS;
+    auto kloop = [&](auto with_cs) {
+    constexpr bool WCS = decltype(with_cs)::value;
     for (int kt = 0; kt < nk; ++kt) {
       wait_vmcnt<0>();
       wg_barrier();
@@ -359,9 +361,15 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
         if (nread == 2) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         else if (nread == 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, WF, 0);
-        if (do_cs) cs[u % XF] = frag_slot_sum<T>(fx[u], cs[u % XF]);
+        if constexpr (WCS) cs[u % XF] = frag_slot_sum<T>(fx[u], cs[u % XF]);
       }
       ++gs;
+    }
+    };
+    if constexpr (CS) {
+      if (do_cs) kloop(std::true_type{}); else kloop(std::false_type{});
+    } else {
+      kloop(std::false_type{});
     }
 
     const int cm0 = m0, cn0 = n0, csplit = split;
