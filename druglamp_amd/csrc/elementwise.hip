@@ -168,6 +168,57 @@ __global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, in
   }
 }
 
+// ---------------- weight preparation: many fp32 master tensors -> compute-dtype (transposed) copies ------
+// One launch refreshes every low-precision / transposed weight image of the model after an optimiser step.
+// block_map[b] = (item, tile): a 64x64 tile of item.src [rows][cols]; plain items land at
+// dst[(row0 + r) * ld + c], transposed items at dst[c * ld + row0 + r] (row0 lets several parameters share one
+// concatenated image, e.g. q|k|v).
+template <typename TD>
+__global__ __launch_bounds__(256) void weight_prep_kernel(const dl_wprep_item* __restrict__ items,
+                                                          const int32_t* __restrict__ block_map) {
+  __shared__ float tile[64][65];
+  const dl_wprep_item it = items[block_map[2 * blockIdx.x]];
+  const int tcols = (it.cols + 63) / 64;
+  const int t = block_map[2 * blockIdx.x + 1];
+  const int r0 = (t / tcols) * 64, c0 = (t % tcols) * 64;
+  const int tid = threadIdx.x, tr = tid >> 4, tc4 = (tid & 15) * 4;
+  TD* dst = reinterpret_cast<TD*>(it.dst);
+  const bool vec = (it.cols & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + tr + 16 * i, c = c0 + tc4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < it.rows) {
+      if (vec && c + 4 <= it.cols) v = *reinterpret_cast<const f32x4*>(it.src + (int64_t)r * it.cols + c);
+      else for (int e = 0; e < 4; ++e) if (c + e < it.cols) v[e] = it.src[(int64_t)r * it.cols + c + e];
+    }
+    if (!it.transpose) {
+      if (r < it.rows) {
+        TD* d = dst + (int64_t)(it.row0 + r) * it.ld + c;
+        if (c + 4 <= it.cols && (it.ld & 3) == 0 && (((uintptr_t)dst) & 15) == 0) store4<TD>(d, v);
+        else for (int e = 0; e < 4; ++e) if (c + e < it.cols) d[e] = from_f32<TD>(v[e]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[tr + 16 * i][tc4 + e] = v[e];
+    }
+  }
+  if (!it.transpose) return;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + tr + 16 * i, r = r0 + tc4;      // output row = source column
+    if (c < it.cols) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = tile[tc4 + e][tr + 16 * i];
+      TD* d = dst + (int64_t)c * it.ld + it.row0 + r;
+      if (r + 4 <= it.rows && (it.ld & 3) == 0 && (it.row0 & 3) == 0 && (((uintptr_t)dst) & 15) == 0) store4<TD>(d, v);
+      else for (int e = 0; e < 4; ++e) if (r + e < it.rows) d[e] = from_f32<TD>(v[e]);
+    }
+  }
+}
+
 // out[l][d] (+)= sum_b x[(b*L + l)][d]
 template <typename T>
 __global__ void rowmod_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int D, int64_t L,
@@ -359,6 +410,19 @@ extern "C" int dl_cast(const void* src, int32_t sdt, void* dst, int32_t ddt, int
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
   else { dl_set_error("dl_cast: bad dtypes"); return DL_ERR_ARG; }
   DL_CHECK_LAUNCH("dl_cast");
+  return DL_OK;
+}
+
+extern "C" int dl_weight_prep(const dl_wprep_item* items_dev, const int32_t* block_map_dev, int32_t n_blocks,
+                              int32_t out_dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(items_dev && block_map_dev && n_blocks > 0, DL_ERR_ARG, "dl_weight_prep: bad args");
+  if (out_dtype == DL_BF16)
+    hipLaunchKernelGGL((weight_prep_kernel<bf16_t>), dim3((uint32_t)n_blocks), dim3(256), 0, s, items_dev, block_map_dev);
+  else if (out_dtype == DL_F32)
+    hipLaunchKernelGGL((weight_prep_kernel<float>), dim3((uint32_t)n_blocks), dim3(256), 0, s, items_dev, block_map_dev);
+  else { dl_set_error("dl_weight_prep: bad out_dtype"); return DL_ERR_ARG; }
+  DL_CHECK_LAUNCH("dl_weight_prep");
   return DL_OK;
 }
 

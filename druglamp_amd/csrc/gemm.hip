@@ -461,7 +461,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
 // out[idx] (+)= sum_z slabs[z][idx]
 template <typename TO>
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, TO* __restrict__ out,
-                                     int64_t mn, int64_t ldc, int N, int splits, int accumulate) {
+                                     int64_t mn, int64_t ldc, int N, int splits, int accumulate,
+                                     const float* __restrict__ cs_slabs, float* __restrict__ cs_out, int M, uint32_t main_blocks) {
+  if (blockIdx.x >= main_blocks) {
+    // trailing workgroups: x_colsum[m] = sum_z cs_slabs[z][m]
+    const int m = (int)(blockIdx.x - main_blocks) * blockDim.x + threadIdx.x;
+    if (m < M) {
+      float a0 = 0.f, a1 = 0.f;
+      int z = 0;
+      for (; z + 1 < splits; z += 2) { a0 += cs_slabs[(int64_t)z * M + m]; a1 += cs_slabs[(int64_t)(z + 1) * M + m]; }
+      if (z < splits) a0 += cs_slabs[(int64_t)z * M + m];
+      cs_out[m] = a0 + a1;
+    }
+    return;
+  }
   const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 >= mn) return;
   // four independent accumulators keep 4 slab loads in flight per thread (fixed order -> deterministic)
@@ -756,21 +769,18 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
     dl_prof_after(0, s, flops, bytes);
   }
   if (slab_path) {
-    if (a->x_colsum) {
-      hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((a->M + 63) / 64)), dim3(1024), 0, s,
-                         (const float*)p.cs_slabs, sp, (int64_t)a->M, (int)a->M, a->x_colsum, 0);
-    }
     const int64_t mn = a->M * a->N;
     const int threads = 256;
     const int64_t blocks = (mn / 4 + threads - 1) / threads;
+    const int64_t cs_blocks = a->x_colsum ? (a->M + threads - 1) / threads : 0;   // column sums ride along
     if (a->out_dtype == DL_F32)
-      hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((uint32_t)blocks), dim3(threads), 0, s,
+      hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((uint32_t)(blocks + cs_blocks)), dim3(threads), 0, s,
                          (const float*)a->workspace, (float*)a->C, mn, a->ldc, (int)a->N, sp,
-                         a->accumulate);
+                         a->accumulate, (const float*)p.cs_slabs, a->x_colsum, (int)a->M, (uint32_t)blocks);
     else
-      hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((uint32_t)blocks), dim3(threads), 0, s,
+      hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((uint32_t)(blocks + cs_blocks)), dim3(threads), 0, s,
                          (const float*)a->workspace, (bf16_t*)a->C, mn, a->ldc, (int)a->N, sp,
-                         a->accumulate);
+                         a->accumulate, (const float*)p.cs_slabs, a->x_colsum, (int)a->M, (uint32_t)blocks);
     DL_CHECK_LAUNCH("dl_gemm(split reduce)");
   }
   return DL_OK;

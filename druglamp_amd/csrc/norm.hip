@@ -185,12 +185,18 @@ extern "C" int dl_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
   else { if (nvg <= 1) LN_BWD(float, 1); else if (nvg <= 2) LN_BWD(float, 2); else if (nvg <= 4) LN_BWD(float, 4); else LN_BWD(float, 8); }
 #undef LN_BWD
   DL_CHECK_LAUNCH("dl_layernorm_bwd");
-  if (dgamma)
-    hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(1024), 0, s,
-                       (const float*)workspace, nb, (int64_t)(2 * D), (int)D, dgamma, accumulate);
-  if (dbeta)
-    hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(1024), 0, s,
-                       (const float*)workspace + D, nb, (int64_t)(2 * D), (int)D, dbeta, accumulate);
+  if (dgamma && dbeta == dgamma + D) {
+    // adjacent outputs ([2][D]): the partials' [2][D] rows reduce in one launch
+    hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((2 * D + 63) / 64)), dim3(1024), 0, s,
+                       (const float*)workspace, nb, (int64_t)(2 * D), (int)(2 * D), dgamma, accumulate);
+  } else {
+    if (dgamma)
+      hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(1024), 0, s,
+                         (const float*)workspace, nb, (int64_t)(2 * D), (int)D, dgamma, accumulate);
+    if (dbeta)
+      hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(1024), 0, s,
+                         (const float*)workspace + D, nb, (int64_t)(2 * D), (int)D, dbeta, accumulate);
+  }
   DL_CHECK_LAUNCH("dl_layernorm_bwd(final)");
   return DL_OK;
 }

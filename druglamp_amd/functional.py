@@ -26,40 +26,114 @@ from . import ops
 # compute-dtype copies of fp32 master parameters, cached per optimiser epoch
 # ------------------------------------------------------------------------------------------------
 _param_epoch = 0
-_lowp_cache = {}
+_lowp_cache = {}            # key -> _LowpEntry
+_lowp_tables = {}           # (device, dtype) -> (signature, items_dev, block_map_dev, n_blocks)
+_derived_cache = {}         # conv-weight layouts etc.: recomputed per optimiser epoch (small)
 
 
 def bump_param_epoch() -> None:
-    """Call after parameters were modified through raw pointers (the fused AdamW kernel)."""
+    """Call after parameters were modified through raw pointers (the fused AdamW kernel).  Images are kept and
+    refreshed in place — all of them by ONE dl_weight_prep launch — at the next lowp() call."""
     global _param_epoch
     _param_epoch += 1
-    _lowp_cache.clear()
 
 
-def lowp(params: Sequence[torch.Tensor], dtype: torch.dtype, transpose: bool = False) -> torch.Tensor:
-    """Compute-dtype tensor holding cat(params, dim=0) (a single param is returned as is in fp32).
-    transpose=True gives the [in][out] copy used by the data-gradient products, so that those are
-    K-contiguous GEMMs too (both operands then stream into LDS by DMA).
+class _LowpEntry:
+    __slots__ = ("refs", "transpose", "dtype", "image", "versions", "epoch", "planned", "pad")
 
-    Cached per (parameter objects, their versions, optimiser epoch).  Entries hold WEAK references and
-    are validated by identity: a Python id can be reused by a new tensor once the old model is gone."""
-    key = (tuple(id(p) for p in params) + (("T",) if transpose else ()), dtype)
-    ver = (_param_epoch,) + tuple(p._version for p in params)
-    hit = _lowp_cache.get(key)
-    if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
-        return hit[1]
+    def __init__(self, params, transpose, dtype, image, planned, pad=None):
+        self.refs = tuple(weakref.ref(p) for p in params)
+        self.transpose, self.dtype, self.image, self.planned, self.pad = transpose, dtype, image, planned, pad
+        self.versions = tuple(p._version for p in params)
+        self.epoch = _param_epoch
+
+    def params(self):
+        ps = tuple(r() for r in self.refs)
+        return None if any(p is None for p in ps) else ps
+
+
+def _build_image(params, dtype, transpose, pad=None):
     with torch.no_grad():
         w = params[0].detach() if len(params) == 1 else torch.cat([p.detach() for p in params], dim=0)
+        if pad is not None:
+            g = torch.zeros(pad, dtype=w.dtype, device=w.device)
+            g[:w.shape[0], :w.shape[1]] = w
+            w = g
         if transpose:
             w = w.t().contiguous()
         if w.dtype != dtype:
             w = ops.cast(w, dtype)
         elif not w.is_contiguous():
             w = w.contiguous()
+    return w
+
+
+def _refresh_all_images() -> None:
+    """Re-derive every planned image from the current fp32 masters: one dl_weight_prep launch per (device, dtype)."""
+    import numpy as np
+    groups = {}
+    for key in list(_lowp_cache.keys()):
+        e = _lowp_cache[key]
+        ps = e.params()
+        if ps is None:
+            del _lowp_cache[key]
+            continue
+        if not e.planned:
+            e.image = _build_image(ps, e.dtype, e.transpose, e.pad)
+            e.versions, e.epoch = tuple(p._version for p in ps), _param_epoch
+            continue
+        groups.setdefault((ps[0].device, e.dtype), []).append((e, ps))
+    item_t = np.dtype([("src", "<u8"), ("dst", "<u8"), ("ld", "<i8"), ("rows", "<i4"), ("cols", "<i4"),
+                       ("row0", "<i4"), ("transpose", "<i4")])
+    for gkey, lst in groups.items():
+        tab = _lowp_tables.get(gkey)
+        sig = tuple(id(e) for e, _ in lst) + tuple(p.data_ptr() for _, ps in lst for p in ps)
+        if tab is None or tab[0] != sig:
+            items, bmap = [], []
+            for e, ps in lst:
+                total = sum(p.shape[0] for p in ps)
+                row0 = 0
+                for p_ in ps:
+                    r, c = p_.shape
+                    ld = e.image.shape[1]                      # [rows][cols] image, or [cols][rows] when transposed
+                    items.append((p_.data_ptr(), e.image.data_ptr(), ld, r, c, row0, 1 if e.transpose else 0))
+                    ntile = ((r + 63) // 64) * ((c + 63) // 64)
+                    bmap.extend((len(items) - 1, t) for t in range(ntile))
+                    row0 += r
+            items_np = np.array(items, dtype=item_t)
+            items_dev = torch.from_numpy(items_np.view(np.uint8).copy()).to(gkey[0])
+            bmap_dev = torch.tensor(bmap, dtype=torch.int32).reshape(-1).to(gkey[0])
+            tab = (sig, items_dev, bmap_dev, len(bmap))
+            _lowp_tables[gkey] = tab
+        ops.weight_prep(tab[1], tab[2], tab[3], gkey[1])
+        for e, ps in lst:
+            e.versions, e.epoch = tuple(p._version for p in ps), _param_epoch
+
+
+def lowp(params: Sequence[torch.Tensor], dtype: torch.dtype, transpose: bool = False, pad=None) -> torch.Tensor:
+    """Compute-dtype tensor holding cat(params, dim=0) (a single fp32 param is returned as is in fp32).
+    transpose=True gives the [in][out] copy used by the data-gradient products, so that those are
+    K-contiguous GEMMs too (both operands then stream into LDS by DMA).
+
+    Images live at fixed addresses for the life of the parameters.  When the masters change (optimiser epoch or
+    tensor version) the FIRST lowp() call refreshes every image of the model with one dl_weight_prep launch.
+    Entries hold WEAK references and are validated by identity: a Python id can be reused by a new tensor once
+    the old model is gone."""
+    if len(params) == 1 and not transpose and pad is None and params[0].dtype == dtype:
+        return params[0].detach()
+    key = (tuple(id(p) for p in params) + (("T",) if transpose else ()) + (("pad",) + tuple(pad) if pad else ()), dtype)
+    e = _lowp_cache.get(key)
+    if e is not None and all(r() is p for r, p in zip(e.refs, params)):
+        if e.epoch != _param_epoch or e.versions != tuple(p._version for p in params):
+            _refresh_all_images()
+        return e.image
+    planned = all(p.dim() == 2 and p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda for p in params)
     if len(_lowp_cache) > 4096:
         _lowp_cache.clear()
-    _lowp_cache[key] = (ver, w, tuple(weakref.ref(p) for p in params))
-    return w
+        _lowp_tables.clear()
+    image = _build_image(params, dtype, transpose, pad)
+    _lowp_cache[key] = _LowpEntry(params, transpose, dtype, image, planned, pad)
+    return image
 
 
 def _f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -552,7 +626,7 @@ def _conv_weight(w: torch.Tensor, dtype: torch.dtype, backward: bool) -> torch.T
     backward: Wd[ci][j'*co + o] = w[o][ci][k-1-j']   (data gradient = correlation with the flipped kernel)"""
     key = ((id(w), "convb" if backward else "convf"), dtype)
     ver = (_param_epoch, w._version)
-    hit = _lowp_cache.get(key)
+    hit = _derived_cache.get(key)
     if hit is not None and hit[0] == ver and hit[2][0]() is w:
         return hit[1]
     with torch.no_grad():
@@ -564,7 +638,9 @@ def _conv_weight(w: torch.Tensor, dtype: torch.dtype, backward: bool) -> torch.T
         g = g.contiguous()
         if g.dtype != dtype:
             g = ops.cast(g, dtype)
-    _lowp_cache[key] = (ver, g, (weakref.ref(w),))
+    if len(_derived_cache) > 1024:
+        _derived_cache.clear()
+    _derived_cache[key] = (ver, g, (weakref.ref(w),))
     return g
 
 
@@ -658,19 +734,8 @@ class ProteinCNNFn(torch.autograd.Function):
 # feature widths (641 -> 648, 385 -> 392) to the 16-byte granularity of the MFMA operand loaders
 # ------------------------------------------------------------------------------------------------
 def _padded_weight(w: torch.Tensor, Np: int, Kp: int, dtype: torch.dtype) -> torch.Tensor:
-    key = ((id(w), "pad", Np, Kp), dtype)
-    ver = (_param_epoch, w._version)
-    hit = _lowp_cache.get(key)
-    if hit is not None and hit[0] == ver and hit[2][0]() is w:
-        return hit[1]
-    with torch.no_grad():
-        N, K = w.shape
-        g = torch.zeros((Np, Kp), dtype=w.dtype, device=w.device)
-        g[:N, :K] = w.detach()
-        if g.dtype != dtype:
-            g = ops.cast(g, dtype)
-    _lowp_cache[key] = (ver, g, (weakref.ref(w),))
-    return g
+    """[Np][Kp] zero-padded compute-dtype image of w [N][K] (padding written once, body refreshed with the rest)."""
+    return lowp((w,), dtype, pad=(Np, Kp))
 
 
 class DenseFn(torch.autograd.Function):

@@ -131,8 +131,10 @@ def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dres=None, need_param_grads=True
     L = _lib.lib()
     M, D = x2d.shape
     dx = torch.empty_like(x2d) if out is None else out
-    dgamma = torch.empty(D, dtype=torch.float32, device=x2d.device) if need_param_grads else None
-    dbeta = torch.empty(D, dtype=torch.float32, device=x2d.device) if need_param_grads else None
+    dgamma = dbeta = None
+    if need_param_grads:
+        gb = torch.empty((2, D), dtype=torch.float32, device=x2d.device)   # adjacent: one final-reduction launch
+        dgamma, dbeta = gb[0], gb[1]
     ws = _ws.get(L.dl_layernorm_bwd_workspace_bytes(M, D), x2d.device)
     check(L.dl_layernorm_bwd(dy2d.data_ptr(), dy2d.stride(0), x2d.data_ptr(), x2d.stride(0), mean.data_ptr(),
                              rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), 0 if dres is None else dres.stride(0),
@@ -378,3 +380,10 @@ def fill_pool(x: torch.Tensor, site_len: int, out_dtype: torch.dtype):
     check(_lib.lib().dl_fill_pool(x.data_ptr(), fill.data_ptr(), pooled.data_ptr(), B, S, F, site_len, _dt(x),
                                   _DT[out_dtype], _stream()), "dl_fill_pool")
     return fill, pooled
+
+
+def weight_prep(items_dev: torch.Tensor, block_map_dev: torch.Tensor, n_blocks: int, out_dtype: torch.dtype) -> None:
+    """One launch over a device-side list of (fp32 master -> image) copies; see dl_weight_prep."""
+    _need_gpu(items_dev, block_map_dev)
+    check(_lib.lib().dl_weight_prep(items_dev.data_ptr(), block_map_dev.data_ptr(), int(n_blocks), _DT[out_dtype],
+                                    _stream()), "dl_weight_prep")

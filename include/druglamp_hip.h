@@ -220,6 +220,21 @@ int dl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dt
 /* dst(bf16|f32) = src(f32|bf16) elementwise cast (weight casts, master fp32 -> compute dtype). */
 int dl_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n,
             dl_stream s);
+/* Weight preparation: ONE launch refreshes every compute-dtype (and transposed) image of the fp32 master
+ * parameters after an optimiser step — the per-parameter `.to(dtype)` / `.t().contiguous()` / `cat(q,k,v)` copies
+ * a torch implementation of the reference's modules makes implicitly, batched.  items / block_map are DEVICE
+ * arrays built once by the host: block_map[2b] = item index, block_map[2b+1] = 64x64 tile index in that item.
+ * plain item : dst[(row0 + r) * ld + c] = src[r][c];   transposed item : dst[c * ld + row0 + r] = src[r][c]. */
+typedef struct dl_wprep_item {
+  const float* src;        /* fp32 master parameter, [rows][cols] contiguous */
+  void* dst;               /* image base (out_dtype) */
+  int64_t ld;              /* image leading dimension in elements */
+  int32_t rows, cols;
+  int32_t row0;            /* offset of this parameter inside a concatenated image */
+  int32_t transpose;
+} dl_wprep_item;
+int dl_weight_prep(const dl_wprep_item* items_dev, const int32_t* block_map_dev, int32_t n_blocks,
+                   int32_t out_dtype, dl_stream s);
 /* out[d] (+)= sum over rows r of x[r][d] where rows are grouped by (r % L): pe gradients. */
 int dl_rowmod_sum(const void* x, float* out, int64_t M, int64_t D, int64_t L, int32_t accumulate,
                   int32_t dtype, dl_stream s);

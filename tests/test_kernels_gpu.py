@@ -137,3 +137,34 @@ def test_weight_gradient_gemm_emits_bias_gradient(M, N, K, dt):
     assert (db.double() - ref_db).abs().max() <= 2e-6 * max(1.0, float(ref_db.abs().max())) + 1e-3 * (dt == torch.bfloat16) * 0
     ref = dy[:, :64].double().t() @ x.double()
     assert (dw[:64].double() - ref).abs().max() <= 5e-6 * ref.abs().max()
+
+
+@pytest.mark.gpu
+def test_weight_images_are_refreshed_in_place_by_one_launch():
+    """lowp(): compute-dtype / transposed / concatenated weight images keep their addresses and follow the fp32
+    masters after bump_param_epoch() (ragged shapes included)."""
+    from druglamp_amd import functional as Fn
+    g = torch.Generator().manual_seed(2)
+    ps = [torch.nn.Parameter(torch.randn(r, c, generator=g).cuda()) for r, c in [(128, 256), (75, 128), (256, 641), (64, 256), (192, 256)]]
+    def expect(params, dt, tr):
+        w = torch.cat([p.detach() for p in params], 0)
+        return (w.t() if tr else w).to(dt)
+    reqs = [((ps[0],), torch.bfloat16, False), ((ps[0],), torch.bfloat16, True), ((ps[1],), torch.bfloat16, True),
+            ((ps[2],), torch.bfloat16, False), ((ps[2],), torch.bfloat16, True), ((ps[0], ps[3], ps[4]), torch.bfloat16, False),
+            ((ps[0], ps[3], ps[4]), torch.bfloat16, True), ((ps[1],), torch.float32, True)]
+    imgs = [Fn.lowp(p, dt, tr) for p, dt, tr in reqs]
+    for (p, dt, tr), im in zip(reqs, imgs):
+        assert torch.equal(im, expect(p, dt, tr))
+    ptrs = [im.data_ptr() for im in imgs]
+    with torch.no_grad():
+        for p in ps:
+            p.mul_(1.5).add_(0.25)          # version bump
+    again = [Fn.lowp(p, dt, tr) for p, dt, tr in reqs]
+    assert [im.data_ptr() for im in again] == ptrs
+    for (p, dt, tr), im in zip(reqs, again):
+        assert torch.equal(im, expect(p, dt, tr))
+    for p in ps:                             # raw-pointer style update + epoch bump
+        p.data.copy_(torch.randn(p.shape, generator=g))
+    Fn.bump_param_epoch()
+    for (p, dt, tr) in reqs:
+        assert torch.equal(Fn.lowp(p, dt, tr), expect(p, dt, tr))
