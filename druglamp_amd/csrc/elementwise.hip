@@ -158,6 +158,90 @@ __global__ void fill_pool_kernel(const T* __restrict__ x, T* __restrict__ fill, 
   }
 }
 
+// ---------------- ProteinCNN tail: the reference's (B,C,L).view(B,L,C) + site pooling, in one pass -----------
+// z is the channel-last conv output with `halo` zero rows around every sample: z[b][halo + l][c].  The reference
+// holds the same values channel-first (mem[b][c*L + l]), REINTERPRETS that buffer as (B, L, C) and then averages
+// the S = site_len chunks of n_site rows: pooled[b][o] = 1/S sum_s mem[b][s*n_site*C + o], o = j*C + c'.
+// With L = S*n_site and o = n_site*q + r (q < C, r < n_site) this is
+//   pooled[b][n_site*q + r] = 1/S sum_s z[b][halo + n_site*((s*C + q) % S) + r][(s*C + q) / S],
+// so a workgroup that loads the S strips of RR rows {n_site*k + r0 .. + RR} (k < S) has every contribution to
+// its C*RR outputs.  Backward is the same index map read the other way (each z element feeds one output).
+constexpr int SP_RR = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void cnn_sitepool_fwd_kernel(const T* __restrict__ z, T* __restrict__ out, int L, int C,
+                                                                int halo, int S) {
+  extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+  T* strip = reinterpret_cast<T*>(sp_smem);                 // [S][RR][C]
+  const int n_site = L / S;
+  const int b = blockIdx.y, r0 = blockIdx.x * SP_RR, tid = threadIdx.x;
+  const int LP = L + 2 * halo;
+  const T* zb = z + (int64_t)b * LP * C;
+  const int cpr = C / 8;                                     // 16-byte chunks per row
+  for (int c = tid; c < S * SP_RR * cpr; c += 256) {
+    const int row = c / cpr, ch = c % cpr, k = row / SP_RR, i = row % SP_RR;
+    const int l = n_site * k + r0 + i;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r0 + i < n_site) v = *reinterpret_cast<const u32x4*>(zb + (int64_t)(halo + l) * C + ch * 8);
+    *reinterpret_cast<u32x4*>(strip + (int64_t)row * C + ch * 8) = v;
+  }
+  __syncthreads();
+  const float inv = 1.0f / (float)S;
+  // thread -> (q, half of the RR rows): 16 consecutive outputs
+  for (int w = tid; w < C * 2; w += 256) {
+    const int q = w >> 1, i0 = (w & 1) * (SP_RR / 2);
+    float acc[SP_RR / 2];
+#pragma unroll
+    for (int i = 0; i < SP_RR / 2; ++i) acc[i] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const int v = s * C + q, cc = v / S, k = v % S;
+      const T* src = strip + ((int64_t)k * SP_RR + i0) * C + cc;
+#pragma unroll
+      for (int i = 0; i < SP_RR / 2; ++i) acc[i] += to_f32(src[(int64_t)i * C]);
+    }
+    T* dst = out + (int64_t)b * L / S * C + (int64_t)n_site * q + r0 + i0;
+#pragma unroll
+    for (int i = 0; i < SP_RR / 2; ++i)
+      if (r0 + i0 + i < n_site) dst[i] = from_f32<T>(acc[i] * inv);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cnn_sitepool_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dz, int L, int C,
+                                                                int halo, int S) {
+  extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+  float* g = reinterpret_cast<float*>(sp_smem);              // [C][RR]
+  const int n_site = L / S;
+  const int b = blockIdx.y, r0 = blockIdx.x * SP_RR, tid = threadIdx.x;
+  const int LP = L + 2 * halo;
+  const float inv = 1.0f / (float)S;
+  const T* db = dout + (int64_t)b * n_site * C;
+  for (int e = tid; e < C * SP_RR; e += 256) {
+    const int q = e / SP_RR, i = e % SP_RR;
+    g[e] = (r0 + i < n_site) ? to_f32(db[(int64_t)n_site * q + r0 + i]) * inv : 0.f;
+  }
+  __syncthreads();
+  T* zb = dz + (int64_t)b * LP * C;
+  const int cpr = C / 8;
+  for (int c = tid; c < S * SP_RR * cpr; c += 256) {
+    const int row = c / cpr, ch = c % cpr, k = row / SP_RR, i = row % SP_RR;
+    if (r0 + i >= n_site) continue;
+    const int l = n_site * k + r0 + i;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = g[(((ch * 8 + e) * S + k) % C) * SP_RR + i];
+    T* dst = zb + (int64_t)(halo + l) * C + ch * 8;
+    store4<T>(dst, f32x4{v[0], v[1], v[2], v[3]});
+    store4<T>(dst + 4, f32x4{v[4], v[5], v[6], v[7]});
+  }
+  if (blockIdx.x == 0) {                                     // halo rows of this sample
+    for (int c = tid; c < 2 * halo * cpr; c += 256) {
+      const int hr = c / cpr, ch = c % cpr;
+      const int row = hr < halo ? hr : L + hr;               // top rows 0..halo-1, bottom rows halo+L..
+      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(zb + (int64_t)row * C + ch * 8)) = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+}
+
 template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
   const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -410,6 +494,41 @@ extern "C" int dl_cast(const void* src, int32_t sdt, void* dst, int32_t ddt, int
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
   else { dl_set_error("dl_cast: bad dtypes"); return DL_ERR_ARG; }
   DL_CHECK_LAUNCH("dl_cast");
+  return DL_OK;
+}
+
+static int sitepool_check(const char* who, const void* a, const void* b, int64_t B, int64_t L, int64_t C, int32_t halo,
+                          int32_t site_len, int32_t dtype) {
+  DL_CHECK_ARG(a && b && B > 0 && L > 0 && C > 0 && halo >= 0 && site_len > 0, DL_ERR_ARG, "%s: bad args", who);
+  DL_CHECK_ARG(L % site_len == 0 && C % 8 == 0 && dtype == DL_BF16, DL_ERR_SHAPE,
+               "%s: needs L %% site_len == 0, C %% 8 == 0, bf16 (the fp32 pipelines take the torch formulation)", who);
+  DL_CHECK_ARG((int64_t)site_len * SP_RR * C * 2 <= 160 * 1024 && B <= 65535, DL_ERR_SHAPE, "%s: strip does not fit LDS", who);
+  return DL_OK;
+}
+extern "C" int dl_cnn_sitepool_fwd(const void* z, void* pooled, int64_t B, int64_t L, int64_t C, int32_t halo,
+                                   int32_t site_len, int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int rc = sitepool_check("dl_cnn_sitepool_fwd", z, pooled, B, L, C, halo, site_len, dtype);
+  if (rc != DL_OK) return rc;
+  const int n_site = (int)(L / site_len);
+  const size_t lds = (size_t)site_len * SP_RR * C * 2;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)cnn_sitepool_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL((cnn_sitepool_fwd_kernel<bf16_t>), dim3((uint32_t)((n_site + SP_RR - 1) / SP_RR), (uint32_t)B), dim3(256), lds, s,
+                     (const bf16_t*)z, (bf16_t*)pooled, (int)L, (int)C, (int)halo, (int)site_len);
+  DL_CHECK_LAUNCH("dl_cnn_sitepool_fwd");
+  return DL_OK;
+}
+extern "C" int dl_cnn_sitepool_bwd(const void* dpooled, void* dz, int64_t B, int64_t L, int64_t C, int32_t halo,
+                                   int32_t site_len, int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int rc = sitepool_check("dl_cnn_sitepool_bwd", dpooled, dz, B, L, C, halo, site_len, dtype);
+  if (rc != DL_OK) return rc;
+  const int n_site = (int)(L / site_len);
+  const size_t lds = (size_t)C * SP_RR * sizeof(float);
+  hipLaunchKernelGGL((cnn_sitepool_bwd_kernel<bf16_t>), dim3((uint32_t)((n_site + SP_RR - 1) / SP_RR), (uint32_t)B), dim3(256), lds, s,
+                     (const bf16_t*)dpooled, (bf16_t*)dz, (int)L, (int)C, (int)halo, (int)site_len);
+  DL_CHECK_LAUNCH("dl_cnn_sitepool_bwd");
   return DL_OK;
 }
 

@@ -652,7 +652,7 @@ class ProteinCNNFn(torch.autograd.Function):
     elementwise pass that also re-zeroes the halo rows.  Returns (z [B, L, C] view, batch mean/var x3)."""
 
     @staticmethod
-    def forward(ctx, x, training, eps, *params):
+    def forward(ctx, x, training, eps, pool_site_len, *params):
         B, LP, C = x.shape
         Lv = LP - 2 * _CNN_HALO
         R = B * LP
@@ -682,24 +682,31 @@ class ProteinCNNFn(torch.autograd.Function):
             meta.append((k, pl, w))
             cur = z
         ctx.save_for_backward(*saved)
-        ctx.cfg = (B, LP, C, Lv, training)
+        ctx.cfg = (B, LP, C, Lv, training, pool_site_len)
         ctx.weights = [m[2] for m in meta]
-        out = cur.reshape(B, LP, C)[:, _CNN_HALO:_CNN_HALO + Lv]
+        if pool_site_len:
+            # the reference's (B,C,L).view(B,L,C) reinterpretation + site pooling, straight from the padded buffer
+            out = ops.cnn_sitepool_fwd(cur.reshape(B, LP, C), Lv, _CNN_HALO, pool_site_len)
+        else:
+            out = cur.reshape(B, LP, C)[:, _CNN_HALO:_CNN_HALO + Lv]
         ctx.mark_non_differentiable(*stats_out)
         return (out,) + tuple(stats_out)
 
     @staticmethod
     def backward(ctx, dout, *_):
-        B, LP, C, Lv, training = ctx.cfg
+        B, LP, C, Lv, training, pool_site_len = ctx.cfg
         if not training:
             raise RuntimeError("ProteinCNNFn.backward is only implemented for training-mode BatchNorm")
         sv = ctx.saved_tensors
         R = B * LP
         n = B * Lv
         cdt = sv[0].dtype
-        dz = torch.zeros((B, LP, C), dtype=cdt, device=dout.device)
-        dz[:, _CNN_HALO:_CNN_HALO + Lv] = dout
-        dz = dz.reshape(R, C)
+        if pool_site_len:
+            dz = ops.cnn_sitepool_bwd(dout, Lv, _CNN_HALO, pool_site_len).reshape(R, C)
+        else:
+            dz = torch.zeros((B, LP, C), dtype=cdt, device=dout.device)
+            dz[:, _CNN_HALO:_CNN_HALO + Lv] = dout
+            dz = dz.reshape(R, C)
         grads = [None] * 18
         for i in (2, 1, 0):
             xin, y, mean, rstd, gamma = sv[i * 5:(i + 1) * 5]
@@ -710,10 +717,10 @@ class ProteinCNNFn(torch.autograd.Function):
             Mg = R - (k - 1)
             sums = ops.bn_bwd_reduce(dz, y, mean, rstd, LP, _CNN_HALO, Lv)
             dpre = ops.bn_bwd_apply(dz, y, mean, rstd, gamma, sums, 1.0 / n, True, LP, _CNN_HALO, Lv)
-            dWg = ops.gemm(dpre[pl:pl + Mg], xin, M=C, N=k * C, K=Mg, x_kslow=True, w_kslow=True, ldx=C, ldw=C,
-                           out_dtype=torch.float32, split_k=0)
+            # rows outside [pl, pl + Mg) are halo rows (zero in dpre), so the bias gradient can ride along
+            dWg, dbias = _wgrad(dpre[pl:pl + Mg], xin, C, k * C, Mg, C, C)
             grads[i * 6 + 0] = dWg.reshape(C, k, C).permute(0, 2, 1).contiguous()
-            grads[i * 6 + 1] = ops.colsum(dpre)
+            grads[i * 6 + 1] = dbias
             grads[i * 6 + 2] = sums[C:].clone()
             grads[i * 6 + 3] = sums[:C].clone()
             if i > 0 or ctx.needs_input_grad[0]:
@@ -725,7 +732,7 @@ class ProteinCNNFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.zeros((B, LP, C), dtype=cdt, device=dout.device)
             dx[:, _CNN_HALO:_CNN_HALO + Lv] = dz.reshape(B, LP, C)[:, _CNN_HALO:_CNN_HALO + Lv]
-        return (dx, None, None) + tuple(grads)
+        return (dx, None, None, None) + tuple(grads)
 
 
 

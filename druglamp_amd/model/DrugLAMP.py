@@ -23,7 +23,7 @@ class DrugLAMP(DrugLAMPBase):
         # materialised by SSL.forward on SSL epochs only
         ssl = {"vp": vp, "xp": (xp, fill_p), "fill_bit_p": fill_p, "vd": vd, "xd": (xd, fill_d)}
         xp, xd = xps, xdp
-        vpf = self._site_pool(self.protein_extractor(vp, fill_p))
+        vpf = self.protein_extractor(vp, fill_p, site_pool=self.site_len)
         xpf, xdf = self._llm_adaptors(xp, xd)
         vpf, vdf = vpf.float(), vd.float()
         cp = {"prot": vpf, "aug_prot": xpf, "drug": vdf, "aug_drug": xdf} if self.two_c2p else None

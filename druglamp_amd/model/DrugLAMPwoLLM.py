@@ -11,7 +11,7 @@ class DrugLAMPwoLLM(DrugLAMPBase):
         vd = self.drug_extractor(vd)
         fill_p, _ = ops.fill_pool(xp, self.site_len, self.compute_dtype)
         ssl = {"vp": vp, "xp": None, "fill_bit_p": fill_p, "vd": vd, "xd": None, "p_mode": "vp"}
-        vpf = self._site_pool(self.protein_extractor(vp, fill_p))
+        vpf = self.protein_extractor(vp, fill_p, site_pool=self.site_len)
         vpf, vdf = vpf.float(), vd.float()
         mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpf, vdf)
         f, self.attn, self.guide_attn = self.pmma(mv, mv)

@@ -137,10 +137,12 @@ class ProteinCNN(nn.Module):
 
     compute_dtype = torch.float32
 
-    def forward(self, v, fill_mask):
+    def forward(self, v, fill_mask, site_pool=0):
         """Embedding lookup + fill bit are torch glue; the three Conv1d + ReLU + BatchNorm1d stages run as
         channel-last implicit GEMMs + BatchNorm kernels (functional.ProteinCNNFn).  The reference's final
-        `.view(B, L, C)` of the channel-first (B, C, L) buffer is reproduced exactly."""
+        `.view(B, L, C)` of the channel-first (B, C, L) buffer is reproduced exactly.  site_pool = site_len (> 0)
+        additionally applies the caller's site pooling (DrugLAMP.py:39-40) inside the same kernel and returns
+        (B, L // site_len, C)."""
         from ..functional import _CNN_HALO, EmbeddingFn, ProteinCNNFn, cast
         ids = v.long()
         w = self.embedding.weight
@@ -152,7 +154,8 @@ class ProteinCNN(nn.Module):
         params = []
         for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)):
             params += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        outs = ProteinCNNFn.apply(x, self.training, self.bn1.eps, *params)
+        fused_pool = int(site_pool) if (site_pool and x.dtype == torch.bfloat16 and L % int(site_pool) == 0) else 0
+        outs = ProteinCNNFn.apply(x, self.training, self.bn1.eps, fused_pool, *params)
         z = outs[0]
         if self.training:
             n = B * L
@@ -162,8 +165,12 @@ class ProteinCNN(nn.Module):
                     bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
                     bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
                     bn.num_batches_tracked += 1
-        z = z.transpose(1, 2).contiguous()                                          # (B, C, L) like the reference
-        return z.view(B, L, C)
+        if fused_pool:
+            return z
+        z = z.transpose(1, 2).contiguous().view(B, L, C)                            # (B, C, L) reinterpreted, like the reference
+        if site_pool:
+            z = z.view(B, int(site_pool), L // int(site_pool), C).mean(dim=1)
+        return z
 
 
 class FeedForwardLayer(nn.Module):

@@ -387,3 +387,23 @@ def weight_prep(items_dev: torch.Tensor, block_map_dev: torch.Tensor, n_blocks: 
     _need_gpu(items_dev, block_map_dev)
     check(_lib.lib().dl_weight_prep(items_dev.data_ptr(), block_map_dev.data_ptr(), int(n_blocks), _DT[out_dtype],
                                     _stream()), "dl_weight_prep")
+
+
+def cnn_sitepool_fwd(z: torch.Tensor, L: int, halo: int, site_len: int) -> torch.Tensor:
+    """z (B, L + 2*halo, C) channel-last -> pooled (B, L // site_len, C); see dl_cnn_sitepool_fwd."""
+    _need_gpu(z)
+    B, LP, C = z.shape
+    out = torch.empty((B, L // site_len, C), dtype=z.dtype, device=z.device)
+    check(_lib.lib().dl_cnn_sitepool_fwd(z.data_ptr(), out.data_ptr(), B, L, C, halo, site_len, _dt(z), _stream()),
+          "dl_cnn_sitepool_fwd")
+    return out
+
+
+def cnn_sitepool_bwd(dpooled: torch.Tensor, L: int, halo: int, site_len: int) -> torch.Tensor:
+    _need_gpu(dpooled)
+    dpooled = dpooled.contiguous()
+    B, _, C = dpooled.shape
+    dz = torch.empty((B, L + 2 * halo, C), dtype=dpooled.dtype, device=dpooled.device)
+    check(_lib.lib().dl_cnn_sitepool_bwd(dpooled.data_ptr(), dz.data_ptr(), B, L, C, halo, site_len, _dt(dpooled),
+                                         _stream()), "dl_cnn_sitepool_bwd")
+    return dz

@@ -220,6 +220,15 @@ int dl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dt
 /* dst(bf16|f32) = src(f32|bf16) elementwise cast (weight casts, master fp32 -> compute dtype). */
 int dl_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n,
             dl_stream s);
+/* ProteinCNN tail (model/basic_model.py:176-179 + DrugLAMP.py:39-40): the reference keeps the conv output
+ * channel-first (B, C, L), REINTERPRETS that buffer with .view(B, L, C) and then site-pools it
+ * (.view(B, site_len, n_site, C).mean(1)).  z is this library's channel-last conv output with `halo` zero rows
+ * around every sample, [B][L + 2*halo][C]; pooled is [B][L / site_len][C].  fwd reproduces view + mean exactly in
+ * one pass over z; bwd writes the full padded gradient dz (halo rows zeroed) from dpooled.  bf16 only. */
+int dl_cnn_sitepool_fwd(const void* z, void* pooled, int64_t B, int64_t L, int64_t C, int32_t halo,
+                        int32_t site_len, int32_t dtype, dl_stream s);
+int dl_cnn_sitepool_bwd(const void* dpooled, void* dz, int64_t B, int64_t L, int64_t C, int32_t halo,
+                        int32_t site_len, int32_t dtype, dl_stream s);
 /* Weight preparation: ONE launch refreshes every compute-dtype (and transposed) image of the fp32 master
  * parameters after an optimiser step — the per-parameter `.to(dtype)` / `.t().contiguous()` / `cat(q,k,v)` copies
  * a torch implementation of the reference's modules makes implicitly, batched.  items / block_map are DEVICE

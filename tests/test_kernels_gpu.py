@@ -168,3 +168,25 @@ def test_weight_images_are_refreshed_in_place_by_one_launch():
     Fn.bump_param_epoch()
     for (p, dt, tr) in reqs:
         assert torch.equal(Fn.lowp(p, dt, tr), expect(p, dt, tr))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,C,S", [(3, 2304, 128, 9), (2, 96, 64, 3), (2, 160, 128, 5)])
+def test_cnn_view_and_site_pool_kernel_matches_reference_formulation(B, L, C, S):
+    """dl_cnn_sitepool_fwd/bwd == (channel-first buffer).view(B, L, C).view(B, S, L/S, C).mean(1) and its
+    autograd backward (basic_model.py:176-179 + DrugLAMP.py:39-40), incl. the zeroed halo rows of dz."""
+    from druglamp_amd import ops
+    halo = 4
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(B, L + 2 * halo, C, generator=g).to(torch.bfloat16).cuda()
+    z[:, :halo] = 0
+    z[:, halo + L:] = 0
+    zin = z[:, halo:halo + L].float().requires_grad_(True)                  # (B, L, C) channel-last
+    ref = zin.transpose(1, 2).contiguous().view(B, L, C).view(B, S, L // S, C).mean(1)
+    got = ops.cnn_sitepool_fwd(z, L, halo, S)
+    torch.testing.assert_close(got.float(), ref.detach(), rtol=1e-2, atol=1e-2)
+    dout = torch.randn(B, L // S, C, generator=g).to(torch.bfloat16).cuda()
+    ref.backward(dout.float())
+    dz = ops.cnn_sitepool_bwd(dout, L, halo, S)
+    assert torch.count_nonzero(dz[:, :halo]) == 0 and torch.count_nonzero(dz[:, halo + L:]) == 0
+    torch.testing.assert_close(dz[:, halo:halo + L].float(), zin.grad, rtol=1e-2, atol=1e-3)
