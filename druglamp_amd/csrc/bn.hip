@@ -174,3 +174,31 @@ extern "C" int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean,
   DL_CHECK_LAUNCH("dl_bn_bwd_apply");
   return DL_OK;
 }
+
+// ---- finalize: sums -> mean / biased var / rstd, and the running-statistics update, in one tiny launch ---------
+namespace {
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float inv_n, float unbias, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ var, float* __restrict__ rstd,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float m = sums[c] * inv_n;
+  const float v = fmaxf(sums[C + c] * inv_n - m * m, 0.f);
+  mean[c] = m;
+  var[c] = v;
+  rstd[c] = rsqrtf(v + eps);
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (v * unbias);
+}
+}  // namespace
+
+extern "C" int dl_bn_finalize(const float* sums, int64_t n, float eps, float momentum, float* mean, float* var,
+                              float* rstd, float* running_mean, float* running_var, int64_t C, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(sums && mean && var && rstd && n > 0 && C > 0, DL_ERR_ARG, "dl_bn_finalize: bad args");
+  const float unbias = n > 1 ? (float)((double)n / (double)(n - 1)) : 1.f;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((uint32_t)((C + 127) / 128)), dim3(128), 0, s, sums, (float)(1.0 / (double)n),
+                     unbias, eps, momentum, mean, var, rstd, running_mean, running_var, (int)C);
+  DL_CHECK_LAUNCH("dl_bn_finalize");
+  return DL_OK;
+}

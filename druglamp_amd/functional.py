@@ -652,7 +652,7 @@ class ProteinCNNFn(torch.autograd.Function):
     elementwise pass that also re-zeroes the halo rows.  Returns (z [B, L, C] view, batch mean/var x3)."""
 
     @staticmethod
-    def forward(ctx, x, training, eps, pool_site_len, *params):
+    def forward(ctx, x, training, eps, pool_site_len, momenta, *params):
         B, LP, C = x.shape
         Lv = LP - 2 * _CNN_HALO
         R = B * LP
@@ -670,12 +670,14 @@ class ProteinCNNFn(torch.autograd.Function):
             Mg = R - (k - 1)
             ops.gemm(cur, Wg, M=Mg, N=C, K=k * C, ldx=C, bias=_f32(b), act=2, out=y[pl:pl + Mg])
             if training:
+                # batch statistics + nn.BatchNorm1d's running-stat update (momentum given) in one tiny launch
                 sums = ops.bn_stats(y, LP, _CNN_HALO, Lv)
-                mean = sums[:C] / n
-                var = (sums[C:] / n - mean * mean).clamp_(min=0)
+                upd = momenta is not None and rmean.dtype == torch.float32
+                mean, var, rstd = ops.bn_finalize(sums, n, eps, momenta[i] if upd else 0.0,
+                                                  rmean.detach() if upd else None, rvar.detach() if upd else None)
             else:
                 mean, var = rmean.detach().float(), rvar.detach().float()
-            rstd = torch.rsqrt(var + eps)
+                rstd = torch.rsqrt(var + eps)
             z = ops.bn_apply_fwd(y, mean, rstd, gamma.detach().float(), beta.detach().float(), LP, _CNN_HALO, Lv)
             saved += [cur, y, mean, rstd, gamma.detach().float()]
             stats_out += [mean, var]
@@ -732,7 +734,7 @@ class ProteinCNNFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.zeros((B, LP, C), dtype=cdt, device=dout.device)
             dx[:, _CNN_HALO:_CNN_HALO + Lv] = dz.reshape(B, LP, C)[:, _CNN_HALO:_CNN_HALO + Lv]
-        return (dx, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None) + tuple(grads)
 
 
 
@@ -833,16 +835,17 @@ class BatchNormRowsFn(torch.autograd.Function):
     Returns (y, mean, var) with biased variance; running-stat bookkeeping stays with the caller."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, training, eps):
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, eps, momentum):
         R, C = x.shape
         x = x.contiguous()
         if training:
             sums = ops.bn_stats(x, 0, 0, 0)
-            mean = sums[:C] / R
-            var = (sums[C:] / R - mean * mean).clamp_(min=0)
+            upd = momentum is not None and rmean is not None and rmean.dtype == torch.float32
+            mean, var, rstd = ops.bn_finalize(sums, R, eps, momentum if upd else 0.0, rmean.detach() if upd else None,
+                                              rvar.detach() if upd else None)
         else:
             mean, var = rmean.detach().float(), rvar.detach().float()
-        rstd = torch.rsqrt(var + eps)
+            rstd = torch.rsqrt(var + eps)
         g = gamma.detach().float()
         y = ops.bn_apply_fwd(x, mean, rstd, g, beta.detach().float(), 0, 0, 0)
         ctx.save_for_backward(x, mean, rstd, g)
@@ -859,16 +862,14 @@ class BatchNormRowsFn(torch.autograd.Function):
         dy = dy.contiguous()
         sums = ops.bn_bwd_reduce(dy, x, mean, rstd, 0, 0, 0)
         dx = ops.bn_bwd_apply(dy, x, mean, rstd, g, sums, 1.0 / R, False, 0, 0, 0)
-        return dx, sums[C:].clone(), sums[:C].clone(), None, None, None, None
+        return dx, sums[C:].clone(), sums[:C].clone(), None, None, None, None, None
 
 
 def batch_norm_rows(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor) -> torch.Tensor:
     """nn.BatchNorm1d semantics (incl. running statistics, momentum, unbiased running variance)."""
-    y, mean, var = BatchNormRowsFn.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.eps)
+    y, mean, var = BatchNormRowsFn.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.eps,
+                                         bn.momentum if bn.training else None)
     if bn.training:
-        n = x2d.shape[0]
         with torch.no_grad():
-            bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
-            bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
-            bn.num_batches_tracked += 1
+            bn.num_batches_tracked += 1        # running mean / var were updated by dl_bn_finalize
     return y

@@ -155,16 +155,13 @@ class ProteinCNN(nn.Module):
         for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)):
             params += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
         fused_pool = int(site_pool) if (site_pool and x.dtype == torch.bfloat16 and L % int(site_pool) == 0) else 0
-        outs = ProteinCNNFn.apply(x, self.training, self.bn1.eps, fused_pool, *params)
+        momenta = (self.bn1.momentum, self.bn2.momentum, self.bn3.momentum) if self.training else None
+        outs = ProteinCNNFn.apply(x, self.training, self.bn1.eps, fused_pool, momenta, *params)
         z = outs[0]
         if self.training:
-            n = B * L
             with torch.no_grad():
-                for i, bn in enumerate((self.bn1, self.bn2, self.bn3)):
-                    mean, var = outs[1 + 2 * i], outs[2 + 2 * i]
-                    bn.running_mean.mul_(1 - bn.momentum).add_(mean, alpha=bn.momentum)
-                    bn.running_var.mul_(1 - bn.momentum).add_(var * (n / max(n - 1, 1)), alpha=bn.momentum)
-                    bn.num_batches_tracked += 1
+                for bn in (self.bn1, self.bn2, self.bn3):
+                    bn.num_batches_tracked += 1    # running mean / var were updated inside (dl_bn_finalize)
         if fused_pool:
             return z
         z = z.transpose(1, 2).contiguous().view(B, L, C)                            # (B, C, L) reinterpreted, like the reference

@@ -335,6 +335,15 @@ def bn_stats(y2d, win, halo, valid):
     return sums
 
 
+def bn_finalize(sums, n, eps, momentum=0.0, running_mean=None, running_var=None):
+    """(mean, biased var, rstd) from dl_bn_stats sums; updates the running statistics in place when given."""
+    Cc = sums.numel() // 2
+    out = torch.empty((3, Cc), dtype=torch.float32, device=sums.device)
+    check(_lib.lib().dl_bn_finalize(sums.data_ptr(), int(n), float(eps), float(momentum), out[0].data_ptr(), out[1].data_ptr(),
+                                    out[2].data_ptr(), _ptr(running_mean), _ptr(running_var), Cc, _stream()), "dl_bn_finalize")
+    return out[0], out[1], out[2]
+
+
 def bn_apply_fwd(y2d, mean, rstd, gamma, beta, win, halo, valid):
     R, Cc = y2d.shape
     z = torch.empty_like(y2d)

@@ -107,6 +107,11 @@ size_t dl_colsum_workspace_bytes(int64_t M, int64_t N);
 size_t dl_bn_workspace_bytes(int64_t R, int64_t C);
 int dl_bn_stats(const void* y, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid,
                 int32_t dtype, float* sums, void* workspace, size_t workspace_bytes, dl_stream s);
+/* sums (from dl_bn_stats: [sum | sum of squares]) -> batch mean, biased variance, rstd = rsqrt(var + eps), and
+ * nn.BatchNorm1d's running-statistics update (momentum, unbiased running variance) in one launch; running_* may
+ * be NULL. */
+int dl_bn_finalize(const float* sums, int64_t n, float eps, float momentum, float* mean, float* var, float* rstd,
+                   float* running_mean, float* running_var, int64_t C, dl_stream s);
 int dl_bn_apply_fwd(const void* y, void* z, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid,
                     int32_t dtype, dl_stream s);
