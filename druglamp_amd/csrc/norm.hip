@@ -4,7 +4,7 @@
 
 namespace {
 constexpr int LN_MAXV = 8;            // up to 8 x (64 lanes x 4 elems) = 2048 columns
-constexpr int LN_BWD_ROWS = 128;      // rows per workgroup in backward (32 per wave)
+constexpr int LN_BWD_ROWS = 32;       // rows per workgroup in backward (8 per wave, two in flight)
 
 template <typename T, int NV_>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int64_t ldx,
@@ -80,40 +80,61 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
     gm[j] = (c < nv) ? *reinterpret_cast<const f32x4*>(gamma + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int64_t r0 = (int64_t)blockIdx.x * LN_BWD_ROWS;
-  for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
-    const int64_t row = r0 + rr;
-    if (row >= M) break;
-    const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[NV_], g[NV_];
-    float c1 = 0.f, c2 = 0.f;
+  // two rows per iteration: both rows' loads are issued before either row's reductions, so one HBM latency is
+  // paid per PAIR of rows (the kernel was latency-bound at one row per wave at a time)
+  for (int rr = wave; rr < LN_BWD_ROWS; rr += 8) {
+    const int64_t rowA = r0 + rr, rowB = r0 + rr + 4;
+    if (rowA >= M) break;
+    const bool hasB = rowB < M;
+    f32x4 xa[NV_], da[NV_], xb[NV_], db_[NV_];
 #pragma unroll
     for (int j = 0; j < NV_; ++j) {
       const int c = lane + 64 * j;
       if (c < nv) {
-        const f32x4 xv = load4<T>(x + row * ldx + c * 4);
-        const f32x4 dv = load4<T>(dy + row * lddy + c * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[j][e] = (xv[e] - mu) * rs;
-          g[j][e] = dv[e] * gm[j][e];
-          c1 += g[j][e];
-          c2 += g[j][e] * xh[j][e];
-          dg[j][e] += dv[e] * xh[j][e];
-          db[j][e] += dv[e];
+        xa[j] = load4<T>(x + rowA * ldx + c * 4);
+        da[j] = load4<T>(dy + rowA * lddy + c * 4);
+        if (hasB) {
+          xb[j] = load4<T>(x + rowB * ldx + c * 4);
+          db_[j] = load4<T>(dy + rowB * lddy + c * 4);
         }
       }
     }
-    c1 = wave_sum(c1) / (float)D;
-    c2 = wave_sum(c2) / (float)D;
 #pragma unroll
-    for (int j = 0; j < NV_; ++j) {
-      const int c = lane + 64 * j;
-      if (c < nv) {
-        f32x4 o;
+    for (int half = 0; half < 2; ++half) {
+      if (half == 1 && !hasB) break;
+      const int64_t row = half == 0 ? rowA : rowB;
+      const float mu = mean[row], rs = rstd[row];
+      f32x4 xh[NV_], g[NV_];
+      float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - c1 - xh[j][e] * c2);
-        if (dres) o += load4<T>(dres + row * lddres + c * 4);
-        store4<T>(dx + row * lddx + c * 4, o);
+      for (int j = 0; j < NV_; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) {
+          const f32x4 xv = half == 0 ? xa[j] : xb[j];
+          const f32x4 dv = half == 0 ? da[j] : db_[j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xh[j][e] = (xv[e] - mu) * rs;
+            g[j][e] = dv[e] * gm[j][e];
+            c1 += g[j][e];
+            c2 += g[j][e] * xh[j][e];
+            dg[j][e] += dv[e] * xh[j][e];
+            db[j][e] += dv[e];
+          }
+        }
+      }
+      c1 = wave_sum(c1) / (float)D;
+      c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+      for (int j = 0; j < NV_; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - c1 - xh[j][e] * c2);
+          if (dres) o += load4<T>(dres + row * lddres + c * 4);
+          store4<T>(dx + row * lddx + c * 4, o);
+        }
       }
     }
   }
