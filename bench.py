@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 HOT_FLOPS_PER_PAIR_STEP = 18.52e9      # PMMA + PGCA, fwd + bwd
 MODEL_FLOPS_PER_PAIR_STEP = 24.7e9     # whole model
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 BF16_PEAK_TFLOPS = 2500.0              # dense MFMA peak, MI355X_MICROARCH.md
 F32_PEAK_TFLOPS = 157.3
 
@@ -167,13 +168,24 @@ def main():
                 # HBM bytes per dl_gemm launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
                 # workload (tools/pmc_summary.py; x2 gfx950 read correction), committed under profiles/
                 traffic = round(json.load(open(pmc))["families"]["gemm"]["traffic_bytes_per_launch"])
-            out["roofline"] = {"kernel": "dl_gemm (all layouts: fwd / dgrad / wgrad)", "bound": "mfma",
-                               "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
-                               "algorithmic_bytes_per_launch": round(by / n),
-                               "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
-                               "time_share_of_step": round(ms / (dt * 1e3), 3),
-                               "algorithmic_hbm_GBps": round(by / (ms * 1e-3) / 1e9, 1)}
+            # Which roofline binds the family: the algorithmic bytes of all launches at the HBM peak vs their flops at
+            # the dense MFMA peak.  For this workload (most products have K <= 512) the HBM floor is the larger one.
+            t_hbm = by / (HBM_PEAK_GBPS * 1e9)
+            t_mfma = fl / (peak * 1e12)
+            mfma_obj = {"achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
+            gbps = by / (ms * 1e-3) / 1e9
+            hbm_obj = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)}
+            bound = "hbm" if t_hbm >= t_mfma else "mfma"
+            out["roofline"] = {"kernel": "dl_gemm (all layouts: fwd / dgrad / wgrad)", "bound": bound}
+            out["roofline"].update(hbm_obj if bound == "hbm" else mfma_obj)
+            out["roofline"].update({
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                "algorithmic_bytes_per_launch": round(by / n), "algorithmic_flops_per_launch": round(fl / n),
+                "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+                "time_share_of_step": round(ms / (dt * 1e3), 3),
+                "floor_ms_per_step": {"hbm": round(t_hbm * 1e3 / args.steps, 3), "mfma": round(t_mfma * 1e3 / args.steps, 3),
+                                      "measured": round(ms / args.steps, 3)},
+                "mfma": mfma_obj, "hbm": hbm_obj})
             for name in ("attn_fwd", "attn_bwd"):
                 n2, ms2, fl2, _ = fam_stats[name]
                 if n2:

@@ -463,6 +463,7 @@ class TokenGateFn(torch.autograd.Function):
         out, gate = ops.token_gate_fwd(v2.reshape(B, L, D), logits.reshape(B, L, H), H, add_residual)
         ctx.save_for_backward(v2, lw1, lw2, pre, hid, gate)
         ctx.cfg = (B, L, D, H, dd, add_residual)
+        ctx.w1, ctx.w2 = w1, w2
         return out
 
     @staticmethod
@@ -470,14 +471,23 @@ class TokenGateFn(torch.autograd.Function):
         v2, lw1, lw2, pre, hid, gate = ctx.saved_tensors
         B, L, D, H, dd, add_residual = ctx.cfg
         M = B * L
+        cdt = v2.dtype
         dv_gate, dlogits = ops.token_gate_bwd(dout.contiguous(), v2.reshape(B, L, D), gate, H, add_residual)
         dl2 = dlogits.reshape(M, H)
         dw2 = ops.gemm(dl2, hid, M=H, N=dd, K=M, x_kslow=True, w_kslow=True, ldx=H, ldw=dd, out_dtype=torch.float32,
                        split_k=0)
         db2 = ops.colsum(dl2)
-        dpre = ops.gemm(dl2, lw2, M=M, N=dd, K=H, w_kslow=True, ldw=dd, dact_pre=pre)
+        if cdt == torch.bfloat16 and H <= 64 and dd % 8 == 0:
+            # K = H (8) is far below one k-step: zero-pad the contraction to 64 so that the product takes the
+            # LDS-DMA large-tile kernel with the gelu' epilogue (was 219 us in the register-staged general path)
+            dl2p = torch.zeros((M, 64), dtype=cdt, device=dl2.device)
+            dl2p[:, :H] = dl2
+            w2t = lowp((ctx.w2,), cdt, transpose=True, pad=(64, dd))           # [dd][64] image of W2^T
+            dpre = ops.gemm(dl2p, w2t, M=M, N=dd, K=64, dact_pre=pre)
+        else:
+            dpre = ops.gemm(dl2, lw2, M=M, N=dd, K=H, w_kslow=True, ldw=dd, dact_pre=pre)
         dw1, db1 = _wgrad(dpre, v2, dd, D, M, dd, D)
-        dv = ops.gemm(dpre, lw1, M=M, N=D, K=dd, w_kslow=True, ldw=D, residual=dv_gate.reshape(M, D))
+        dv = ops.gemm(dpre, lowp((ctx.w1,), cdt, transpose=True), M=M, N=D, K=dd, residual=dv_gate.reshape(M, D))
         return dv.reshape(B, L, D), dw1, db1, dw2, db2, None, None
 
 
