@@ -100,6 +100,7 @@ SIGNATURES = {
     "dl_cnn_sitepool_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "dl_cnn_sitepool_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "dl_bn_finalize": (c_i32, [c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "dl_embed_pad": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "dl_weight_prep": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp]),
     "dl_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "dl_cast": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i64, c_vp]),
@@ -148,6 +149,7 @@ def check(rc: int, what: str = "") -> None:
         import torch
         print("[dl] %s" % what, file=sys.stderr, flush=True)
         torch.cuda.synchronize()
+        print("[dl-ok] %s" % what, file=sys.stderr, flush=True)
     if rc != 0:
         msg = lib().dl_last_error()
         raise RuntimeError("druglamp_hip %s failed (status %d): %s" % (what, rc, msg.decode() if msg else "?"))

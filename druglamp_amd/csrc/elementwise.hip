@@ -158,6 +158,44 @@ __global__ void fill_pool_kernel(const T* __restrict__ x, T* __restrict__ fill, 
   }
 }
 
+// ---------------- ProteinCNN head: embedding gather + fill-bit column + halo rows, in one pass ---------------
+// out[b][halo + l][0..D-1] = weight[ids[b][l]][:], out[b][halo + l][D] = fill[b][l]; halo rows are zero.
+// (basic_model.py:168-171: embedding, cat with the fill bit; the zero halo is this library's conv padding.)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_pad_kernel(const int64_t* __restrict__ ids, const T* __restrict__ weight,
+                                                         const T* __restrict__ fill, T* __restrict__ out, int64_t B, int L,
+                                                         int V, int D, int halo) {
+  extern __shared__ __attribute__((aligned(16))) char ep_smem[];
+  T* tab = reinterpret_cast<T*>(ep_smem);                    // [V][D]
+  for (int i = threadIdx.x; i < V * D; i += 256) tab[i] = weight[i];
+  __syncthreads();
+  const int C = D + 1, cpr = C / 8, LP = L + 2 * halo;
+  const int64_t nchunks = B * LP * cpr;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * 256) {
+    const int64_t row = c / cpr;
+    const int ch = (int)(c % cpr);
+    const int64_t b = row / LP;
+    const int lp = (int)(row % LP), l = lp - halo;
+    T v[8];
+    if (l < 0 || l >= L) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(0.f);
+    } else {
+      int64_t id = ids[b * L + l];
+      id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+      const T* src = tab + id * D;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = ch * 8 + e;
+        v[e] = col < D ? src[col] : fill[b * L + l];
+      }
+    }
+    T* dst = out + row * C + ch * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = v[e];
+  }
+}
+
 // ---------------- ProteinCNN tail: the reference's (B,C,L).view(B,L,C) + site pooling, in one pass -----------
 // z is the channel-last conv output with `halo` zero rows around every sample: z[b][halo + l][c].  The reference
 // holds the same values channel-first (mem[b][c*L + l]), REINTERPRETS that buffer as (B, L, C) and then averages
@@ -494,6 +532,25 @@ extern "C" int dl_cast(const void* src, int32_t sdt, void* dst, int32_t ddt, int
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
   else { dl_set_error("dl_cast: bad dtypes"); return DL_ERR_ARG; }
   DL_CHECK_LAUNCH("dl_cast");
+  return DL_OK;
+}
+
+extern "C" int dl_embed_pad(const int64_t* ids, const void* weight, const void* fill, void* out, int64_t B, int64_t L,
+                            int32_t V, int32_t D, int32_t halo, int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(ids && weight && fill && out && B > 0 && L > 0 && V > 0 && D > 0 && halo >= 0, DL_ERR_ARG, "dl_embed_pad: bad args");
+  DL_CHECK_ARG((D + 1) % 8 == 0 && (size_t)V * D * dl_dtype_size(dtype) <= 64 * 1024, DL_ERR_SHAPE,
+               "dl_embed_pad: needs (D + 1) %% 8 == 0 and a table that fits 64 KB of LDS");
+  const int64_t nchunks = B * (L + 2 * halo) * ((D + 1) / 8);
+  const uint32_t blocks = (uint32_t)((nchunks + 256 * 8 - 1) / (256 * 8) < 4096 ? (nchunks + 256 * 8 - 1) / (256 * 8) : 4096);
+  const size_t lds = (size_t)V * D * dl_dtype_size(dtype);
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((embed_pad_kernel<bf16_t>), dim3(blocks), dim3(256), lds, s, ids, (const bf16_t*)weight, (const bf16_t*)fill,
+                       (bf16_t*)out, B, (int)L, V, D, halo);
+  else
+    hipLaunchKernelGGL((embed_pad_kernel<float>), dim3(blocks), dim3(256), lds, s, ids, (const float*)weight, (const float*)fill,
+                       (float*)out, B, (int)L, V, D, halo);
+  DL_CHECK_LAUNCH("dl_embed_pad");
   return DL_OK;
 }
 

@@ -516,15 +516,24 @@ int auto_split(int64_t M, int64_t N, int64_t K, int bke, int bt) {
 }
 
 int big_tt_plan(const dl_gemm_args* a, int* bm_out);
+// no k-range may be empty: the DMA path requests a slab's first operand tile before it looks at the range, and an
+// empty range would start past the last row of the operands
+static int trim_splits(int64_t K, int step, int sp) {
+  const int64_t ksteps = (K + step - 1) / step;
+  if (sp > ksteps) sp = (int)ksteps;
+  if (sp < 1) sp = 1;
+  const int64_t per = (ksteps + sp - 1) / sp;
+  return (int)((ksteps + per - 1) / per);
+}
 int resolve_split(const dl_gemm_args* a) {
-  { const int sp = big_tt_plan(a, nullptr); if (sp > 0) return sp; }
+  { const int sp = big_tt_plan(a, nullptr); if (sp > 0) return trim_splits(a->K, 64, sp); }
   const int bke = BKB / (int)dl_dtype_size(a->in_dtype);
-  if (a->split_k > 0) return a->split_k;
+  if (a->split_k > 0) return trim_splits(a->K, bke, a->split_k);
   if (a->split_k < 0) return 1;
   // auto: only legal for plain f32 outputs
   const bool plain = !a->bias && !a->residual && !a->act && !a->pre_out && !a->dact_pre &&
                      a->dropout_p <= 0.f && a->out_dtype == DL_F32 && (a->N % 4 == 0);
-  return plain ? auto_split(a->M, a->N, a->K, bke, 32 * pick_tw(a)) : 1;
+  return plain ? trim_splits(a->K, bke, auto_split(a->M, a->N, a->K, bke, 32 * pick_tw(a))) : 1;
 }
 
 // specialised epilogue id (see gemm_kernel), 1 = general

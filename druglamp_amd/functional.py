@@ -662,7 +662,7 @@ class ProteinCNNFn(torch.autograd.Function):
     elementwise pass that also re-zeroes the halo rows.  Returns (z [B, L, C] view, batch mean/var x3)."""
 
     @staticmethod
-    def forward(ctx, x, training, eps, pool_site_len, momenta, *params):
+    def forward(ctx, x, training, eps, pool_site_len, momenta, raw_dx, *params):
         B, LP, C = x.shape
         Lv = LP - 2 * _CNN_HALO
         R = B * LP
@@ -694,7 +694,7 @@ class ProteinCNNFn(torch.autograd.Function):
             meta.append((k, pl, w))
             cur = z
         ctx.save_for_backward(*saved)
-        ctx.cfg = (B, LP, C, Lv, training, pool_site_len)
+        ctx.cfg = (B, LP, C, Lv, training, pool_site_len, raw_dx)
         ctx.weights = [m[2] for m in meta]
         if pool_site_len:
             # the reference's (B,C,L).view(B,L,C) reinterpretation + site pooling, straight from the padded buffer
@@ -706,7 +706,7 @@ class ProteinCNNFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, *_):
-        B, LP, C, Lv, training, pool_site_len = ctx.cfg
+        B, LP, C, Lv, training, pool_site_len, raw_dx = ctx.cfg
         if not training:
             raise RuntimeError("ProteinCNNFn.backward is only implemented for training-mode BatchNorm")
         sv = ctx.saved_tensors
@@ -739,12 +739,18 @@ class ProteinCNNFn(torch.autograd.Function):
                 Wd = _conv_weight(w, cdt, True)
                 dprev = torch.empty((R, C), dtype=cdt, device=dout.device)
                 ops.gemm(dpre, Wd, M=Mg, N=C, K=k * C, ldx=C, out=dprev[pr:pr + Mg])
+                if i == 0 and raw_dx:                       # rows the GEMM does not write must be finite for the consumer
+                    dprev[:pr].zero_()
+                    dprev[pr + Mg:].zero_()
                 dz = dprev
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.zeros((B, LP, C), dtype=cdt, device=dout.device)
-            dx[:, _CNN_HALO:_CNN_HALO + Lv] = dz.reshape(B, LP, C)[:, _CNN_HALO:_CNN_HALO + Lv]
-        return (dx, None, None, None, None) + tuple(grads)
+            if raw_dx:
+                dx = dz.reshape(B, LP, C)        # halo rows hold finite junk; EmbedPadFn ignores them
+            else:
+                dx = torch.zeros((B, LP, C), dtype=cdt, device=dout.device)
+                dx[:, _CNN_HALO:_CNN_HALO + Lv] = dz.reshape(B, LP, C)[:, _CNN_HALO:_CNN_HALO + Lv]
+        return (dx, None, None, None, None, None) + tuple(grads)
 
 
 
@@ -838,6 +844,37 @@ class EmbeddingFn(torch.autograd.Function):
             dw[ctx.padding_idx].zero_()          # nn.Embedding(padding_idx=...) never updates that row
         return None, dw, None
 
+
+
+class EmbedPadFn(torch.autograd.Function):
+    """ProteinCNN input in one kernel: embedding rows + fill-bit column + zero halo rows, (B, L + 2*HALO, D + 1).
+    Backward takes the PADDED gradient as it leaves ProteinCNNFn (halo rows may hold finite junk) and forms the
+    embedding gradient as a one-hot GEMM whose one-hot rows are zero at the halo positions."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, fill, padding_idx):
+        ctx.save_for_backward(ids)
+        ctx.wshape = tuple(weight.shape)
+        ctx.padding_idx = padding_idx
+        return ops.embed_pad(ids, weight.detach(), fill, _CNN_HALO)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        V, D = ctx.wshape
+        B, LP, C = dy.shape
+        Vp = (V + 7) // 8 * 8
+        R = B * LP
+        cdt = dy.dtype
+        onehot = torch.zeros((B, LP, Vp), dtype=cdt, device=dy.device)
+        onehot[:, _CNN_HALO:LP - _CNN_HALO].scatter_(2, ids.unsqueeze(-1), 1.0)
+        g = dy.contiguous().reshape(R, C)
+        dw = ops.gemm(onehot.reshape(R, Vp), g, M=Vp, N=C, K=R, x_kslow=True, w_kslow=True, ldx=Vp, ldw=C,
+                      out_dtype=torch.float32, split_k=0)
+        dw = dw[:V, :D]
+        if ctx.padding_idx is not None:
+            dw[ctx.padding_idx].zero_()          # nn.Embedding(padding_idx=...) never updates that row
+        return None, dw, None, None
 
 
 class BatchNormRowsFn(torch.autograd.Function):

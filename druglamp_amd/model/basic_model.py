@@ -47,15 +47,22 @@ class _GraphConvDense(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_feats))
         nn.init.xavier_uniform_(self.weight)
 
-    def forward(self, adj, feat):
-        """adj: (B, Nr, Nr) with Nr <= N nodes.  Nodes >= Nr are virtual padding nodes whose only edge is
-        their self loop (degree 1): for them the normalised aggregation is the identity, so only the
-        real-atom block goes through the batched product."""
-        Nr = adj.shape[-1]
-        fr = feat[:, :Nr]
-        dout = adj.sum(dim=-1).clamp(min=1).pow(-0.5).unsqueeze(-1)     # out-degree of the source node
-        din = adj.sum(dim=-2).clamp(min=1).pow(-0.5).unsqueeze(-1)      # in-degree of the destination
-        agg = torch.bmm(adj.transpose(1, 2).to(fr.dtype), fr * dout.to(fr.dtype)) * din.to(fr.dtype)
+    @staticmethod
+    def normalised_adjacency(adj, dtype):
+        """ahat[b][i][j] = din[i] * adj[b][j][i] * dout[j] (D^-1/2 A^T D^-1/2 with clamped degrees) — computed ONCE per
+        batch and shared by every layer (the adjacency carries no gradient)."""
+        with torch.no_grad():
+            a = adj.float()
+            dout = a.sum(dim=-1).clamp(min=1).pow(-0.5)                 # out-degree of the source node j
+            din = a.sum(dim=-2).clamp(min=1).pow(-0.5)                  # in-degree of the destination i
+            return (a.transpose(1, 2) * din.unsqueeze(-1) * dout.unsqueeze(-2)).to(dtype).contiguous()
+
+    def forward(self, ahat, feat):
+        """ahat: normalised adjacency (B, Nr, Nr) with Nr <= N nodes.  Nodes >= Nr are virtual padding nodes whose
+        only edge is their self loop (degree 1): for them the normalised aggregation is the identity, so only
+        the real-atom block goes through the batched product."""
+        Nr = ahat.shape[-1]
+        agg = torch.bmm(ahat, feat[:, :Nr])
         if Nr < feat.shape[1]:
             agg = torch.cat((agg, feat[:, Nr:]), dim=1)
         return F.relu(Fn.dense(agg, self.weight.t(), self.bias))            # feature transform on the HIP GEMM path
@@ -68,8 +75,8 @@ class _GCNLayerDense(nn.Module):
         self.res_connection = nn.Linear(in_feats, out_feats)
         self.bn_layer = nn.BatchNorm1d(out_feats)
 
-    def forward(self, adj, feats):
-        new = self.graph_conv(adj, feats) + F.relu(Fn.dense(feats, self.res_connection.weight, self.res_connection.bias))
+    def forward(self, ahat, feats):
+        new = self.graph_conv(ahat, feats) + F.relu(Fn.dense(feats, self.res_connection.weight, self.res_connection.bias))
         B, N, C = new.shape
         return Fn.batch_norm_rows(self.bn_layer, new.reshape(B * N, C)).reshape(B, N, C)
 
@@ -83,8 +90,9 @@ class _GCNDense(nn.Module):
             in_feats = h
 
     def forward(self, adj, feats):
+        ahat = _GraphConvDense.normalised_adjacency(adj, feats.dtype)
         for layer in self.gnn_layers:
-            feats = layer(adj, feats)
+            feats = layer(ahat, feats)
         return feats
 
 
@@ -143,20 +151,19 @@ class ProteinCNN(nn.Module):
         `.view(B, L, C)` of the channel-first (B, C, L) buffer is reproduced exactly.  site_pool = site_len (> 0)
         additionally applies the caller's site pooling (DrugLAMP.py:39-40) inside the same kernel and returns
         (B, L // site_len, C)."""
-        from ..functional import _CNN_HALO, EmbeddingFn, ProteinCNNFn, cast
+        from ..functional import EmbedPadFn, ProteinCNNFn, cast
         ids = v.long()
         w = self.embedding.weight
-        x = EmbeddingFn.apply(ids, cast(w, self.compute_dtype) if w.requires_grad else w.detach().to(self.compute_dtype),
-                              self.embedding.padding_idx)
-        x = torch.cat((x, fill_mask.unsqueeze(-1).to(x.dtype)), dim=-1)            # (B, L, C) channel-last
-        B, L, C = x.shape
-        x = F.pad(x, (0, 0, _CNN_HALO, _CNN_HALO))
+        wc = cast(w, self.compute_dtype) if w.requires_grad else w.detach().to(self.compute_dtype)
+        x = EmbedPadFn.apply(ids, wc, fill_mask, self.embedding.padding_idx)        # (B, L + 2*HALO, C) channel-last
+        B, L = ids.shape
+        C = x.shape[-1]
         params = []
         for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)):
             params += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
         fused_pool = int(site_pool) if (site_pool and x.dtype == torch.bfloat16 and L % int(site_pool) == 0) else 0
         momenta = (self.bn1.momentum, self.bn2.momentum, self.bn3.momentum) if self.training else None
-        outs = ProteinCNNFn.apply(x, self.training, self.bn1.eps, fused_pool, momenta, *params)
+        outs = ProteinCNNFn.apply(x, self.training, self.bn1.eps, fused_pool, momenta, True, *params)
         z = outs[0]
         if self.training:
             with torch.no_grad():

@@ -416,3 +416,17 @@ def cnn_sitepool_bwd(dpooled: torch.Tensor, L: int, halo: int, site_len: int) ->
     check(_lib.lib().dl_cnn_sitepool_bwd(dpooled.data_ptr(), dz.data_ptr(), B, L, C, halo, site_len, _dt(dpooled),
                                          _stream()), "dl_cnn_sitepool_bwd")
     return dz
+
+
+def embed_pad(ids: torch.Tensor, weight: torch.Tensor, fill: torch.Tensor, halo: int) -> torch.Tensor:
+    """ids (B, L) int64, weight (V, D), fill (B, L) -> (B, L + 2*halo, D + 1); see dl_embed_pad."""
+    _need_gpu(ids, weight, fill)
+    B, L = ids.shape
+    V, D = weight.shape
+    ids = ids.contiguous()
+    weight = weight.contiguous()
+    fill = fill.to(weight.dtype).contiguous()
+    out = torch.empty((B, L + 2 * halo, D + 1), dtype=weight.dtype, device=weight.device)
+    check(_lib.lib().dl_embed_pad(ids.data_ptr(), weight.data_ptr(), fill.data_ptr(), out.data_ptr(), B, L, V, D, halo,
+                                  _dt(weight), _stream()), "dl_embed_pad")
+    return out

@@ -225,6 +225,12 @@ int dl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dt
 /* dst(bf16|f32) = src(f32|bf16) elementwise cast (weight casts, master fp32 -> compute dtype). */
 int dl_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n,
             dl_stream s);
+/* ProteinCNN head (model/basic_model.py:168-171): out[b][halo + l][:D] = weight[ids[b][l]][:] (nn.Embedding row
+ * gather), out[b][halo + l][D] = fill[b][l] (the concatenated fill bit); `halo` zero rows on each side of every
+ * sample are the conv 'same' padding of this library's channel-last layout.  weight [V][D], fill [B][L] and out
+ * [B][L + 2*halo][D + 1] are `dtype`. */
+int dl_embed_pad(const int64_t* ids, const void* weight, const void* fill, void* out, int64_t B, int64_t L,
+                 int32_t V, int32_t D, int32_t halo, int32_t dtype, dl_stream s);
 /* ProteinCNN tail (model/basic_model.py:176-179 + DrugLAMP.py:39-40): the reference keeps the conv output
  * channel-first (B, C, L), REINTERPRETS that buffer with .view(B, L, C) and then site-pools it
  * (.view(B, site_len, n_site, C).mean(1)).  z is this library's channel-last conv output with `halo` zero rows

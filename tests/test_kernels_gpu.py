@@ -190,3 +190,26 @@ def test_cnn_view_and_site_pool_kernel_matches_reference_formulation(B, L, C, S)
     dz = ops.cnn_sitepool_bwd(dout, L, halo, S)
     assert torch.count_nonzero(dz[:, :halo]) == 0 and torch.count_nonzero(dz[:, halo + L:]) == 0
     torch.testing.assert_close(dz[:, halo:halo + L].float(), zin.grad, rtol=1e-2, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_embed_pad_matches_embedding_cat_pad_and_its_gradient(dt):
+    """EmbedPadFn == pad(cat(embedding(ids), fill)) with the embedding gradient of nn.Embedding(padding_idx=0); the
+    row count (8 * 2312) makes the one-hot weight-gradient GEMM's k-steps not divide its split count (empty k-ranges
+    once started past the operands' last row)."""
+    from druglamp_amd import functional as Fn
+    g = torch.Generator().manual_seed(6)
+    B, L, V, D, halo = 8, 2304, 27, 127, Fn._CNN_HALO
+    ids = torch.randint(0, V, (B, L), generator=g).cuda()
+    w = torch.randn(V, D, generator=g).to(dt).cuda().requires_grad_(True)
+    fill = (torch.rand(B, L, generator=g) > 0.5).to(dt).cuda()
+    out = Fn.EmbedPadFn.apply(ids, w, fill, 0)
+    ref = torch.nn.functional.pad(torch.cat((w.detach()[ids], fill.unsqueeze(-1)), -1), (0, 0, halo, halo))
+    assert torch.equal(out, ref)
+    dy = torch.randn(B, L + 2 * halo, D + 1, generator=g).to(dt).cuda()
+    out.backward(dy)
+    wr = w.detach().float().clone().requires_grad_(True)
+    torch.nn.functional.embedding(ids, wr, padding_idx=0).backward(dy[:, halo:halo + L, :D].float())
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    assert (w.grad.float() - wr.grad).abs().max() <= tol * wr.grad.abs().max()
