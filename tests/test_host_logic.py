@@ -154,9 +154,12 @@ def test_c_abi_argument_validation_without_gpu():
     a.X = p16 + 2                                   # misaligned operand
     assert L.dl_gemm(C.byref(a), None) == -3 and b"aligned" in L.dl_last_error()
     a.X = p16
+    a.K = 512                                       # 8 k-steps: a 4-way split keeps 4 non-empty slabs
     a.split_k, a.out_dtype = 4, _lib.DL_F32         # split-K without workspace
     assert L.dl_gemm(C.byref(a), None) == -4 and b"workspace" in L.dl_last_error()
     assert L.dl_gemm_workspace_bytes(C.byref(a)) == 4 * 64 * 64 * 4
+    a.K, a.split_k = 192, 8                         # 3 k-steps: the plan is trimmed to 3 non-empty slabs
+    assert L.dl_gemm_workspace_bytes(C.byref(a)) == 3 * 64 * 64 * 4
     f = _lib.AttnFwdArgs()
     f.Q = f.K = f.V = f.O = p16
     f.n_problems, f.n_heads, f.n_segments, f.Lq, f.Lk, f.head_dim, f.dtype = 1, 1, 1, 16, 16, 48, _lib.DL_BF16
