@@ -1,0 +1,108 @@
+"""Size-independent properties of the HIP path at the benchmark's FULL sizes (per-GPU batch 256: 65536-row
+activations, 512 x 4 x 2 attention problems, 591872-row conv buffers), where the CPU oracle is too slow to be the
+checker: linearity, normalisation identities, mask replay, run-to-run bit reproducibility."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DT = torch.bfloat16
+
+
+def _attn(q, k, v, P, H, S, shift, L, hd):
+    from druglamp_amd import ops
+    d = H * hd
+    o = torch.empty(S, P * L, d, device="cuda", dtype=q.dtype)
+    st = (L * d, hd, d)
+    lse = ops.attn_fwd(q, k, v, n_problems=P, n_heads=H, n_segments=S, partner_shift=shift, Lq=L, Lk=L, head_dim=hd,
+                       scale=1.0 / math.sqrt(hd), q_strides=st, k_strides=st, v_strides=st, out=o, o_strides=st,
+                       o_ss=P * L * d)
+    return o, lse
+
+
+def test_paired_attention_rows_are_convex_combinations_and_linear_in_v():
+    """P = 512 problems x 4 heads x 2 segments x 256 x 256 (the PMMA paired shape).  softmax rows sum to one: V = 1
+    gives O = 1 exactly-ish; O is linear in V; LSE does not depend on V."""
+    P, H, S, L, hd = 512, 4, 2, 256, 64
+    g = torch.Generator().manual_seed(0)
+    d = H * hd
+    q = (torch.randn(P * L, d, generator=g) * 0.7).to(DT).cuda()
+    k = (torch.randn(P * L, d, generator=g) * 0.7).to(DT).cuda()
+    v1 = torch.randn(P * L, d, generator=g).to(DT).cuda()
+    v2 = torch.randn(P * L, d, generator=g).to(DT).cuda()
+    ones = torch.ones_like(v1)
+    o1, lse1 = _attn(q, k, v1, P, H, S, P // 2, L, hd)
+    o2, lse2 = _attn(q, k, v2, P, H, S, P // 2, L, hd)
+    oo, _ = _attn(q, k, ones, P, H, S, P // 2, L, hd)
+    assert (oo.float() - 1).abs().max() <= 1e-2
+    assert torch.equal(lse1, lse2)
+    o12, _ = _attn(q, k, (v1.float() * 0.5 + v2.float() * 0.25).to(DT), P, H, S, P // 2, L, hd)
+    lin = o1.float() * 0.5 + o2.float() * 0.25
+    assert (o12.float() - lin).abs().max() <= 4e-2
+    # every output row lies inside the value range of its head (convexity)
+    assert o1.float().abs().max() <= v1.float().abs().max() + 1e-2
+
+
+def test_gemm_is_linear_and_dropout_masks_replay_at_full_size():
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 65536, 1024, 256
+    x1 = torch.randn(M, K, generator=g).to(DT).cuda()
+    x2 = torch.randn(M, K, generator=g).to(DT).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DT).cuda()
+    y1 = ops.gemm(x1, w, M=M, N=N, K=K).float()
+    y2 = ops.gemm(x2, w, M=M, N=N, K=K).float()
+    y12 = ops.gemm((x1.float() + x2.float()).to(DT), w, M=M, N=N, K=K).float()
+    assert (y12 - (y1 + y2)).abs().max() <= 3e-2 * (y1.abs().max() + y2.abs().max())
+    # dropout: the forward epilogue's mask equals the mask dl_dropout_apply replays from (seed, index)
+    yd = ops.gemm(x1, w, M=M, N=N, K=K, dropout_p=0.1, seed=77)
+    base = ops.gemm(x1, w, M=M, N=N, K=K)
+    rep = ops.dropout_apply(base, 0.1, 77)
+    assert torch.equal(yd == 0, rep == 0)                       # identical keep pattern
+    assert (yd.float() - rep.float()).abs().max() <= 1e-2 * yd.float().abs().max()   # one rounding vs two
+    keep = (yd != 0).float().mean().item()
+    assert abs(keep - 0.9) < 2e-3
+    # weight gradient with bias gradient: column sums of ones are the row count, dW of (ones, x) = column sums of x
+    ones = torch.ones(M, 256, device="cuda", dtype=DT)
+    db = torch.empty(256, device="cuda")
+    dw = ops.gemm(ones, x1, M=256, N=K, K=M, x_kslow=True, w_kslow=True, ldx=256, ldw=K, out_dtype=torch.float32,
+                  split_k=0, x_colsum=db)
+    assert torch.equal(db, torch.full_like(db, float(M)))
+    cs = x1.double().sum(0)
+    assert (dw.double() - cs).abs().max() <= 1e-5 * cs.abs().max() + 1e-3
+
+
+def test_layernorm_rows_are_standardised_at_full_size():
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(2)
+    M, D = 65536, 512
+    x = (torch.randn(M, D, generator=g) * 3 + 1).to(DT).cuda()
+    y, mean, rstd = ops.layernorm_fwd(x, torch.ones(D, device="cuda"), torch.zeros(D, device="cuda"), 1e-6)
+    yf = y.float()
+    assert yf.mean(1).abs().max() <= 2e-2 and (yf.var(1, unbiased=False) - 1).abs().max() <= 3e-2
+    assert (mean - x.float().mean(1)).abs().max() <= 1e-3
+
+
+def test_training_step_is_bit_reproducible():
+    """Same seeds -> identical loss and identical parameters after two steps (no atomics anywhere on the path)."""
+    from druglamp_amd import ops
+    from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
+    from druglamp_amd.model import MInterface
+    from druglamp_amd.synthetic import make_batch
+    from druglamp_amd.trainer import Trainer
+    dev = torch.device("cuda", 0)
+    res = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        ops.manual_seed(9)
+        cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP")
+        model = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
+        tr = Trainer(model, cfg, device=dev, compute_dtype=DT)
+        tr.set_lrs(cfg["SOLVER"]["LR"], cfg["SOLVER"]["SSL_LR"], cfg["SOLVER"]["CM_LR"])
+        batch, meta = make_batch(64, dev, seed=3, with_graph=True, llm_dtype=DT)
+        losses = [tr.training_step(batch, meta=meta, cur_epoch=1) for _ in range(2)]
+        torch.cuda.synchronize()
+        res.append((losses, torch.cat([p.detach().flatten() for p in model.parameters()]).clone()))
+    assert [sorted(x.items()) for x in res[0][0]] == [sorted(x.items()) for x in res[1][0]]
+    assert torch.equal(res[0][1], res[1][1])
