@@ -1,6 +1,7 @@
 """DrugLAMP (reference: model/DrugLAMP.py:8-78): forward(vd, vp, xd, xp, mode) -> 5-tuple / 4-tuple."""
 import torch
 
+from .. import functional as Fn
 from .. import ops
 from .basic_model import DrugLAMPBase
 
@@ -23,12 +24,13 @@ class DrugLAMP(DrugLAMPBase):
         # materialised by SSL.forward on SSL epochs only
         ssl = {"vp": vp, "xp": (xp, fill_p), "fill_bit_p": fill_p, "vd": vd, "xd": (xd, fill_d)}
         xp, xd = xps, xdp
-        vpf = self.protein_extractor(vp, fill_p, site_pool=self.site_len)
-        xpf, xdf = self._llm_adaptors(xp, xd)
-        vpf, vdf = vpf.float(), vd.float()
-        cp = {"prot": vpf, "aug_prot": xpf, "drug": vdf, "aug_drug": xdf} if self.two_c2p else None
-        mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpf, vdf)
-        mx, self.A_x_gca = self._gca_branch(self.x_gca, self.x_mhla, self.x_gca_norm, xpf, xdf)
+        vpc = self.protein_extractor(vp, fill_p, site_pool=self.site_len)       # compute dtype
+        vdc = Fn.cast(vd, cdt)
+        xpc, xdc = self._llm_adaptors(xp, xd)
+        vpf = vpc.float()                                                       # fp32 copies only for the returned tuple
+        cp = {"prot": vpf, "aug_prot": xpc.float(), "drug": vd.float(), "aug_drug": xdc.float()} if self.two_c2p else None
+        mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, vdc)
+        mx, self.A_x_gca = self._gca_branch(self.x_gca, self.x_mhla, self.x_gca_norm, xpc, xdc)
         f, self.attn, self.guide_attn = self.pmma(mx, mv)
         with self._glue():
             score = self.mlp_classifier(f.mean(dim=1))

@@ -1,4 +1,5 @@
 """DrugLAMPwoLLM (reference: model/DrugLAMPwoLLM.py:8-51): no LLM branch; pmma(mv, mv)."""
+from .. import functional as Fn
 from .. import ops
 from .basic_model import DrugLAMPBase
 
@@ -11,9 +12,9 @@ class DrugLAMPwoLLM(DrugLAMPBase):
         vd = self.drug_extractor(vd)
         fill_p, _ = ops.fill_pool(xp, self.site_len, self.compute_dtype)
         ssl = {"vp": vp, "xp": None, "fill_bit_p": fill_p, "vd": vd, "xd": None, "p_mode": "vp"}
-        vpf = self.protein_extractor(vp, fill_p, site_pool=self.site_len)
-        vpf, vdf = vpf.float(), vd.float()
-        mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpf, vdf)
+        vpc = self.protein_extractor(vp, fill_p, site_pool=self.site_len)       # compute dtype
+        vpf = vpc.float()
+        mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, Fn.cast(vd, self.compute_dtype))
         f, self.attn, self.guide_attn = self.pmma(mv, mv)
         with self._glue():
             score = self.mlp_classifier(f.mean(dim=1))

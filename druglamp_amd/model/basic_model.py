@@ -283,7 +283,9 @@ class DrugLAMPBase(nn.Module):
                      need_weights=self.keep_raw_attention, need_raw=True)
         m = torch.cat((prot_sites, m.permute(1, 0, 2)), 2)
         m = mhla(m, add_residual=True)                                  # mhla(h) + h in one launch set
-        m = Fn.layer_norm(m.float(), norm.weight, norm.bias, norm.eps)
+        # inputs arrive in the compute dtype and stay in it (the LayerNorm kernel keeps fp32 statistics either way):
+        # no fp32 round trips between PGCA, MHLA, LayerNorm and PMMA
+        m = Fn.layer_norm(m, norm.weight, norm.bias, norm.eps)
         return m, raw
 
     def _llm_adaptors(self, xp_cat, xd_cat):
@@ -303,7 +305,7 @@ class DrugLAMPBase(nn.Module):
         h = Fn.dense(xd, self.lin_d1.weight, self.lin_d1.bias, act=True)
         h = Fn.layer_norm(h, self.d_norm.weight, self.d_norm.bias, self.d_norm.eps)
         xdf = Fn.dense(h, self.lin_d2.weight, self.lin_d2.bias)
-        return xpf.float(), xdf.float()
+        return xpf, xdf                                # compute dtype
 
     def get_cross_attn_mat(self, modality="v"):
         if modality == "v":
