@@ -237,23 +237,29 @@ template <typename T> __device__ __forceinline__ f32x4 gelu4(f32x4 v) {
     return f32x4{ga[0], ga[1], gb[0], gb[1]};
   }
 }
+// gelu'(x) - 1/2 is odd; on |x| <= 5.5 it is x * P(x^2) / Q(x^2) with P cubic and Q cubic in x^2 to 1.0e-4 absolute
+// (least-squares fit, checked in fp32 arithmetic over [-9, 9]) — a factor 40 below the bf16 rounding of the product it
+// feeds.  One reciprocal and 8 packed FMAs per pair instead of erf + exp (the gelu' data-gradient epilogue is VALU-bound).
+__device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
+  x = __builtin_elementwise_max(__builtin_elementwise_min(x, bc2(5.5f)), bc2(-5.5f));
+  const f32x2 x2 = x * x;
+  f32x2 p = fma2(bc2(1.6454146817e-04f), x2, bc2(1.4818409354e-02f));
+  p = fma2(p, x2, bc2(-2.9252399590e-02f));
+  p = fma2(p, x2, bc2(7.9844805043e-01f));
+  f32x2 q = fma2(bc2(5.5159476634e-03f), x2, bc2(3.8876839848e-02f));
+  q = fma2(q, x2, bc2(3.0011850475e-01f));
+  q = fma2(q, x2, bc2(1.0f));
+  const f32x2 r = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
+  return fma2(x * p, r, bc2(0.5f));
+}
 template <typename T> __device__ __forceinline__ f32x4 gelu_grad4(f32x4 v) {
   if constexpr (sizeof(T) == 4) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = gelu_erf_grad(v[e]);
     return v;
   } else {
-    f32x4 o;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const f32x2 a = {v[2 * h], v[2 * h + 1]};
-      const f32x2 cdf = fma2(bc2(0.5f), erf_fast2(a * bc2(0.70710678118654752440f)), bc2(0.5f));
-      const f32x2 t = a * a * bc2(-0.5f * 1.44269504088896340736f);
-      const f32x2 pdf = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} * bc2(0.39894228040143267794f);
-      const f32x2 g = fma2(a, pdf, cdf);
-      o[2 * h] = g[0]; o[2 * h + 1] = g[1];
-    }
-    return o;
+    const f32x2 a = gelu_grad_fast2(f32x2{v[0], v[1]}), b = gelu_grad_fast2(f32x2{v[2], v[3]});
+    return f32x4{a[0], a[1], b[0], b[1]};
   }
 }
 

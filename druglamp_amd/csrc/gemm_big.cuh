@@ -17,13 +17,13 @@
 //               128-byte line.
 #pragma once
 
+// One 8-column piece of an output row.  b0/b1: the lane's bias values (the column is fixed per lane, loaded once per
+// tile); ext: the residual (EPI 3) or the saved pre-activation (EPI 4) for this piece, requested several pieces
+// ahead by the caller so that its HBM latency is not paid once per piece.
 template <int EPI>
-__device__ __forceinline__ void big_epilogue8(const GemmP& p, int m, int n, f32x4 a0, f32x4 a1) {
+__device__ __forceinline__ void big_epilogue8(const GemmP& p, int m, int n, f32x4 a0, f32x4 a1, f32x4 b0, f32x4 b1, u32x4 ext) {
   typedef bf16_t T;
-  if (EPI != 4 && p.bias) {
-    a0 += *reinterpret_cast<const f32x4*>(p.bias + n);
-    a1 += *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-  }
+  if constexpr (EPI != 4) { a0 += b0; a1 += b1; }
   if constexpr (EPI == 2) {
     T* pd = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
     u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
@@ -33,18 +33,16 @@ __device__ __forceinline__ void big_epilogue8(const GemmP& p, int m, int n, f32x
 #pragma unroll
     for (int r = 0; r < 4; ++r) { a0[r] = fmaxf(a0[r], 0.f); a1[r] = fmaxf(a1[r], 0.f); }
   } else if constexpr (EPI == 4) {
-    const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.dact_pre) + (int64_t)m * p.lddp + n);
-    a0 *= gelu_grad4<T>(f32x4{bf16lo(q[0]), bf16hi(q[0]), bf16lo(q[1]), bf16hi(q[1])});
-    a1 *= gelu_grad4<T>(f32x4{bf16lo(q[2]), bf16hi(q[2]), bf16lo(q[3]), bf16hi(q[3])});
+    a0 *= gelu_grad4<T>(f32x4{bf16lo(ext[0]), bf16hi(ext[0]), bf16lo(ext[1]), bf16hi(ext[1])});
+    a1 *= gelu_grad4<T>(f32x4{bf16lo(ext[2]), bf16hi(ext[2]), bf16lo(ext[3]), bf16hi(ext[3])});
   }
   if (EPI != 5 && EPI != 0 && p.drop_thr16) {
     a0 = dl_dropout4(a0, p.seed, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
     a1 = dl_dropout4(a1, p.seed, (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
   }
   if constexpr (EPI == 3) {
-    const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n);
-    a0 += f32x4{bf16lo(q[0]), bf16hi(q[0]), bf16lo(q[1]), bf16hi(q[1])};
-    a1 += f32x4{bf16lo(q[2]), bf16hi(q[2]), bf16lo(q[3]), bf16hi(q[3])};
+    a0 += f32x4{bf16lo(ext[0]), bf16hi(ext[0]), bf16lo(ext[1]), bf16hi(ext[1])};
+    a1 += f32x4{bf16lo(ext[2]), bf16hi(ext[2]), bf16lo(ext[3]), bf16hi(ext[3])};
   }
   u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
   *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n) = o;
@@ -197,10 +195,35 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_kernel(const GemmP
     }
     wg_barrier();                                   // all waves are done reading the last stage buffer
     char* st = smem + ((gs + NSTAGE - 1) % NSTAGE) * STAGE + wave * (SR * 256);
+    // pieces of this lane: item = (i, hp, h) -> row m_of(item), columns n_lane .. n_lane + 7
+    constexpr int HPI = 16 / SR, HH = SR / 8, NITEM = XF * HPI * HH, PF = 4;
+    const int n_lane = cn0 + wn * 16 * WF + (lane & 7) * 8;
+    const bool n_ok = n_lane < p.N;
+    auto m_of = [&](int item) { return cm0 + wm * 16 * XF + (item / (HPI * HH)) * 16 + ((item / HH) % HPI) * SR + (lane >> 3) + 8 * (item % HH); };
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (EPI != 4 && p.bias && n_ok) {
+      b0 = *reinterpret_cast<const f32x4*>(p.bias + n_lane);
+      b1 = *reinterpret_cast<const f32x4*>(p.bias + n_lane + 4);
+    }
+    auto fetch = [&](int item) -> u32x4 {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if constexpr (EPI == 3 || EPI == 4) {
+        const int m = m_of(item);
+        if (m < p.M && n_ok) {
+          const T* src = EPI == 3 ? reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n_lane
+                                  : reinterpret_cast<const T*>(p.dact_pre) + (int64_t)m * p.lddp + n_lane;
+          v = *reinterpret_cast<const u32x4*>(src);
+        }
+      }
+      return v;
+    };
+    u32x4 ext[NITEM];
+#pragma unroll
+    for (int it2 = 0; it2 < PF && it2 < NITEM; ++it2) ext[it2] = fetch(it2);
 #pragma unroll
     for (int i = 0; i < XF; ++i) {
 #pragma unroll
-      for (int hp = 0; hp < 16 / SR; ++hp) {
+      for (int hp = 0; hp < HPI; ++hp) {
         if (SR == 16 || (il >> 3) == hp) {
           const int wr = il & (SR - 1);
 #pragma unroll
@@ -209,12 +232,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_kernel(const GemmP
         // lanes exchange rows through the slice: keep the reads out of the (possibly divergent) write region
         wave_sync();
 #pragma unroll
-        for (int h = 0; h < SR / 8; ++h) {
+        for (int h = 0; h < HH; ++h) {
+          const int item = (i * HPI + hp) * HH + h;
+          if (item + PF < NITEM) ext[item + PF] = fetch(item + PF);
           const int r = (lane >> 3) + 8 * h, c8 = lane & 7;
           const f32x4 a0 = __builtin_bit_cast(f32x4, lds_read16(st, r * 256 + (((2 * c8) ^ r) << 4)));
           const f32x4 a1 = __builtin_bit_cast(f32x4, lds_read16(st, r * 256 + (((2 * c8 + 1) ^ r) << 4)));
-          const int m = cm0 + wm * 16 * XF + i * 16 + hp * SR + r, n = cn0 + wn * 16 * WF + c8 * 8;
-          if (m < p.M && n < p.N && !(p.dbg & 1)) big_epilogue8<EPI>(p, m, n, a0, a1);
+          const int m = m_of(item);
+          if (m < p.M && n_ok && !(p.dbg & 1)) big_epilogue8<EPI>(p, m, n_lane, a0, a1, b0, b1, ext[item]);
         }
         wave_sync();
       }
