@@ -51,6 +51,65 @@ __global__ void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__
     *reinterpret_cast<f32x4*>(d0) = s0; *reinterpret_cast<f32x4*>(d1) = s1;
   }
 }
+
+// bf16, C in {64, 128, 256}: 16-byte loads, every lane busy (256 / (C/8) rows per pass), four passes in flight.
+// Same partial layout as above.  grid (1, chunks).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_wide_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ y,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              int64_t R, int C, int64_t win, int64_t halo, int64_t valid,
+                                                              float* __restrict__ partial, int rows_per_block) {
+  __shared__ float red[2][256][8];
+  const int tid = threadIdx.x;
+  const int cpr = C >> 3, rpp = 256 / cpr;                  // chunks per row, rows per pass
+  const int ch = tid % cpr, rsub = tid / cpr, c = ch * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(R, r0 + rows_per_block);
+  float s0[8], s1[8], mu[8], rs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; mu[e] = MODE == 1 ? mean[c + e] : 0.f; rs[e] = MODE == 1 ? rstd[c + e] : 1.f; }
+  auto unpack = [](u32x4 w, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo(w[i]); f[2 * i + 1] = bf16hi(w[i]); }
+  };
+  for (int64_t r = r0 + rsub; r < r1; r += 4 * rpp) {
+    u32x4 va[4], vy[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t rr = r + (int64_t)u * rpp;
+      ok[u] = rr < r1 && row_valid(rr, win, halo, valid);
+      va[u] = u32x4{0u, 0u, 0u, 0u}; vy[u] = va[u];
+      if (ok[u]) {
+        va[u] = *reinterpret_cast<const u32x4*>(a + rr * C + c);
+        if (MODE == 1) vy[u] = *reinterpret_cast<const u32x4*>(y + rr * C + c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      float v[8], w[8];
+      unpack(va[u], v);
+      if (MODE == 1) unpack(vy[u], w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s0[e] += v[e];
+        s1[e] += MODE == 0 ? v[e] * v[e] : v[e] * ((w[e] - mu[e]) * rs[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][tid][e] = s0[e]; red[1][tid][e] = s1[e]; }
+  __syncthreads();
+  // thread t < 2*C sums column (t % C) of array (t / C) over the rpp row groups
+  for (int t = tid; t < 2 * C; t += 256) {
+    const int which = t / C, col = t % C, cch = col >> 3, e = col & 7;
+    float acc = 0.f;
+    for (int g = 0; g < rpp; ++g) acc += red[which][g * cpr + cch][e];
+    partial[((int64_t)blockIdx.y * 2 + which) * C + col] = acc;
+  }
+}
+
 template <typename T>
 __global__ void bn_apply_fwd_kernel(const T* __restrict__ y, T* __restrict__ z, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -113,7 +172,10 @@ static int bn_reduce(const char* who, const void* a, const void* y, const float*
   const int rpb = bn_rows_per_block(R, C);
   const int chunks = (int)((R + rpb - 1) / rpb);
   dim3 grid((uint32_t)((C + 255) / 256), (uint32_t)chunks);
-  if (dtype == DL_BF16)
+  if (dtype == DL_BF16 && (C == 64 || C == 128 || C == 256) && ((uintptr_t)a & 15) == 0 && (!y || ((uintptr_t)y & 15) == 0))
+    hipLaunchKernelGGL((bn_partial_wide_kernel<MODE>), dim3(1, (uint32_t)chunks), dim3(256), 0, s, (const bf16_t*)a,
+                       (const bf16_t*)y, mean, rstd, R, (int)C, win, halo, valid, (float*)ws, rpb);
+  else if (dtype == DL_BF16)
     hipLaunchKernelGGL((bn_partial_kernel<bf16_t, MODE>), grid, dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)y,
                        mean, rstd, R, (int)C, win, halo, valid, (float*)ws, rpb);
   else
