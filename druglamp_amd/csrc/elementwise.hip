@@ -341,20 +341,37 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const dl_wprep_item* _
   }
 }
 
-// out[l][d] (+)= sum_b x[(b*L + l)][d]
+// out[l][d] (+)= sum_b x[(b*L + l)][d].  One 64-lane column group per workgroup; its four waves take every fourth
+// batch element with four loads in flight each, then reduce through LDS (fixed order).
 template <typename T>
-__global__ void rowmod_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int D, int64_t L,
-                                  int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void rowmod_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M, int D,
+                                                          int64_t L, int accumulate) {
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   const int64_t n4 = L * (D / 4);
-  if (i >= n4) return;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
   const int64_t l = i / (D / 4);
   const int col = (int)(i % (D / 4)) * 4;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t row = l; row < M; row += L) s += load4<T>(x + row * D + col);
-  float* dst = out + l * D + col;
-  if (accumulate) s += *reinterpret_cast<const f32x4*>(dst);
-  *reinterpret_cast<f32x4*>(dst) = s;
+  if (i < n4) {
+    const int64_t nb = M / L;
+    int64_t b = wave;
+    for (; b + 12 < nb; b += 16) {
+      s0 += load4<T>(x + ((b) * L + l) * D + col);
+      s1 += load4<T>(x + ((b + 4) * L + l) * D + col);
+      s2 += load4<T>(x + ((b + 8) * L + l) * D + col);
+      s3 += load4<T>(x + ((b + 12) * L + l) * D + col);
+    }
+    for (; b < nb; b += 4) s0 += load4<T>(x + (b * L + l) * D + col);
+  }
+  red[wave][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wave == 0 && i < n4) {
+    f32x4 s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float* dst = out + l * D + col;
+    if (accumulate) s += *reinterpret_cast<const f32x4*>(dst);
+    *reinterpret_cast<f32x4*>(dst) = s;
+  }
 }
 
 // ---------------- AdamW --------------------------------------------------------------------------
@@ -608,10 +625,10 @@ extern "C" int dl_rowmod_sum(const void* x, float* out, int64_t M, int64_t D, in
   DL_CHECK_ARG(x && out && M > 0 && D > 0 && D % 4 == 0 && L > 0 && M % L == 0, DL_ERR_ARG, "dl_rowmod_sum: bad args");
   const int64_t n4 = L * D / 4;
   if (dtype == DL_BF16)
-    hipLaunchKernelGGL((rowmod_sum_kernel<bf16_t>), dim3(nblk(n4, 64)), dim3(64), 0, s, (const bf16_t*)x, out, M,
+    hipLaunchKernelGGL((rowmod_sum_kernel<bf16_t>), dim3(nblk(n4, 64)), dim3(256), 0, s, (const bf16_t*)x, out, M,
                        (int)D, L, accumulate);
   else
-    hipLaunchKernelGGL((rowmod_sum_kernel<float>), dim3(nblk(n4, 64)), dim3(64), 0, s, (const float*)x, out, M,
+    hipLaunchKernelGGL((rowmod_sum_kernel<float>), dim3(nblk(n4, 64)), dim3(256), 0, s, (const float*)x, out, M,
                        (int)D, L, accumulate);
   DL_CHECK_LAUNCH("dl_rowmod_sum");
   return DL_OK;

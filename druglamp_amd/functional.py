@@ -474,9 +474,7 @@ class TokenGateFn(torch.autograd.Function):
         cdt = v2.dtype
         dv_gate, dlogits = ops.token_gate_bwd(dout.contiguous(), v2.reshape(B, L, D), gate, H, add_residual)
         dl2 = dlogits.reshape(M, H)
-        dw2 = ops.gemm(dl2, hid, M=H, N=dd, K=M, x_kslow=True, w_kslow=True, ldx=H, ldw=dd, out_dtype=torch.float32,
-                       split_k=0)
-        db2 = ops.colsum(dl2)
+        dw2, db2 = _wgrad(dl2, hid, H, dd, M, H, dd)
         if cdt == torch.bfloat16 and H <= 64 and dd % 8 == 0:
             # K = H (8) is far below one k-step: zero-pad the contraction to 64 so that the product takes the
             # LDS-DMA large-tile kernel with the gelu' epilogue (was 219 us in the register-staged general path)
