@@ -83,26 +83,28 @@ extern "C" int dl_prof_collect(int32_t family, int64_t* launches, double* total_
 
 __global__ void dl_reduce_partials_kernel(const float* __restrict__ partial, int chunks, int64_t stride, int ncols,
                                           float* __restrict__ out, int accumulate) {
-  // blockDim.x = 64 * NW waves; wave w takes chunks w, w+NW, ... (4 loads in flight per thread)
-  __shared__ float red[16][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  // 1024 threads = 16 columns x 64 row-lanes (DL_REDUCE_COLS columns per workgroup -> ncols / 16 workgroups, four
+  // times the parallelism of the old 64-column form whose 8..16 workgroups took 12 us on 2048-chunk LayerNorm
+  // partials).  Row-lane k sums chunks k, k + 64, ... with four loads in flight, then a fixed-order LDS tree.
+  __shared__ float red[64][17];
+  const int cl = threadIdx.x & 15, k = threadIdx.x >> 4;
+  const int c = blockIdx.x * DL_REDUCE_COLS + cl;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (c < ncols) {
-    int k = wave;
-    for (; k + 3 * nw < chunks; k += 4 * nw) {
-      a0 += partial[(int64_t)k * stride + c];
-      a1 += partial[(int64_t)(k + nw) * stride + c];
-      a2 += partial[(int64_t)(k + 2 * nw) * stride + c];
-      a3 += partial[(int64_t)(k + 3 * nw) * stride + c];
+    int z = k;
+    for (; z + 192 < chunks; z += 256) {
+      a0 += partial[(int64_t)z * stride + c];
+      a1 += partial[(int64_t)(z + 64) * stride + c];
+      a2 += partial[(int64_t)(z + 128) * stride + c];
+      a3 += partial[(int64_t)(z + 192) * stride + c];
     }
-    for (; k < chunks; k += nw) a0 += partial[(int64_t)k * stride + c];
+    for (; z < chunks; z += 64) a0 += partial[(int64_t)z * stride + c];
   }
-  red[wave][lane] = (a0 + a1) + (a2 + a3);
+  red[k][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (wave == 0 && c < ncols) {
-    float s = 0.f;
-    for (int w = 0; w < nw; ++w) s += red[w][lane];
-    out[c] = accumulate ? out[c] + s : s;
+  for (int half = 32; half > 0; half >>= 1) {
+    if (k < half) red[k][cl] += red[k + half][cl];
+    __syncthreads();
   }
+  if (k == 0 && c < ncols) out[c] = accumulate ? out[c] + red[0][cl] : red[0][cl];
 }

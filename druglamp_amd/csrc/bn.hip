@@ -181,7 +181,7 @@ static int bn_reduce(const char* who, const void* a, const void* y, const float*
   else
     hipLaunchKernelGGL((bn_partial_kernel<float, MODE>), grid, dim3(256), 0, s, (const float*)a, (const float*)y, mean,
                        rstd, R, (int)C, win, halo, valid, (float*)ws, rpb);
-  hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((2 * C + 63) / 64)), dim3(1024), 0, s, (const float*)ws,
+  hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((2 * C + DL_REDUCE_COLS - 1) / DL_REDUCE_COLS)), dim3(1024), 0, s, (const float*)ws,
                      chunks, (int64_t)(2 * C), (int)(2 * C), sums, 0);
   DL_CHECK_LAUNCH(who);
   return DL_OK;

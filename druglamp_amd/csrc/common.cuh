@@ -306,8 +306,8 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblocks) {
 }
 
 // Second stage of the two-stage column reductions: out[c] (+)= sum_k partial[k*stride + c], c < ncols.
-// One workgroup (4 waves) per 64 columns; wave w takes chunks w, w+4, ... with 4 independent
-// accumulators (loads are coalesced 256-byte rows), then the 4 waves combine through LDS.
-// Deterministic (fixed summation order).
+// One 1024-thread workgroup per DL_REDUCE_COLS columns (16 columns x 64 row-lanes); deterministic (fixed
+// summation order).
+constexpr int DL_REDUCE_COLS = 16;   // columns per workgroup of dl_reduce_partials_kernel (launch with 1024 threads)
 __global__ void dl_reduce_partials_kernel(const float* __restrict__ partial, int chunks, int64_t stride, int ncols,
                                           float* __restrict__ out, int accumulate);

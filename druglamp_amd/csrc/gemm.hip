@@ -859,7 +859,7 @@ extern "C" int dl_colsum(const void* X, int64_t ldx, int64_t M, int64_t N, int32
     hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)X, ldx, M,
                        (int)N, (float*)workspace, rpb);
   DL_CHECK_LAUNCH("dl_colsum(partial)");
-  hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((N + 63) / 64)), dim3(1024), 0, s,
+  hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((N + DL_REDUCE_COLS - 1) / DL_REDUCE_COLS)), dim3(1024), 0, s,
                      (const float*)workspace, chunks, (int64_t)N, (int)N, out, accumulate);
   DL_CHECK_LAUNCH("dl_colsum(final)");
   return DL_OK;

@@ -208,14 +208,14 @@ extern "C" int dl_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
   DL_CHECK_LAUNCH("dl_layernorm_bwd");
   if (dgamma && dbeta == dgamma + D) {
     // adjacent outputs ([2][D]): the partials' [2][D] rows reduce in one launch
-    hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((2 * D + 63) / 64)), dim3(1024), 0, s,
+    hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((2 * D + DL_REDUCE_COLS - 1) / DL_REDUCE_COLS)), dim3(1024), 0, s,
                        (const float*)workspace, nb, (int64_t)(2 * D), (int)(2 * D), dgamma, accumulate);
   } else {
     if (dgamma)
-      hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(1024), 0, s,
+      hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + DL_REDUCE_COLS - 1) / DL_REDUCE_COLS)), dim3(1024), 0, s,
                          (const float*)workspace, nb, (int64_t)(2 * D), (int)D, dgamma, accumulate);
     if (dbeta)
-      hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + 63) / 64)), dim3(1024), 0, s,
+      hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((D + DL_REDUCE_COLS - 1) / DL_REDUCE_COLS)), dim3(1024), 0, s,
                          (const float*)workspace + D, nb, (int64_t)(2 * D), (int)D, dbeta, accumulate);
   }
   DL_CHECK_LAUNCH("dl_layernorm_bwd(final)");
