@@ -86,16 +86,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
     const int64_t rowA = r0 + rr, rowB = r0 + rr + 4;
     if (rowA >= M) break;
     const bool hasB = rowB < M;
-    f32x4 xa[NV_], da[NV_], xb[NV_], db_[NV_];
+    f32x4 xa[NV_], da[NV_], xb[NV_], db_[NV_], ra[NV_], rb[NV_];
 #pragma unroll
     for (int j = 0; j < NV_; ++j) {
       const int c = lane + 64 * j;
+      ra[j] = f32x4{0.f, 0.f, 0.f, 0.f}; rb[j] = ra[j];
       if (c < nv) {
         xa[j] = load4<T>(x + rowA * ldx + c * 4);
         da[j] = load4<T>(dy + rowA * lddy + c * 4);
+        if (dres) ra[j] = load4<T>(dres + rowA * lddres + c * 4);
         if (hasB) {
           xb[j] = load4<T>(x + rowB * ldx + c * 4);
           db_[j] = load4<T>(dy + rowB * lddy + c * 4);
+          if (dres) rb[j] = load4<T>(dres + rowB * lddres + c * 4);
         }
       }
     }
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - c1 - xh[j][e] * c2);
-          if (dres) o += load4<T>(dres + row * lddres + c * 4);
+          o += half == 0 ? ra[j] : rb[j];
           store4<T>(dx + row * lddx + c * 4, o);
         }
       }
