@@ -736,7 +736,7 @@ template <typename T, int HD>
 int launch_bwd(const AttnP& p, hipStream_t s) {
   constexpr int QT = fwd_qt<T>();
   constexpr int QB = 4 * QT * 16;
-  constexpr int KT = (sizeof(T) == 2 && HD == 64) ? 2 : 1;
+  constexpr int KT = sizeof(T) == 2 ? 2 : 1;
   constexpr int KVB = 4 * KT * 16;
   const dim3 gq((uint32_t)((p.Lq + QB - 1) / QB), (uint32_t)p.H, (uint32_t)p.P);
   const dim3 gk((uint32_t)((p.Lk + KVB - 1) / KVB), (uint32_t)p.H, (uint32_t)p.P);
