@@ -33,6 +33,34 @@ struct AttnP {
   float scale;
 };
 
+__device__ __attribute__((aligned(16))) const uint32_t attn_zero_page[4] = {0u, 0u, 0u, 0u};
+
+// LDS-DMA of `total_rows` (a multiple of 64) rows of head_dim elements into an ATile image: source-side XOR
+// swizzle, rows >= valid_rows read a zero page.  NT threads; completes at the next __syncthreads().
+template <typename T, int HD, int NT>
+__device__ __forceinline__ void dma_rows(char* lds, const T* base, int64_t row_stride, int valid_rows, int total_rows) {
+  using TL = ATile<T, HD>;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int nchunks = total_rows * TL::CPR;
+  const char* zero = reinterpret_cast<const char*>(attn_zero_page);
+  for (int c0 = 0; c0 < nchunks; c0 += NT) {
+    const int c = c0 + tid;
+    const int row = c / TL::CPR, ch = (c % TL::CPR) ^ (row & 7);
+    const char* src = (c < nchunks && row < valid_rows) ? reinterpret_cast<const char*>(base + (int64_t)row * row_stride + ch * TL::EPC) : zero;
+    const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((c0 + wave * 64) * 16));
+    if (c0 + wave * 64 < nchunks)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
+  }
+}
+// sum_d a[d] * b[d] over the 8 bf16 of one fragment
+__device__ __forceinline__ float dot8_bf16(u32x4 a, u32x4 b) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += bf16lo(a[i]) * bf16lo(b[i]) + bf16hi(a[i]) * bf16hi(b[i]);
+  return s;
+}
+
 // =================================== forward ===================================================
 template <typename T, int HD, int QT>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnP p) {
@@ -40,9 +68,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnP p)
   constexpr int KF = Mma<T>::KF, NKF = HD / KF, NDT = HD / 16, CT = KF / 16;
   constexpr int KVB = 64, NKT = KVB / 16, NKP = KVB / KF;
   constexpr int QB = 4 * QT * 16;
-  __shared__ __attribute__((aligned(16))) char smem[2 * KVB * TL::RB];
-  char* Ks = smem;
-  char* Vs = smem + KVB * TL::RB;
+  constexpr int BUF = 2 * KVB * TL::RB;                 // one (K tile, V tile) pair
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 15, g = lane >> 4;
   const int bps = (p.Lq + QB - 1) / QB;
@@ -73,19 +100,20 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnP p)
   for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
   const float c = p.scale * LOG2E;
 
-  Stager<T, HD, KVB> sk, sv;
+  // key tiles stream through two LDS buffers by LDS-DMA: one barrier per tile, no register staging
   const int nt = (p.Lk + KVB - 1) / KVB;
-  sk.load(Kb, p.k_rs, 0, p.Lk);
-  sv.load(Vb, p.v_rs, 0, p.Lk);
+  auto stage = [&](int t, int buf) {
+    char* b = smem + buf * BUF;
+    dma_rows<T, HD, ATT_THREADS>(b, Kb + (int64_t)t * KVB * p.k_rs, p.k_rs, p.Lk - t * KVB, KVB);
+    dma_rows<T, HD, ATT_THREADS>(b + KVB * TL::RB, Vb + (int64_t)t * KVB * p.v_rs, p.v_rs, p.Lk - t * KVB, KVB);
+  };
+  stage(0, 0);
   for (int t = 0; t < nt; ++t) {
     const int k0 = t * KVB;
-    sk.store(Ks);
-    sv.store(Vs);
-    __syncthreads();
-    if (t + 1 < nt) {
-      sk.load(Kb, p.k_rs, k0 + KVB, p.Lk);
-      sv.load(Vb, p.v_rs, k0 + KVB, p.Lk);
-    }
+    __syncthreads();                                    // tile t has landed; everyone is done with the other buffer
+    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+    const char* Ks = smem + (t & 1) * BUF;
+    const char* Vs = Ks + KVB * TL::RB;
     // ---- S^T = K Q^T ----
     f32x4 s[QT][NKT];
 #pragma unroll
@@ -191,34 +219,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnP p)
 // page), after which every wave walks its query tiles of BOTH segments over all key tiles with no workgroup
 // barrier and no further K/V traffic; the next unit's Q fragments are requested before the current unit's
 // math.  Same transposed-score math as attn_fwd_kernel.
-__device__ __attribute__((aligned(16))) const uint32_t attn_zero_page[4] = {0u, 0u, 0u, 0u};
-
-// LDS-DMA of `total_rows` (a multiple of 64) rows of head_dim elements into an ATile image: source-side XOR
-// swizzle, rows >= valid_rows read a zero page.  NT threads; completes at the next __syncthreads().
-template <typename T, int HD, int NT>
-__device__ __forceinline__ void dma_rows(char* lds, const T* base, int64_t row_stride, int valid_rows, int total_rows) {
-  using TL = ATile<T, HD>;
-  const int tid = threadIdx.x, wave = tid >> 6;
-  const int nchunks = total_rows * TL::CPR;
-  const char* zero = reinterpret_cast<const char*>(attn_zero_page);
-  for (int c0 = 0; c0 < nchunks; c0 += NT) {
-    const int c = c0 + tid;
-    const int row = c / TL::CPR, ch = (c % TL::CPR) ^ (row & 7);
-    const char* src = (c < nchunks && row < valid_rows) ? reinterpret_cast<const char*>(base + (int64_t)row * row_stride + ch * TL::EPC) : zero;
-    const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((c0 + wave * 64) * 16));
-    if (c0 + wave * 64 < nchunks)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
-  }
-}
-// sum_d a[d] * b[d] over the 8 bf16 of one fragment
-__device__ __forceinline__ float dot8_bf16(u32x4 a, u32x4 b) {
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) s += bf16lo(a[i]) * bf16lo(b[i]) + bf16hi(a[i]) * bf16hi(b[i]);
-  return s;
-}
-
 template <typename T, int HD, int QT, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_res_kernel(const AttnP p) {
   using TL = ATile<T, HD>;
