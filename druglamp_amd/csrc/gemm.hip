@@ -498,7 +498,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, TO* __rest
 int pick_tw(const dl_gemm_args* a) {
   if (a->x_kslow && a->w_kslow && a->split_k >= 0) {
     const int64_t tiles128 = ((a->M + 127) / 128) * ((a->N + 127) / 128);
-    if (tiles128 <= 4 && a->M >= 256 && a->N >= 256) return 2;
+    if (tiles128 <= 4 && a->M >= 64 && a->N >= 64) return 2;
   }
   return 4;
 }
