@@ -6,6 +6,9 @@ namespace {
 constexpr int LN_MAXV = 8;            // up to 8 x (64 lanes x 4 elems) = 2048 columns
 constexpr int LN_BWD_ROWS = 32;       // rows per workgroup in backward (8 per wave, two in flight)
 
+// One wave per row, LN_FWD_RPW rows per wave with all of their loads issued first (the one-row form was bound by
+// one HBM latency per row: 3.5 TB/s).
+constexpr int LN_FWD_RPW = 2;
 template <typename T, int NV_>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma,
@@ -14,46 +17,58 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
                                                      float* __restrict__ rstd_out, int64_t M, int D,
                                                      float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-  if (row >= M) return;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * LN_FWD_RPW;
+  if (row0 >= M) return;
   const int nv = D >> 2;  // vec4 chunks per row
-  f32x4 v[NV_];
-  float s = 0.f;
+  f32x4 v[LN_FWD_RPW][NV_];
+#pragma unroll
+  for (int r = 0; r < LN_FWD_RPW; ++r)
+#pragma unroll
+    for (int j = 0; j < NV_; ++j) {
+      const int c = lane + 64 * j;
+      v[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < nv && row0 + r < M) v[r][j] = load4<T>(x + (row0 + r) * ldx + c * 4);
+    }
+  f32x4 gm[NV_], bt[NV_];
 #pragma unroll
   for (int j = 0; j < NV_; ++j) {
     const int c = lane + 64 * j;
-    if (c < nv) {
-      v[j] = load4<T>(x + row * ldx + c * 4);
-      s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
-    }
+    gm[j] = bt[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < nv) { gm[j] = *reinterpret_cast<const f32x4*>(gamma + c * 4); bt[j] = *reinterpret_cast<const f32x4*>(beta + c * 4); }
   }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < NV_; ++j) {
-    const int c = lane + 64 * j;
-    if (c < nv) {
+  for (int r = 0; r < LN_FWD_RPW; ++r) {
+    const int64_t row = row0 + r;
+    if (row >= M) break;
+    float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q += d * d; }
+    for (int j = 0; j < NV_; ++j) s += (v[r][j][0] + v[r][j][1]) + (v[r][j][2] + v[r][j][3]);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV_; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[r][j][e] - mean; q += d * d; }
+      }
     }
-  }
-  const float var = wave_sum(q) / (float)D;
-  const float rstd = rsqrtf(var + eps);
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = rsqrtf(var + eps);
 #pragma unroll
-  for (int j = 0; j < NV_; ++j) {
-    const int c = lane + 64 * j;
-    if (c < nv) {
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c * 4);
-      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c * 4);
-      f32x4 o;
+    for (int j = 0; j < NV_; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nv) {
+        f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * gm[e] + bt[e];
-      store4<T>(y + row * ldy + c * 4, o);
+        for (int e = 0; e < 4; ++e) o[e] = (v[r][j][e] - mean) * rstd * gm[j][e] + bt[j][e];
+        store4<T>(y + row * ldy + c * 4, o);
+      }
     }
-  }
-  if (lane == 0) {
-    if (mean_out) mean_out[row] = mean;
-    if (rstd_out) rstd_out[row] = rstd;
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
   }
 }
 
@@ -170,7 +185,7 @@ extern "C" int dl_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, 
   DL_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, DL_ERR_SHAPE,
                "dl_layernorm_fwd: D=%ld must be a multiple of 4 and <= %d", (long)D, 256 * LN_MAXV);
   DL_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0, DL_ERR_ALIGN, "dl_layernorm_fwd: ld must be multiple of 4");
-  const uint32_t blocks = (uint32_t)((M + 3) / 4);
+  const uint32_t blocks = (uint32_t)((M + 4 * LN_FWD_RPW - 1) / (4 * LN_FWD_RPW));
   dl_prof_before(3, s);
 #define LN_FWD(TT, NVV) hipLaunchKernelGGL((ln_fwd_kernel<TT, NVV>), dim3(blocks), dim3(256), 0, s, (const TT*)x, ldx, \
                                           gamma, beta, (TT*)y, ldy, mean, rstd, M, (int)D, eps)
