@@ -498,7 +498,9 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, TO* __rest
 int pick_tw(const dl_gemm_args* a) {
   if (a->x_kslow && a->w_kslow && a->split_k >= 0) {
     const int64_t tiles128 = ((a->M + 127) / 128) * ((a->N + 127) / 128);
-    if (tiles128 <= 4 && a->M >= 64 && a->N >= 64) return 2;
+    // (whole k-steps only: the register-staged 64x64 form is twice slower than the 128-tile one, 202 vs 111 us on the
+    //  128x384x591870 conv gradient)
+    if (tiles128 <= 4 && a->M >= 64 && a->N >= 64 && a->K % (BKB / (int)dl_dtype_size(a->in_dtype)) == 0) return 2;
   }
   return 4;
 }
