@@ -88,4 +88,4 @@ class CrossModality(nn.Module):
         pidx, didx, gt = label_matrix(meta, self.use_cm)
         p_lats, d_lats = self.latents_from_means(*means, pidx, didx)
         gt_dev = torch.from_numpy(gt).to(p_lats.device)
-        return Fn.TripletSigCosFn.apply(p_lats, d_lats, gt_dev, float(self.m_sch_loss_fn.margin))
+        return Fn.TripletSigCosFn.apply(p_lats.float(), d_lats.float(), gt_dev, float(self.m_sch_loss_fn.margin))

@@ -84,7 +84,7 @@ class SSL(nn.Module):
     def drug_simclr(self, vd, xd):
         q = self.net(vd.reshape(-1, vd.shape[-1]))
         k = self.llm_net(xd.reshape(-1, xd.shape[-1]))
-        return Fn.NTXentFn.apply(q, k, self.temperature)
+        return Fn.NTXentFn.apply(q.float(), k.float(), self.temperature)
 
     def drug_simsiam(self, vd, xd):
         one, two = vd.reshape(-1, vd.shape[-1]), xd.reshape(-1, xd.shape[-1])
@@ -93,7 +93,7 @@ class SSL(nn.Module):
         with torch.no_grad():
             t_one = self.net(one)
             t_two = self.llm_net(two)
-        rows = Fn.CosRowLossFn.apply(pred_one, t_two) + Fn.CosRowLossFn.apply(pred_two, t_one)
+        rows = Fn.CosRowLossFn.apply(pred_one.float(), t_two.float()) + Fn.CosRowLossFn.apply(pred_two.float(), t_one.float())
         return rows.mean()
 
     def prot_mlm(self, seq, extractor, xp, fill_bit, mode, mask_ignore_token_ids=(0,), mask_prob=0.15,

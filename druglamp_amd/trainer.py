@@ -186,13 +186,15 @@ class Trainer:
             kw = dict(ssl_input)
             if ssl_masks is not None:
                 kw.update(mask=ssl_masks[0], replace=ssl_masks[1])
-            d = m.ssl_model(**kw)
+            with m._glue():                 # bf16 compute dtype: the heads' torch layers run under bf16 autocast
+                d = m.ssl_model(**kw)
             ssl_loss = (d["prot_ssl"] + d["drug_ssl"]) * 0.1
             ssl_loss.backward(retain_graph=compute_cm)
             out["ssl"] = ssl_loss.detach()
         if compute_cm:
             self._zero_grad()
-            cm_loss = m.cm_model(**cm_input, meta=meta)
+            with m._glue():
+                cm_loss = m.cm_model(**cm_input, meta=meta)
             if cur_epoch == self.cm_init_epoch:
                 c, l = float(cm_loss), float(cls_loss)
                 if c > 0:
