@@ -912,9 +912,34 @@ class BatchNormRowsFn(torch.autograd.Function):
 
 def batch_norm_rows(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor) -> torch.Tensor:
     """nn.BatchNorm1d semantics (incl. running statistics, momentum, unbiased running variance)."""
-    y, mean, var = BatchNormRowsFn.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.eps,
+    C = x2d.shape[1]
+    w = bn.weight if bn.weight is not None else torch.ones(C, device=x2d.device)      # affine=False
+    b = bn.bias if bn.bias is not None else torch.zeros(C, device=x2d.device)
+    y, mean, var = BatchNormRowsFn.apply(x2d, w, b, bn.running_mean, bn.running_var, bn.training, bn.eps,
                                          bn.momentum if bn.training else None)
     if bn.training:
         with torch.no_grad():
             bn.num_batches_tracked += 1        # running mean / var were updated by dl_bn_finalize
     return y
+
+
+def run_mlp(seq, x: torch.Tensor) -> torch.Tensor:
+    """An nn.Sequential of Linear / BatchNorm1d / ReLU (the SimSiam projector and predictor MLPs,
+    self_supervised_learning.py:126-143) applied to rows x [M, K'] on the HIP path: every Linear is a dl_gemm
+    (DenseFn: widths padded to multiples of 8, K' may carry zero padding columns), every BatchNorm1d the dl_bn_*
+    kernels incl. the running-statistics update.  The modules stay plain torch parameter holders."""
+    import torch.nn as nn
+    for layer in seq:
+        if isinstance(layer, nn.Linear):
+            if x.shape[-1] < layer.in_features:
+                raise ValueError("run_mlp: input narrower than the layer")
+            x = dense(x, layer.weight, layer.bias)
+        elif isinstance(layer, nn.BatchNorm1d):
+            if x.shape[-1] != layer.num_features:
+                x = x[:, :layer.num_features].contiguous()
+            x = batch_norm_rows(layer, x)
+        elif isinstance(layer, nn.ReLU):
+            x = torch.relu(x)
+        else:
+            raise NotImplementedError("run_mlp: %s" % type(layer).__name__)
+    return x

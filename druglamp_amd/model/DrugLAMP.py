@@ -22,7 +22,7 @@ class DrugLAMP(DrugLAMPBase):
         # the reference concatenates the fill bits onto the raw tensors here (DrugLAMP.py:11-19); those copies
         # are only consumed by the SSL head, so they are handed over as (tensor, fill bit) pairs and
         # materialised by SSL.forward on SSL epochs only
-        ssl = {"vp": vp, "xp": (xp, fill_p), "fill_bit_p": fill_p, "vd": vd, "xd": (xd, fill_d)}
+        ssl = {"vp": vp, "xp": (xp, fill_p), "fill_bit_p": fill_p, "vd": vd, "xd": (xdp, xd.shape[-1] + 1)}   # drug LLM features + fill bit, zero-padded to 392 columns
         xp, xd = xps, xdp
         vpc = self.protein_extractor(vp, fill_p, site_pool=self.site_len)       # compute dtype
         vdc = Fn.cast(vd, cdt)

@@ -259,7 +259,7 @@ class DrugLAMPBase(nn.Module):
             raise ValueError("compute dtype must be float32 or bfloat16")
         self.compute_dtype = dtype
         for m in self.modules():
-            if isinstance(m, (GuidedCrossAttention, MultiHeadLinearAttention, PairedMultimodelAttention, ProteinCNN, MolecularGCN)):
+            if isinstance(m, (GuidedCrossAttention, MultiHeadLinearAttention, PairedMultimodelAttention, ProteinCNN, MolecularGCN, SSL)):
                 m.compute_dtype = dtype
         return self
 

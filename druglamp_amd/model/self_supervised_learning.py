@@ -53,10 +53,13 @@ class SimProj(nn.Module):
         self.projection_out = projection_out
         self.projection_hidden_size = projection_hidden_size
 
-    def forward(self, x):
+    def forward(self, x, in_dim=None):
+        """x may carry zero padding columns beyond in_dim (the fill-bit-augmented LLM features are 385 -> 392 wide)."""
         if self.projector is None:
-            self.projector = _simsiam_mlp(x.shape[1], self.projection_out, self.projection_hidden_size).to(x.device)
-        return self.projector(x)
+            self.projector = _simsiam_mlp(in_dim or x.shape[1], self.projection_out, self.projection_hidden_size).to(x.device)
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+            return Fn.run_mlp(self.projector, x)
+        return self.projector(x[:, :self.projector[0].in_features])
 
 
 class SSL(nn.Module):
@@ -81,18 +84,37 @@ class SSL(nn.Module):
             if proj.projector is None:
                 proj.projector = _simsiam_mlp(dim, proj.projection_out, proj.projection_hidden_size).to(device)
 
+    compute_dtype = torch.float32
+
+    def _rows(self, vd, xd):
+        """(vd rows, xd rows, xd feature width).  xd is either the reference's (B, L, 385) tensor or the
+        (padded features (B, L, 392), 385) pair the DrugLAMP forward hands over."""
+        xd_dim = None
+        if isinstance(xd, (tuple, list)) and isinstance(xd[1], int):
+            xd, xd_dim = xd
+        one, two = vd.reshape(-1, vd.shape[-1]), xd.reshape(-1, xd.shape[-1])
+        if one.is_cuda:
+            one, two = Fn.cast(one, self.compute_dtype), Fn.cast(two, self.compute_dtype)
+        return one, two, xd_dim
+
+    def _predict(self, x):
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+            return Fn.run_mlp(self.predictor, x)
+        return self.predictor(x)
+
     def drug_simclr(self, vd, xd):
-        q = self.net(vd.reshape(-1, vd.shape[-1]))
-        k = self.llm_net(xd.reshape(-1, xd.shape[-1]))
+        one, two, xd_dim = self._rows(vd, xd)
+        q = self.net(one)
+        k = self.llm_net(two, xd_dim)
         return Fn.NTXentFn.apply(q.float(), k.float(), self.temperature)
 
     def drug_simsiam(self, vd, xd):
-        one, two = vd.reshape(-1, vd.shape[-1]), xd.reshape(-1, xd.shape[-1])
-        pred_one = self.predictor(self.net(one))
-        pred_two = self.predictor(self.llm_net(two))
+        one, two, xd_dim = self._rows(vd, xd)
+        pred_one = self._predict(self.net(one))
+        pred_two = self._predict(self.llm_net(two, xd_dim))
         with torch.no_grad():
             t_one = self.net(one)
-            t_two = self.llm_net(two)
+            t_two = self.llm_net(two, xd_dim)
         rows = Fn.CosRowLossFn.apply(pred_one.float(), t_two.float()) + Fn.CosRowLossFn.apply(pred_two.float(), t_one.float())
         return rows.mean()
 
@@ -116,7 +138,7 @@ class SSL(nn.Module):
     def forward(self, vp, xp, fill_bit_p, vd, xd, p_mode="double", mask=None, replace=None):
         if isinstance(xp, (tuple, list)):          # (embeddings (B,S,640), fill bit (B,S)) -> (B,S,641)
             xp = torch.cat((xp[0], xp[1].unsqueeze(-1).to(xp[0].dtype)), dim=-1)
-        if isinstance(xd, (tuple, list)):
+        if isinstance(xd, (tuple, list)) and not isinstance(xd[1], int):
             xd = torch.cat((xd[0], xd[1].unsqueeze(-1).to(xd[0].dtype)), dim=-1)
         prot = self.prot_mlm(vp, self.extractor, xp, fill_bit_p, p_mode, mask=mask, replace=replace)
         if vd is None or xd is None:
