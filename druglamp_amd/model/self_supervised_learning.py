@@ -127,17 +127,30 @@ class SSL(nn.Module):
         labels = seq.masked_fill(~mask, pad_token_id).long()
         masked_seq = seq.clone().detach().masked_fill(mask & replace, mask_token_id)
         loss = 0.0
+        n_cls = self.to_logits.out_features
+
+        def head(lin, h):
+            # nn.Linear on the HIP GEMM path (DenseFn: output padded to 32 columns, input may carry zero padding)
+            if h.is_cuda and h.dtype in (torch.float32, torch.bfloat16):
+                return Fn.dense(h, lin.weight, lin.bias)[..., :n_cls]
+            return lin(h[..., :lin.in_features])
+
         if mode != "xp":
-            logits = self.to_logits(extractor(masked_seq, fill_bit))
+            logits = head(self.to_logits, extractor(masked_seq, fill_bit))
             loss = loss + F.cross_entropy(logits.float().transpose(1, 2), labels, ignore_index=pad_token_id)
         if mode != "vp":
-            llm_logits = self.llm_to_logits(xp)
+            llm_logits = head(self.llm_to_logits, xp)
             loss = loss + F.cross_entropy(llm_logits.float().transpose(1, 2), labels, ignore_index=pad_token_id)
         return loss / 2 if mode == "double" else loss
 
     def forward(self, vp, xp, fill_bit_p, vd, xd, p_mode="double", mask=None, replace=None):
         if isinstance(xp, (tuple, list)):          # (embeddings (B,S,640), fill bit (B,S)) -> (B,S,641)
-            xp = torch.cat((xp[0], xp[1].unsqueeze(-1).to(xp[0].dtype)), dim=-1)
+            if xp[0].is_cuda and xp[0].dtype in (torch.float32, torch.bfloat16):
+                # one pass: fill-bit-augmented features, zero-padded to 648 columns, compute dtype
+                from .. import ops
+                xp = ops.fill_pool(xp[0], 1, self.compute_dtype)[1]
+            else:
+                xp = torch.cat((xp[0], xp[1].unsqueeze(-1).to(xp[0].dtype)), dim=-1)
         if isinstance(xd, (tuple, list)) and not isinstance(xd[1], int):
             xd = torch.cat((xd[0], xd[1].unsqueeze(-1).to(xd[0].dtype)), dim=-1)
         prot = self.prot_mlm(vp, self.extractor, xp, fill_bit_p, p_mode, mask=mask, replace=replace)
