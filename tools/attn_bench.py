@@ -9,7 +9,8 @@ def timeit(fn, n=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 dt = torch.bfloat16
 # (name, P, H, S, shift, Lq, Lk, hd)
-cases = [("pmma paired", 512, 4, 2, 256, 256, 256, 64), ("pmma self", 256, 4, 1, 0, 256, 256, 128), ("pgca", 256, 1, 1, 0, 256, 512, 128)]
+cases = [("pmma paired", 512, 4, 2, 256, 256, 256, 64), ("pmma self", 256, 4, 1, 0, 256, 256, 128), ("pgca", 256, 1, 1, 0, 256, 512, 128),
+         ("north-star x-attn (B=256, Ld=64, Lp=512, d=256)", 256, 4, 1, 0, 64, 512, 64), ("same, 2 heads of 128", 256, 2, 1, 0, 64, 512, 128)]
 for name, P, H, S, shift, Lq, Lk, hd in cases:
     d = H * hd
     qkv = (torch.randn(P * Lq, 3 * d, device=dev) * 0.5).to(dt)
