@@ -205,11 +205,15 @@ __global__ __launch_bounds__(256) void embed_pad_kernel(const int64_t* __restric
 // so a workgroup that loads the S strips of RR rows {n_site*k + r0 .. + RR} (k < S) has every contribution to
 // its C*RR outputs.  Backward is the same index map read the other way (each z element feeds one output).
 constexpr int SP_RR = 32;
+constexpr int SP_PITCH = 34;      // elements per LDS image row of the forward kernel (68 bytes)
 template <typename T>
 __global__ __launch_bounds__(256) void cnn_sitepool_fwd_kernel(const T* __restrict__ z, T* __restrict__ out, int L, int C,
                                                                 int halo, int S) {
+  // LDS image T[v = c * S + k][i] (pitch SP_PITCH elements): the row index v is exactly the order in which the
+  // S contributions of output column q are consumed (v = s * C + q), so the gather below reads contiguous rows;
+  // the scattered 2-byte writes of the load phase land on 8 different banks per 16 lanes with this pitch.
   extern __shared__ __attribute__((aligned(16))) char sp_smem[];
-  T* strip = reinterpret_cast<T*>(sp_smem);                 // [S][RR][C]
+  T* img = reinterpret_cast<T*>(sp_smem);                   // [C * S][SP_PITCH]
   const int n_site = L / S;
   const int b = blockIdx.y, r0 = blockIdx.x * SP_RR, tid = threadIdx.x;
   const int LP = L + 2 * halo;
@@ -218,9 +222,15 @@ __global__ __launch_bounds__(256) void cnn_sitepool_fwd_kernel(const T* __restri
   for (int c = tid; c < S * SP_RR * cpr; c += 256) {
     const int row = c / cpr, ch = c % cpr, k = row / SP_RR, i = row % SP_RR;
     const int l = n_site * k + r0 + i;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (r0 + i < n_site) v = *reinterpret_cast<const u32x4*>(zb + (int64_t)(halo + l) * C + ch * 8);
-    *reinterpret_cast<u32x4*>(strip + (int64_t)row * C + ch * 8) = v;
+    T v[8];
+    if (r0 + i < n_site) {
+      *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(zb + (int64_t)(halo + l) * C + ch * 8);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) img[((ch * 8 + e) * S + k) * SP_PITCH + i] = v[e];
   }
   __syncthreads();
   const float inv = 1.0f / (float)S;
@@ -231,10 +241,13 @@ __global__ __launch_bounds__(256) void cnn_sitepool_fwd_kernel(const T* __restri
 #pragma unroll
     for (int i = 0; i < SP_RR / 2; ++i) acc[i] = 0.f;
     for (int s = 0; s < S; ++s) {
-      const int v = s * C + q, cc = v / S, k = v % S;
-      const T* src = strip + ((int64_t)k * SP_RR + i0) * C + cc;
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(img + (int64_t)(s * C + q) * SP_PITCH + i0);
 #pragma unroll
-      for (int i = 0; i < SP_RR / 2; ++i) acc[i] += to_f32(src[(int64_t)i * C]);
+      for (int i = 0; i < SP_RR / 4; ++i) {
+        const uint32_t u = src[i];
+        acc[2 * i] += bf16lo(u);
+        acc[2 * i + 1] += bf16hi(u);
+      }
     }
     T* dst = out + (int64_t)b * L / S * C + (int64_t)n_site * q + r0 + i0;
 #pragma unroll
@@ -576,7 +589,7 @@ static int sitepool_check(const char* who, const void* a, const void* b, int64_t
   DL_CHECK_ARG(a && b && B > 0 && L > 0 && C > 0 && halo >= 0 && site_len > 0, DL_ERR_ARG, "%s: bad args", who);
   DL_CHECK_ARG(L % site_len == 0 && C % 8 == 0 && dtype == DL_BF16, DL_ERR_SHAPE,
                "%s: needs L %% site_len == 0, C %% 8 == 0, bf16 (the fp32 pipelines take the torch formulation)", who);
-  DL_CHECK_ARG((int64_t)site_len * SP_RR * C * 2 <= 160 * 1024 && B <= 65535, DL_ERR_SHAPE, "%s: strip does not fit LDS", who);
+  DL_CHECK_ARG((int64_t)site_len * C * SP_PITCH * 2 <= 160 * 1024 && B <= 65535, DL_ERR_SHAPE, "%s: strip does not fit LDS", who);
   return DL_OK;
 }
 extern "C" int dl_cnn_sitepool_fwd(const void* z, void* pooled, int64_t B, int64_t L, int64_t C, int32_t halo,
@@ -585,7 +598,7 @@ extern "C" int dl_cnn_sitepool_fwd(const void* z, void* pooled, int64_t B, int64
   int rc = sitepool_check("dl_cnn_sitepool_fwd", z, pooled, B, L, C, halo, site_len, dtype);
   if (rc != DL_OK) return rc;
   const int n_site = (int)(L / site_len);
-  const size_t lds = (size_t)site_len * SP_RR * C * 2;
+  const size_t lds = (size_t)site_len * C * SP_PITCH * 2;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)cnn_sitepool_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   hipLaunchKernelGGL((cnn_sitepool_fwd_kernel<bf16_t>), dim3((uint32_t)((n_site + SP_RR - 1) / SP_RR), (uint32_t)B), dim3(256), lds, s,
