@@ -63,6 +63,38 @@ __global__ void gate_bwd_kernel(const T* __restrict__ dout, const T* __restrict_
   for (int l = lane; l < L; l += 64) dst[(int64_t)l * H] = from_f32<T>(g[l] * (dg_s[l] - dot));
 }
 
+// Same contract, coalesced: the (b, j) slab is L rows of hd elements laid out contiguously, so 64 lanes x 4 elements
+// cover 256 / hd whole rows per pass (LPR = hd / 4 lanes per row, a power of two) instead of one lane walking a whole
+// row with 64-byte-strided 8-byte accesses; the per-row dot product is a shuffle reduction over LPR lanes.
+template <typename T>
+__global__ void gate_bwd_rows_kernel(const T* __restrict__ dout, const T* __restrict__ v, const float* __restrict__ gate,
+                                     T* __restrict__ dv, T* __restrict__ dlogits, int L, int H, int hd, float res) {
+  extern __shared__ float dg_s[];
+  const int bj = blockIdx.x, b = bj / H, j = bj % H, lane = threadIdx.x;
+  const int64_t base = ((int64_t)b * H + j) * L * hd;
+  const float* g = gate + (int64_t)bj * L;
+  const int lpr = hd >> 2, rpp = 64 / lpr;               // lanes per row, rows per pass
+  const int sub = lane % lpr, rsub = lane / lpr;
+  float dot = 0.f;
+  for (int l0 = 0; l0 < L; l0 += rpp) {
+    const int l = l0 + rsub;
+    float acc = 0.f, gl = 0.f;
+    if (l < L) {
+      gl = g[l];
+      const int64_t e = base + (int64_t)l * hd + sub * 4;
+      const f32x4 d4 = load4<T>(dout + e), v4 = load4<T>(v + e);
+      acc = d4[0] * v4[0] + d4[1] * v4[1] + d4[2] * v4[2] + d4[3] * v4[3];
+      store4<T>(dv + e, d4 * (gl + res));
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (l < L && sub == 0) { dg_s[l] = acc; dot += gl * acc; }
+  }
+  dot = wave_sum(dot);
+  __syncthreads();
+  T* dst = dlogits + (int64_t)b * L * H + j;
+  for (int l = lane; l < L; l += 64) dst[(int64_t)l * H] = from_f32<T>(g[l] * (dg_s[l] - dot));
+}
+
 // ---------------- positional add + dropout / dropout apply -------------------------------------
 template <typename T>
 __global__ void add_rowmod_dropout_kernel(const T* __restrict__ x, const T* __restrict__ pe, T* __restrict__ y,
@@ -461,7 +493,16 @@ extern "C" int dl_token_gate_bwd(const void* dout, const void* v, const float* g
                "dl_token_gate_bwd: bad shape");
   const int hd = (int)(D / H);
   const float res = add_residual ? 1.0f : 0.0f;
-  if (dtype == DL_BF16)
+  const int lpr = hd / 4;
+  const bool rows_form = lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0;
+  if (dtype == DL_BF16 && rows_form)
+    hipLaunchKernelGGL((gate_bwd_rows_kernel<bf16_t>), dim3((uint32_t)(B * H)), dim3(64), (size_t)L * 4, s,
+                       (const bf16_t*)dout, (const bf16_t*)v, gate, (bf16_t*)dv, (bf16_t*)dlogits, (int)L, (int)H,
+                       hd, res);
+  else if (dtype == DL_F32 && rows_form)
+    hipLaunchKernelGGL((gate_bwd_rows_kernel<float>), dim3((uint32_t)(B * H)), dim3(64), (size_t)L * 4, s,
+                       (const float*)dout, (const float*)v, gate, (float*)dv, (float*)dlogits, (int)L, (int)H, hd, res);
+  else if (dtype == DL_BF16)
     hipLaunchKernelGGL((gate_bwd_kernel<bf16_t>), dim3((uint32_t)(B * H)), dim3(64), (size_t)L * 4, s,
                        (const bf16_t*)dout, (const bf16_t*)v, gate, (bf16_t*)dv, (bf16_t*)dlogits, (int)L, (int)H,
                        hd, res);
