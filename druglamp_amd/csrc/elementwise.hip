@@ -198,33 +198,46 @@ __global__ __launch_bounds__(256) void embed_pad_kernel(const int64_t* __restric
                                                          const T* __restrict__ fill, T* __restrict__ out, int64_t B, int L,
                                                          int V, int D, int halo) {
   extern __shared__ __attribute__((aligned(16))) char ep_smem[];
-  T* tab = reinterpret_cast<T*>(ep_smem);                    // [V][D]
-  for (int i = threadIdx.x; i < V * D; i += 256) tab[i] = weight[i];
-  __syncthreads();
+  T* tab = reinterpret_cast<T*>(ep_smem);                    // [V][C]: rows padded to C = D + 1 -> one 16-byte read per chunk
   const int C = D + 1, cpr = C / 8, LP = L + 2 * halo;
-  const int64_t nchunks = B * LP * cpr;
-  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * 256) {
-    const int64_t row = c / cpr;
-    const int ch = (int)(c % cpr);
-    const int64_t b = row / LP;
-    const int lp = (int)(row % LP), l = lp - halo;
+  // weight arrives padded to [V][C] (last column unused): the table is copied with 16-byte loads
+  for (int i = threadIdx.x; i < V * C * (int)sizeof(T) / 16; i += 256)
+    reinterpret_cast<u32x4*>(ep_smem)[i] = reinterpret_cast<const u32x4*>(weight)[i];
+  __syncthreads();
+  // grid (chunks of one sample / 256, B): 32-bit index arithmetic only (three 64-bit divisions per chunk were the
+  // whole cost of the first version of this kernel)
+  const int b = blockIdx.y;
+  const int per_sample = LP * cpr;
+  for (int ci = blockIdx.x * 256 + threadIdx.x; ci < per_sample; ci += gridDim.x * 256) {
+    const int lp = ci / cpr, ch = ci - lp * cpr, l = lp - halo;
+    const int64_t row = (int64_t)b * LP + lp;
     T v[8];
     if (l < 0 || l >= L) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(0.f);
     } else {
-      int64_t id = ids[b * L + l];
+      int64_t id = ids[(int64_t)b * L + l];
       id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-      const T* src = tab + id * D;
+      const T* src = tab + id * C + ch * 8;
+      if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(src);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int col = ch * 8 + e;
-        v[e] = col < D ? src[col] : fill[b * L + l];
+        for (int e = 0; e < 8; ++e) v[e] = src[e];
       }
+      if (ch == cpr - 1) v[7] = fill[(int64_t)b * L + l];  // the last column is the fill bit
     }
     T* dst = out + row * C + ch * 8;
+    if constexpr (sizeof(T) == 2) {
+      u32x4 pk;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dst[e] = v[e];
+      for (int e = 0; e < 4; ++e)
+        pk[e] = (uint32_t)__builtin_bit_cast(uint16_t, v[2 * e]) | ((uint32_t)__builtin_bit_cast(uint16_t, v[2 * e + 1]) << 16);
+      *reinterpret_cast<u32x4*>(dst) = pk;              // one 16-byte store per chunk
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e] = v[e];
+    }
   }
 }
 
@@ -612,9 +625,11 @@ extern "C" int dl_embed_pad(const int64_t* ids, const void* weight, const void* 
   DL_CHECK_ARG(ids && weight && fill && out && B > 0 && L > 0 && V > 0 && D > 0 && halo >= 0, DL_ERR_ARG, "dl_embed_pad: bad args");
   DL_CHECK_ARG((D + 1) % 8 == 0 && (size_t)V * D * dl_dtype_size(dtype) <= 64 * 1024, DL_ERR_SHAPE,
                "dl_embed_pad: needs (D + 1) %% 8 == 0 and a table that fits 64 KB of LDS");
-  const int64_t nchunks = B * (L + 2 * halo) * ((D + 1) / 8);
-  const uint32_t blocks = (uint32_t)((nchunks + 256 * 8 - 1) / (256 * 8) < 4096 ? (nchunks + 256 * 8 - 1) / (256 * 8) : 4096);
-  const size_t lds = (size_t)V * D * dl_dtype_size(dtype);
+  DL_CHECK_ARG(B <= 65535, DL_ERR_SHAPE, "dl_embed_pad: B must fit a grid dimension");
+  const int64_t per_sample = (L + 2 * halo) * ((D + 1) / 8);
+  const int64_t bx = (per_sample + 255) / 256;
+  const dim3 blocks((uint32_t)(bx < 16 ? bx : 16), (uint32_t)B);   // each workgroup builds the LDS table once: keep them few
+  const size_t lds = (size_t)V * (D + 1) * dl_dtype_size(dtype);
   if (dtype == DL_BF16)
     hipLaunchKernelGGL((embed_pad_kernel<bf16_t>), dim3(blocks), dim3(256), lds, s, ids, (const bf16_t*)weight, (const bf16_t*)fill,
                        (bf16_t*)out, B, (int)L, V, D, halo);

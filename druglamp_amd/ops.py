@@ -424,7 +424,7 @@ def embed_pad(ids: torch.Tensor, weight: torch.Tensor, fill: torch.Tensor, halo:
     B, L = ids.shape
     V, D = weight.shape
     ids = ids.contiguous()
-    weight = weight.contiguous()
+    weight = torch.nn.functional.pad(weight, (0, 1)).contiguous()      # [V][D + 1]: 16-byte aligned table rows
     fill = fill.to(weight.dtype).contiguous()
     out = torch.empty((B, L + 2 * halo, D + 1), dtype=weight.dtype, device=weight.device)
     check(_lib.lib().dl_embed_pad(ids.data_ptr(), weight.data_ptr(), fill.data_ptr(), out.data_ptr(), B, L, V, D, halo,

@@ -227,8 +227,8 @@ int dl_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, in
             dl_stream s);
 /* ProteinCNN head (model/basic_model.py:168-171): out[b][halo + l][:D] = weight[ids[b][l]][:] (nn.Embedding row
  * gather), out[b][halo + l][D] = fill[b][l] (the concatenated fill bit); `halo` zero rows on each side of every
- * sample are the conv 'same' padding of this library's channel-last layout.  weight [V][D], fill [B][L] and out
- * [B][L + 2*halo][D + 1] are `dtype`. */
+ * sample are the conv 'same' padding of this library's channel-last layout.  weight is passed PADDED to
+ * [V][D + 1] (last column ignored; 16-byte aligned rows); fill [B][L] and out [B][L + 2*halo][D + 1]; all `dtype`. */
 int dl_embed_pad(const int64_t* ids, const void* weight, const void* fill, void* out, int64_t B, int64_t L,
                  int32_t V, int32_t D, int32_t halo, int32_t dtype, dl_stream s);
 /* ProteinCNN tail (model/basic_model.py:176-179 + DrugLAMP.py:39-40): the reference keeps the conv output
