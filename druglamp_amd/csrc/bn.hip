@@ -11,10 +11,11 @@ static inline int bn_rows_per_block(int64_t R, int64_t C) {
   return (int)((rows + 3) / 4 * 4);
 }
 
+// 32-bit on purpose: a 64-bit modulo costs ~100 instructions and this runs once per row per thread (R < 2^31 is checked)
 __device__ __forceinline__ bool row_valid(int64_t r, int64_t win, int64_t halo, int64_t valid) {
   if (win == 0) return true;
-  const int64_t q = r % win;
-  return q >= halo && q < halo + valid;
+  const uint32_t q = (uint32_t)r % (uint32_t)win;
+  return q >= (uint32_t)halo && q < (uint32_t)(halo + valid);
 }
 
 // grid (ceil(C/256), chunks); lane -> 4 columns; MODE 0: (y, y^2); MODE 1: (dz, dz*yhat)
@@ -115,11 +116,11 @@ __global__ void bn_apply_fwd_kernel(const T* __restrict__ y, T* __restrict__ z, 
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, int64_t R, int C, int64_t win, int64_t halo,
                                     int64_t valid) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c4 = C >> 2;
-  if (i >= R * c4) return;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;          // R * C / 4 < 2^32 is checked by the host
+  const uint32_t c4 = (uint32_t)C >> 2;
+  if (i >= (uint32_t)R * c4) return;
   const int64_t r = i / c4;
-  const int c = (int)(i % c4) * 4;
+  const int c = (int)(i - (uint32_t)r * c4) * 4;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
   if (row_valid(r, win, halo, valid)) {
     const f32x4 v = load4<T>(y + r * C + c);
@@ -135,11 +136,11 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restric
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ sums, float inv_n, int relu_mask, T* __restrict__ dy,
                                     int64_t R, int C, int64_t win, int64_t halo, int64_t valid) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c4 = C >> 2;
-  if (i >= R * c4) return;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;          // R * C / 4 < 2^32 is checked by the host
+  const uint32_t c4 = (uint32_t)C >> 2;
+  if (i >= (uint32_t)R * c4) return;
   const int64_t r = i / c4;
-  const int c = (int)(i % c4) * 4;
+  const int c = (int)(i - (uint32_t)r * c4) * 4;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
   if (row_valid(r, win, halo, valid)) {
     const f32x4 d = load4<T>(dz + r * C + c), yv = load4<T>(y + r * C + c);
@@ -168,6 +169,7 @@ static int bn_reduce(const char* who, const void* a, const void* y, const float*
                      int64_t C, int64_t win, int64_t halo, int64_t valid, int32_t dtype, float* sums, void* ws,
                      size_t ws_bytes, hipStream_t s) {
   DL_CHECK_ARG(a && sums && R > 0 && C > 0 && C % 4 == 0, DL_ERR_ARG, "%s: bad args", who);
+  DL_CHECK_ARG(R < (1ll << 31), DL_ERR_SHAPE, "%s: R must fit 31 bits", who);
   DL_CHECK_ARG(ws && ws_bytes >= dl_bn_workspace_bytes(R, C), DL_ERR_WORKSPACE, "%s: workspace too small", who);
   const int rpb = bn_rows_per_block(R, C);
   const int chunks = (int)((R + rpb - 1) / rpb);
@@ -205,6 +207,7 @@ extern "C" int dl_bn_apply_fwd(const void* y, void* z, const float* mean, const 
                                const float* beta, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid,
                                int32_t dtype, dl_stream stream) {
   hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(R < (1ll << 31) && R * (C / 4) < (1ll << 32), DL_ERR_SHAPE, "dl_bn_apply_fwd: R * C / 4 must fit 32 bits");
   DL_CHECK_ARG(y && z && mean && rstd && gamma && beta && R > 0 && C > 0 && C % 4 == 0, DL_ERR_ARG,
                "dl_bn_apply_fwd: bad args");
   const int64_t n = R * (C / 4);
@@ -223,6 +226,7 @@ extern "C" int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean,
                                const float* sums, float inv_n, int32_t relu_mask, void* dy, int64_t R, int64_t C,
                                int64_t win, int64_t halo, int64_t valid, int32_t dtype, dl_stream stream) {
   hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(R < (1ll << 31) && R * (C / 4) < (1ll << 32), DL_ERR_SHAPE, "dl_bn_bwd_apply: R * C / 4 must fit 32 bits");
   DL_CHECK_ARG(dz && y && mean && rstd && gamma && sums && dy && R > 0 && C > 0 && C % 4 == 0, DL_ERR_ARG,
                "dl_bn_bwd_apply: bad args");
   const int64_t n = R * (C / 4);
