@@ -57,7 +57,8 @@ def get_cfg_defaults() -> CfgNode:
     c.SOLVER = CN(MAX_EPOCH=-1, BATCH_SIZE=-1, NUM_WORKERS=-1, LR=-1., SSL_LR=-1., CM_LR=-1., SEED=-1)
     c.RESULT = CN(OUTPUT_DIR=f"{os.getcwd()}/results/")
     c.RS = CN(TASK=False, METHOD="2C2P", SSL=False, CM=False, INIT_EPOCH=-1, EPOCH_STEP=-1, MAX_MARGIN=-1.,
-              RESET_EPOCH=-1)
+              RESET_EPOCH=-1,
+              GLOBAL_BATCH=False)   # NEW (not in the reference): multi-GPU cross-modal triplets over the all-gathered global batch
     c.COMET = CN(WORKSPACE="lzcstan", PROJECT_NAME="DrugLAMP", USE=True, TAG="Reproduce")
     return c
 

@@ -220,7 +220,7 @@ class DrugLAMPBase(nn.Module):
         self.ssl_model = SSL(prot_extractor=self.protein_extractor, n_prot_feature=n_prot_feature,
                              drug_ssl_type="simsiam", n_hidden=n_hidden)
         self.cm_model = CrossModality(use_cm=True, hidden_size=n_hidden, max_margin=cfg["RS"]["MAX_MARGIN"],
-                                      n_re=cfg["RS"]["RESET_EPOCH"])
+                                      n_re=cfg["RS"]["RESET_EPOCH"], global_batch=bool(cfg["RS"].get("GLOBAL_BATCH", False)))
         model_cfg = CONFIGS["LAMP"](n_hidden)
 
         self.lin_d1 = nn.Linear(n_drug_feature + 1, 2 * n_hidden)
