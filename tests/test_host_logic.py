@@ -160,6 +160,14 @@ def test_c_abi_argument_validation_without_gpu():
     assert L.dl_gemm_workspace_bytes(C.byref(a)) == 4 * 64 * 64 * 4
     a.K, a.split_k = 192, 8                         # 3 k-steps: the plan is trimmed to 3 non-empty slabs
     assert L.dl_gemm_workspace_bytes(C.byref(a)) == 3 * 64 * 64 * 4
+    # weight-gradient form with the fused bias gradient: slabs + one [splits][M] strip; needs x_kslow, w_kslow, split_k = 0
+    a.x_colsum = p16
+    assert L.dl_gemm(C.byref(a), None) == -6 and b"x_colsum" in L.dl_last_error()
+    a.x_kslow = a.w_kslow = 1
+    a.split_k, a.K = 0, 64 * 64
+    sp = L.dl_gemm_workspace_bytes(C.byref(a)) // ((64 * 64 + 64) * 4)
+    assert sp >= 1 and L.dl_gemm_workspace_bytes(C.byref(a)) == sp * (64 * 64 + 64) * 4
+    a.x_colsum, a.x_kslow, a.w_kslow = None, 0, 0
     f = _lib.AttnFwdArgs()
     f.Q = f.K = f.V = f.O = p16
     f.n_problems, f.n_heads, f.n_segments, f.Lq, f.Lk, f.head_dim, f.dtype = 1, 1, 1, 16, 16, 48, _lib.DL_BF16
