@@ -196,7 +196,7 @@ class Trainer:
             with m._glue():
                 cm_loss = m.cm_model(**cm_input, meta=meta)
             if cur_epoch == self.cm_init_epoch:
-                c, l = float(cm_loss), float(cls_loss)
+                c, l = float(cm_loss.detach()), float(cls_loss.detach())
                 if c > 0:
                     while c * self.cm_weight / 10 > l:
                         self.cm_weight /= 10
