@@ -190,6 +190,32 @@ __global__ void fill_pool_kernel(const T* __restrict__ x, T* __restrict__ fill, 
   }
 }
 
+// ---------------- batch assembly from a device-resident embedding store ----------------------------------
+// out[b][s][:] = store[offsets[b] + (s mod len_b)][:] for s < reps_b * len_b, zero afterwards, where
+//   repeat = 1 : reps_b = S / len_b   (reference repeat_pad, utils.py:314-324; len_b > S gives an all-zero block)
+//   repeat = 0 : reps_b = 1           (reference tail_pad,   utils.py:304-312; at most S rows are taken)
+// One 16-byte chunk per thread; 32-bit arithmetic inside a sample.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_pad_kernel(const T* __restrict__ store, const int64_t* __restrict__ offsets,
+                                                          const int32_t* __restrict__ lengths, T* __restrict__ out, int S,
+                                                          int F, int repeat) {
+  const int b = blockIdx.y;
+  const int cpr = F / (16 / (int)sizeof(T));
+  const int len = lengths[b];
+  const int64_t off = offsets[b];
+  const int filled = len <= 0 ? 0 : (repeat ? (S / len) * len : (len < S ? len : S));
+  const int per_sample = S * cpr;
+  for (int ci = blockIdx.x * 256 + threadIdx.x; ci < per_sample; ci += gridDim.x * 256) {
+    const int srow = ci / cpr, ch = ci - srow * cpr;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (srow < filled) {
+      const int r = repeat ? srow % len : srow;
+      v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(store + (off + r) * F) + ch * 16);
+    }
+    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out + ((int64_t)b * S + srow) * F) + ch * 16) = v;
+  }
+}
+
 // ---------------- ProteinCNN head: embedding gather + fill-bit column + halo rows, in one pass ---------------
 // out[b][halo + l][0..D-1] = weight[ids[b][l]][:], out[b][halo + l][D] = fill[b][l]; halo rows are zero.
 // (basic_model.py:168-171: embedding, cat with the fill bit; the zero halo is this library's conv padding.)
@@ -616,6 +642,27 @@ extern "C" int dl_cast(const void* src, int32_t sdt, void* dst, int32_t ddt, int
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
   else { dl_set_error("dl_cast: bad dtypes"); return DL_ERR_ARG; }
   DL_CHECK_LAUNCH("dl_cast");
+  return DL_OK;
+}
+
+extern "C" int dl_gather_pad(const void* store, const int64_t* offsets, const int32_t* lengths, void* out, int64_t B,
+                             int64_t S, int64_t F, int32_t repeat, int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(store && offsets && lengths && out && B > 0 && S > 0 && F > 0, DL_ERR_ARG, "dl_gather_pad: bad args");
+  const int es = (int)dl_dtype_size(dtype);
+  DL_CHECK_ARG((F * es) % 16 == 0 && ((uintptr_t)store & 15) == 0 && ((uintptr_t)out & 15) == 0, DL_ERR_ALIGN,
+               "dl_gather_pad: rows must be whole 16-byte chunks and 16-byte aligned");
+  DL_CHECK_ARG(B <= 65535 && S * (F * es / 16) < (1ll << 31), DL_ERR_SHAPE, "dl_gather_pad: sample too large");
+  const int64_t per_sample = S * (F * es / 16);
+  int64_t bx = (per_sample + 255) / 256;
+  if (bx > 64) bx = 64;
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((gather_pad_kernel<bf16_t>), dim3((uint32_t)bx, (uint32_t)B), dim3(256), 0, s, (const bf16_t*)store, offsets,
+                       lengths, (bf16_t*)out, (int)S, (int)F, repeat);
+  else
+    hipLaunchKernelGGL((gather_pad_kernel<float>), dim3((uint32_t)bx, (uint32_t)B), dim3(256), 0, s, (const float*)store, offsets,
+                       lengths, (float*)out, (int)S, (int)F, repeat);
+  DL_CHECK_LAUNCH("dl_gather_pad");
   return DL_OK;
 }
 

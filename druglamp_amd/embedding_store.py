@@ -1,0 +1,59 @@
+"""Device-resident store of the pre-extracted LLM embeddings.
+
+The reference keeps one `.pt` file per unique drug / protein, `torch.load`s two of them per sample
+(handler/dataset.py:186-195) and pads them on the host in Python loops (utils.py:304-334).  An MI355X has 288 GB of
+HBM: every unique entity's (len, F) embedding is packed ONCE into one contiguous device tensor, and a training batch
+is assembled by one `dl_gather_pad` launch per modality straight into the (B, S, F) layout the model consumes
+(repeat-padding for proteins, tail-padding for drugs) — no per-sample I/O, no host loops, no H2D on the step."""
+from __future__ import annotations
+
+from typing import Dict, Hashable, Iterable, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class EmbeddingStore:
+    def __init__(self, feat_dim: int, dtype: torch.dtype = torch.bfloat16, device="cuda"):
+        self.feat_dim, self.dtype, self.device = feat_dim, dtype, torch.device(device)
+        self._index: Dict[Hashable, Tuple[int, int]] = {}
+        self._chunks, self._rows = [], 0
+        self._store = None
+
+    def add(self, key: Hashable, emb) -> None:
+        """emb: (len, feat_dim) array / tensor.  Keys are unique entities (Drug_ID / Prot_ID)."""
+        if key in self._index:
+            return
+        t = torch.as_tensor(np.asarray(emb) if not torch.is_tensor(emb) else emb)
+        if t.dim() != 2 or t.shape[1] != self.feat_dim:
+            raise ValueError("EmbeddingStore.add: expected (len, %d), got %s" % (self.feat_dim, tuple(t.shape)))
+        self._index[key] = (self._rows, t.shape[0])
+        self._chunks.append(t.to(self.dtype))
+        self._rows += t.shape[0]
+        self._store = None
+
+    def finalize(self) -> "EmbeddingStore":
+        self._store = torch.cat(self._chunks, dim=0).to(self.device).contiguous()
+        self._chunks = [self._store]            # keep one reference so that add() after finalize() still works
+        return self
+
+    @property
+    def nbytes(self) -> int:
+        return self._rows * self.feat_dim * torch.empty((), dtype=self.dtype).element_size()
+
+    def batch(self, keys: Sequence[Hashable], max_rows: int, repeat: bool) -> torch.Tensor:
+        """(B, max_rows, feat_dim): repeat=True is the reference's repeat_pad, repeat=False its tail_pad."""
+        if self._store is None or self._store.shape[0] != self._rows:
+            self.finalize()
+        idx = [self._index[k] for k in keys]
+        offsets = torch.tensor([o for o, _ in idx], dtype=torch.int64, device=self.device)
+        lengths = torch.tensor([n for _, n in idx], dtype=torch.int32, device=self.device)
+        return ops.gather_pad(self._store, offsets, lengths, max_rows, repeat)
+
+
+def collate_llm(prot_store: EmbeddingStore, drug_store: EmbeddingStore, prot_keys: Iterable[Hashable],
+                drug_keys: Iterable[Hashable], prot_rows: int = 9 * 256, drug_rows: int = 512):
+    """(d_llm (B, 512, Dd), p_llm (B, 2304, Dp)) as multimodality_collate_func yields them (utils.py:326-334)."""
+    return drug_store.batch(list(drug_keys), drug_rows, repeat=False), prot_store.batch(list(prot_keys), prot_rows, repeat=True)

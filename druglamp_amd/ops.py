@@ -430,3 +430,13 @@ def embed_pad(ids: torch.Tensor, weight: torch.Tensor, fill: torch.Tensor, halo:
     check(_lib.lib().dl_embed_pad(ids.data_ptr(), weight.data_ptr(), fill.data_ptr(), out.data_ptr(), B, L, V, D, halo,
                                   _dt(weight), _stream()), "dl_embed_pad")
     return out
+
+
+def gather_pad(store: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tensor, S: int, repeat: bool) -> torch.Tensor:
+    """store (rows, F), offsets (B,) int64, lengths (B,) int32 -> (B, S, F); see dl_gather_pad."""
+    _need_gpu(store, offsets, lengths)
+    B, F = offsets.numel(), store.shape[1]
+    out = torch.empty((B, S, F), dtype=store.dtype, device=store.device)
+    check(_lib.lib().dl_gather_pad(store.data_ptr(), offsets.data_ptr(), lengths.data_ptr(), out.data_ptr(), B, S, F,
+                                   int(bool(repeat)), _dt(store), _stream()), "dl_gather_pad")
+    return out

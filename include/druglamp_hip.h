@@ -225,6 +225,16 @@ int dl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, int32_t dt
 /* dst(bf16|f32) = src(f32|bf16) elementwise cast (weight casts, master fp32 -> compute dtype). */
 int dl_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n,
             dl_stream s);
+/* Batch assembly of the pre-extracted LLM embeddings from a DEVICE-RESIDENT packed store (replaces the
+ * reference's per-sample torch.load + host loops, handler/dataset.py:186-195 and utils.py:304-334):
+ *   store   [total_rows][F]  every unique protein / drug embedding, rows of one entity contiguous
+ *   offsets [B] first row of sample b's entity, lengths [B] its row count
+ *   out     [B][S][F]:  repeat = 1 -> the entity's rows written floor(S / len) times back to back, zeros after
+ *                                     (repeat_pad, utils.py:314-324: protein side, S = 9 * 256)
+ *                       repeat = 0 -> rows 0 .. min(len, S) - 1, zeros after (tail_pad, utils.py:304-312: drug side, S = 512)
+ * F * sizeof(dtype) must be a multiple of 16. */
+int dl_gather_pad(const void* store, const int64_t* offsets, const int32_t* lengths, void* out, int64_t B,
+                  int64_t S, int64_t F, int32_t repeat, int32_t dtype, dl_stream s);
 /* ProteinCNN head (model/basic_model.py:168-171): out[b][halo + l][:D] = weight[ids[b][l]][:] (nn.Embedding row
  * gather), out[b][halo + l][D] = fill[b][l] (the concatenated fill bit); `halo` zero rows on each side of every
  * sample are the conv 'same' padding of this library's channel-last layout.  weight is passed PADDED to

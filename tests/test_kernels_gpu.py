@@ -213,3 +213,40 @@ def test_embed_pad_matches_embedding_cat_pad_and_its_gradient(dt):
     torch.nn.functional.embedding(ids, wr, padding_idx=0).backward(dy[:, halo:halo + L, :D].float())
     tol = 1e-4 if dt == torch.float32 else 2e-2
     assert (w.grad.float() - wr.grad).abs().max() <= tol * wr.grad.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_embedding_store_batches_equal_reference_collate_padding(dt):
+    """dl_gather_pad through EmbeddingStore vs oracle/collate.py (pinned to the reference's tail_pad / repeat_pad): pure
+    copies, so bit-exact; ragged lengths incl. 1, maxsize, > maxsize, repeated keys; at the real shapes as well."""
+    import numpy as np
+    from druglamp_amd.embedding_store import EmbeddingStore
+    from oracle import collate
+    lens = [1, 5, 7, 16, 24, 25, 47, 48, 49, 60]
+    xs = collate.ragged_inputs("store.small", lens, 8)
+    st = EmbeddingStore(8, dtype=dt)
+    for i, a in enumerate(xs):
+        st.add("k%d" % i, a)
+    keys = ["k3", "k0", "k9", "k3", "k7", "k8", "k1", "k2", "k4", "k5", "k6"]
+    sel = [xs[int(k[1:])].astype(np.float32) for k in keys]
+    if dt == torch.bfloat16:
+        sel = [torch.from_numpy(a).to(dt).float().numpy() for a in sel]
+    rep = st.batch(keys, 48, repeat=True).float().cpu().numpy()
+    assert np.array_equal(rep, collate.repeat_pad(sel, 48))
+    ok = [i for i, a in enumerate(sel) if a.shape[0] <= 48]
+    tail = st.batch([keys[i] for i in ok], 48, repeat=False).float().cpu().numpy()
+    assert np.array_equal(tail, collate.tail_pad([sel[i] for i in ok], 48))
+    # real shapes: 2304 x 640 protein rows (repeat), 512 x 384 drug rows (tail)
+    g = torch.Generator().manual_seed(0)
+    ps = EmbeddingStore(640, dtype=dt)
+    plen = [300, 1022, 2304, 77]
+    pe = [torch.randn(n, 640, generator=g) for n in plen]
+    for i, e in enumerate(pe):
+        ps.add(i, e)
+    out = ps.batch([2, 0, 3, 1, 0], 2304, repeat=True)
+    for row, k in zip(out, [2, 0, 3, 1, 0]):
+        e = pe[k].to(dt).cuda()
+        n = plen[k]
+        reps = 2304 // n
+        assert torch.equal(row[:reps * n], e.repeat(reps, 1)) and not row[reps * n:].any()

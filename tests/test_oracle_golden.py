@@ -166,3 +166,18 @@ def test_ssl_cm():
             enumerate(zip(g["meta_pid"], g["meta_did"]))]
     cm = O.cm_forward(sd, "cm_model", **out["cm"], meta=meta, margin=0.5)
     assert abs(float(cm) - float(g["cm_loss"])) <= 2e-5 * max(abs(float(g["cm_loss"])), 1e-3)
+
+
+def test_collate_padding_restatement_matches_reference_functions():
+    """oracle/collate.py vs the outputs of the reference's own tail_pad / repeat_pad (tests/golden/collate_pad.npz,
+    generated by tests/golden/make_collate_golden.py): bit-exact, incl. a sequence longer than maxsize (all zeros)."""
+    import os
+    import numpy as np
+    from oracle import collate
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collate_pad.npz"))
+    ms, feat = int(g["maxsize"]), int(g["feat"])
+    tail_in = collate.ragged_inputs("collate.tail", [int(n) for n in g["tail_lens"]], feat)
+    rep_in = collate.ragged_inputs("collate.rep", [int(n) for n in g["rep_lens"]], feat)
+    assert np.array_equal(collate.tail_pad(tail_in, ms), g["tail_out"])
+    assert np.array_equal(collate.repeat_pad(rep_in, ms), g["rep_out"])
+    assert not g["rep_out"][list(g["rep_lens"]).index(60)].any()
