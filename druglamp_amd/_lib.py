@@ -119,6 +119,7 @@ SIGNATURES = {
     "dl_prof_enable": (c_i32, [c_i32, c_i32]),
     "dl_prof_collect": (c_i32, [c_i32, C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),
+    "dl_prof_totals": (c_i32, [c_i32, C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -10,7 +10,9 @@ thread_local char g_err[512] = "";
 
 struct ProfRec { hipEvent_t a, b; double flops, bytes; };
 struct ProfFamily {
-  bool on = false;
+  int period = 0;                 // 0 = off; N >= 1: HIP events around every N-th launch of the family
+  int64_t seen = 0;               // launches since dl_prof_enable (timed or not), with their algorithmic work
+  double all_flops = 0, all_bytes = 0;
   std::vector<ProfRec> recs;
   hipEvent_t pending = nullptr;
 };
@@ -30,18 +32,23 @@ extern "C" const char* dl_last_error(void) { return g_err; }
 extern "C" int dl_version(void) { return 100; }
 
 void dl_prof_before(int family, hipStream_t s) {
-  if (family < 0 || family >= NFAM || !g_prof[family].on) return;
+  if (family < 0 || family >= NFAM || !g_prof[family].period) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfFamily& f = g_prof[family];
+  if (f.seen % f.period != 0) return;
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return;
   (void)hipEventRecord(e, s);
-  g_prof[family].pending = e;
+  f.pending = e;
 }
 
 void dl_prof_after(int family, hipStream_t s, double flops, double bytes) {
-  if (family < 0 || family >= NFAM || !g_prof[family].on) return;
+  if (family < 0 || family >= NFAM || !g_prof[family].period) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfFamily& f = g_prof[family];
+  ++f.seen;
+  f.all_flops += flops;
+  f.all_bytes += bytes;
   if (!f.pending) return;
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return;
@@ -57,7 +64,19 @@ extern "C" int dl_prof_enable(int32_t family, int32_t on) {
   for (auto& r : f.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   f.recs.clear();
   if (f.pending) { (void)hipEventDestroy(f.pending); f.pending = nullptr; }
-  f.on = on != 0;
+  f.period = on > 0 ? on : 0;
+  f.seen = 0;
+  f.all_flops = f.all_bytes = 0;
+  return DL_OK;
+}
+
+extern "C" int dl_prof_totals(int32_t family, int64_t* launches, double* total_flops, double* total_bytes) {
+  DL_CHECK_ARG(family >= 0 && family < NFAM, DL_ERR_ARG, "dl_prof_totals: bad family %d", family);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfFamily& f = g_prof[family];
+  if (launches) *launches = f.seen;
+  if (total_flops) *total_flops = f.all_flops;
+  if (total_bytes) *total_bytes = f.all_bytes;
   return DL_OK;
 }
 

@@ -13,14 +13,18 @@ What is new (MI355X-native):
   * parameters live in ONE flat fp32 arena; gradients are packed into a flat buffer by a single
     multi-tensor copy; each optimiser step is a handful of fused dl_adamw_step launches over
     contiguous runs instead of ~250 per-tensor updates;
-  * gradient all-reduce = one RCCL all-reduce per run on the flat buffer (sum; the 1/world factor is
-    folded into the AdamW kernel's grad_scale), instead of Lightning's DDP wrapper.  Unlike the
-    reference's DDP (which only reduces the cls backward that ran under the wrapper), EVERY loss's
-    gradients are reduced, so replicas never drift.
+  * gradient all-reduce = RCCL all-reduce (sum; the 1/world factor is folded into the AdamW kernel's
+    grad_scale) on 8 MB buckets of the flat buffer, started from inside backward as soon as a bucket's
+    gradients exist (GradOverlap), instead of Lightning's DDP wrapper.  Unlike the reference's DDP
+    (which only reduces the cls backward that ran under the wrapper), the gradients the optimisers
+    consume are reduced whichever loss produced them, so replicas never drift;
+  * a backward pass whose gradients the next zero_grad wipes before any optimiser steps (cls on SSL / CM
+    steps, ssl on CM steps) is not run: the parameters after the step are the same, the step is shorter.
 """
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -95,6 +99,89 @@ class FlatParams:
         return [(s, e, first) for s, e, first, _ in out]
 
 
+class GradOverlap:
+    """Gradient all-reduce overlapped with the backward pass that produces the gradients (world > 1).
+
+    The flat gradient buffer is cut into buckets of consecutive parameters, last parameter first (the
+    order backward roughly finishes them in).  A post-accumulate hook on every parameter counts its
+    bucket down; the hook that completes a bucket packs that bucket's gradients into the flat buffer
+    (one multi-tensor copy) and starts an asynchronous all-reduce (sum) on each contiguous run.  Which
+    parameters a backward pass gives gradients to is learnt from the first pass of each `kind`
+    ("cls" / "ssl" / "cm": that pass runs un-overlapped); parameters outside the learnt set, and
+    buckets that stay incomplete, are reduced by `finish()` after backward.  Every rank runs the same
+    graph, so every rank issues the same collectives in the same order."""
+
+    def __init__(self, flat: FlatParams, bucket_bytes: int = 8 << 20):
+        self.flat = flat
+        self.bucket_elems = max(bucket_bytes // 4, 1)
+        self.expected: Dict[str, frozenset] = {}
+        self.armed: Optional[str] = None
+        self.bucket_of: Dict[int, int] = {}
+        self.buckets: List[List[int]] = []
+        self.pending: List[int] = []
+        self.works: list = []
+        self.reduced: set = set()
+        self.index = {id(p): i for i, p in enumerate(flat.params)}
+        self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in flat.params if p.requires_grad]
+
+    def _plan(self, kind: str):
+        exp = sorted(self.expected[kind], reverse=True)
+        self.buckets, self.bucket_of, cur, n = [], {}, [], 0
+        for i in exp:
+            cur.append(i)
+            n += self.flat.params[i].numel()
+            if n >= self.bucket_elems:
+                self.buckets.append(sorted(cur))
+                cur, n = [], 0
+        if cur:
+            self.buckets.append(sorted(cur))
+        for b, idx in enumerate(self.buckets):
+            for i in idx:
+                self.bucket_of[i] = b
+
+    def arm(self, kind: str):
+        """Call right before the backward pass whose gradients the optimisers will consume."""
+        self.works, self.reduced, self.armed = [], set(), kind
+        if kind in self.expected:
+            self._plan(kind)
+            self.pending = [len(b) for b in self.buckets]
+        else:
+            self.buckets, self.bucket_of, self.pending = [], {}, []
+
+    def _hook(self, p):
+        if self.armed is None:
+            return
+        b = self.bucket_of.get(self.index[id(p)])
+        if b is None:
+            return
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(self.buckets[b])
+
+    def _launch(self, idx: List[int], async_op: bool = True):
+        fl = self.flat
+        torch._foreach_copy_([fl.grad_views[i] for i in idx], [fl.params[i].grad for i in idx])
+        for s, e, _ in fl.runs(idx, lambda i: 0):
+            w = dist.all_reduce(fl.grads[s:e], op=dist.ReduceOp.SUM, async_op=async_op)
+            if async_op:
+                self.works.append(w)
+        self.reduced.update(idx)
+
+    def finish(self) -> List[int]:
+        """After backward: reduce what the hooks did not, wait for everything; returns the indices with a gradient."""
+        kind, self.armed = self.armed, None
+        have = [i for i, p in enumerate(self.flat.params) if p.grad is not None]
+        rest = [i for i in have if i not in self.reduced]
+        if rest:
+            self._launch(rest)
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if kind is not None and self.expected.get(kind) != frozenset(have):
+            self.expected[kind] = frozenset(have)
+        return have
+
+
 class FusedAdamW:
     """torch.optim.AdamW semantics (lr, betas (0.9, 0.999), eps 1e-8, weight_decay 1e-2) on a FlatParams."""
 
@@ -115,6 +202,7 @@ class FusedAdamW:
 
 class Trainer:
     """ExpModule restated (trainer.py:39-292).  `cfg` is the merged config tree."""
+    overlap = None
 
     def __init__(self, model, cfg, device=None, compute_dtype=torch.float32):
         self.model = model
@@ -146,13 +234,25 @@ class Trainer:
         if self.opt_cm:
             self.opt_cm.lr = self.schd_cm.lr
         self.cm_weight = 1.0
+        # the reference wipes the cls (and ssl) gradients with the next zero_grad before any optimiser steps
+        # (header); a backward pass whose gradients nobody consumes is skipped unless asked for
+        self.run_dead_backward = os.environ.get("DL_DEAD_BACKWARD", "0") == "1"
+        ov = os.environ.get("DL_GRAD_OVERLAP", "1")            # "0": reduce after backward; "force": also at world 1
+        grouped = dist.is_available() and dist.is_initialized()
+        self.overlap = GradOverlap(self.flat) if (self.world > 1 and ov != "0") or (ov == "force" and grouped) else None
 
     # -- helpers ------------------------------------------------------------------------------------
     def _zero_grad(self):
         for p in self.flat.params:
             p.grad = None
 
+    def _arm(self, last: str, kind: str):
+        if self.overlap is not None and last == kind:
+            self.overlap.arm(kind)
+
     def _reduce_and_pack(self) -> List[int]:
+        if self.overlap is not None:
+            return self.overlap.finish()
         idx = self.flat.pack_grads()
         if self.world > 1 and idx:
             for s, e, _ in self.flat.runs(idx, lambda i: 0):
@@ -179,7 +279,10 @@ class Trainer:
         _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p)
         self._zero_grad()
         _, cls_loss = binary_cross_entropy(score, labels) if self.n_class == 1 else cross_entropy_logits(score, labels)
-        cls_loss.backward(retain_graph=compute_ssl or compute_cm)
+        last = "cm" if compute_cm else "ssl" if compute_ssl else "cls"     # the backward the optimisers consume
+        if last == "cls" or self.run_dead_backward:
+            self._arm(last, "cls")
+            cls_loss.backward(retain_graph=compute_ssl or compute_cm)
         out = {"cls": cls_loss.detach()}
         if compute_ssl:
             self._zero_grad()
@@ -189,7 +292,9 @@ class Trainer:
             with m._glue():                 # bf16 compute dtype: the heads' torch layers run under bf16 autocast
                 d = m.ssl_model(**kw)
             ssl_loss = (d["prot_ssl"] + d["drug_ssl"]) * 0.1
-            ssl_loss.backward(retain_graph=compute_cm)
+            if last == "ssl" or self.run_dead_backward:
+                self._arm(last, "ssl")
+                ssl_loss.backward(retain_graph=compute_cm)
             out["ssl"] = ssl_loss.detach()
         if compute_cm:
             self._zero_grad()
@@ -203,6 +308,7 @@ class Trainer:
                     while c * self.cm_weight * 10 < l:
                         self.cm_weight *= 10
             cm_loss = cm_loss * self.cm_weight
+            self._arm(last, "cm")
             cm_loss.backward()
             out["cm"] = cm_loss.detach()
         idx = self._reduce_and_pack()

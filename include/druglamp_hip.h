@@ -311,14 +311,20 @@ int dl_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
 
 /* ------------------------------------------------------------------------------------------
  * Kernel timing hooks used by bench.py for the roofline object: when enabled for a kernel
- * family, each launch is bracketed by hipEventRecord on its own stream.
+ * family, launches are bracketed by hipEventRecord on their own stream.
  * family: 0 gemm, 1 attn_fwd, 2 attn_bwd, 3 layernorm.
- * dl_prof_collect synchronises the recorded events and returns launches / total ms / total
- * algorithmic flops / total algorithmic bytes since dl_prof_enable.
+ * dl_prof_enable(family, on): on = 0 off; on = N >= 1 times every N-th launch of the family (an
+ * event pair costs ~6 us of stream time on gfx950: N = 1 times everything, a larger N keeps the
+ * measurement from slowing the step it measures).
+ * dl_prof_collect synchronises the recorded events and returns, over the TIMED launches,
+ * launches / total ms / total algorithmic flops / total algorithmic bytes since dl_prof_enable.
+ * dl_prof_totals returns the count and algorithmic work of ALL launches of the family since
+ * dl_prof_enable, timed or not.
  * ------------------------------------------------------------------------------------------ */
 int dl_prof_enable(int32_t family, int32_t on);
 int dl_prof_collect(int32_t family, int64_t* launches, double* total_ms, double* total_flops,
                     double* total_bytes);
+int dl_prof_totals(int32_t family, int64_t* launches, double* total_flops, double* total_bytes);
 
 #ifdef __cplusplus
 }

@@ -82,3 +82,55 @@ def test_all_gather_rows_autograd_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from druglamp_amd.trainer import FlatParams, GradOverlap
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(),
+                              torch.nn.Linear(32, 3))
+    unused = torch.nn.Parameter(torch.randn(7))                       # never reaches the loss
+    params = list(net.parameters())[:3] + [unused] + list(net.parameters())[3:]
+    flat = FlatParams(params)
+    ov = GradOverlap(flat, bucket_bytes=1024)                           # several buckets on this toy
+    ok, launched_early = True, []
+    for step in range(3):
+        g = torch.Generator().manual_seed(10 * step + rank)
+        x = torch.randn(5, 6, generator=g)
+        for p in params:
+            p.grad = None
+        loss = net(x).square().sum()
+        ov.arm("cls")
+        loss.backward()
+        launched_early.append(len(ov.reduced))
+        idx = ov.finish()
+        ok &= idx == [0, 1, 2, 4, 5, 6]
+        # what both ranks' gradients sum to, recomputed locally from both ranks' inputs
+        want = [torch.zeros_like(p) for p in params]
+        for r in range(world):
+            xr = torch.randn(5, 6, generator=torch.Generator().manual_seed(10 * step + r))
+            gs = torch.autograd.grad(net(xr).square().sum(), [params[i] for i in idx])
+            for i, gi in zip(idx, gs):
+                want[i] += gi
+        for i in idx:
+            ok &= bool(torch.allclose(flat.grad_views[i], want[i], rtol=1e-5, atol=1e-6))
+        ok &= float(flat.grad_views[3].abs().sum()) == 0.0
+    ok &= launched_early[0] == 0 and launched_early[1] > 0 and launched_early[2] > 0   # pass 1 learns, later ones overlap
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_overlapped_gradient_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
