@@ -568,9 +568,42 @@ bool big_eligible(const dl_gemm_args* a, const GemmP& p, int sp) {
   const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
   return tiles >= 192;
 }
+int big_cfg() {
+  static int cfg = -1;
+  if (cfg < 0) { const char* e = getenv("DL_GEMM_BIGCFG"); cfg = e ? atoi(e) : 0; }
+  return cfg;
+}
 void launch_big(const GemmP& p, hipStream_t s) {
   const uint32_t ntiles = (uint32_t)p.mt * p.nt;
+  const int cfg = big_cfg();
+  // tile studies (DL_GEMM_BIGCFG): 1 = 256x128 tiles, 64-byte rows, 3 stages, two 4-wave workgroups per CU;
+  // 2 = 256x256 tiles, 64-byte rows, 4 stages
+  if (cfg == 1) {
+    const uint32_t nblocks = ntiles < 512u ? ntiles : 512u;
+#define DL_BIG(E) hipLaunchKernelGGL((gemm_big_kernel<8, 2, 2, 64, 3, E>), dim3(nblocks), dim3(256), 0, s, p)
+    switch (pick_epi(p, false)) {
+      case 0: DL_BIG(0); break;
+      case 2: DL_BIG(2); break;
+      case 3: DL_BIG(3); break;
+      case 4: DL_BIG(4); break;
+      default: DL_BIG(5); break;
+    }
+#undef DL_BIG
+    return;
+  }
   const uint32_t nblocks = ntiles < 256u ? ntiles : 256u;       // one 128 KB workgroup per CU
+  if (cfg == 2) {
+#define DL_BIG(E) hipLaunchKernelGGL((gemm_big_kernel<8, 2, 4, 64, 4, E>), dim3(nblocks), dim3(512), 0, s, p)
+    switch (pick_epi(p, false)) {
+      case 0: DL_BIG(0); break;
+      case 2: DL_BIG(2); break;
+      case 3: DL_BIG(3); break;
+      case 4: DL_BIG(4); break;
+      default: DL_BIG(5); break;
+    }
+#undef DL_BIG
+    return;
+  }
 #define DL_BIG(E) hipLaunchKernelGGL((gemm_big_kernel<8, 2, 4, 128, 2, E>), dim3(nblocks), dim3(512), 0, s, p)
   switch (pick_epi(p, false)) {
     case 0: DL_BIG(0); break;
@@ -763,7 +796,7 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
     p.k_per_split = (int)(((ksteps + sp - 1) / sp) * 64);
     launch_big_tt(p, s, tt_bm);
   } else if (big_eligible(a, p, sp)) {
-    p.mt = (int)((a->M + 255) / 256); p.nt = (int)((a->N + 255) / 256);
+    p.mt = (int)((a->M + 255) / 256); p.nt = (int)((a->N + (big_cfg() == 1 ? 127 : 255)) / (big_cfg() == 1 ? 128 : 256));
     launch_big(p, s);
   } else if (a->in_dtype == DL_BF16) {
     if (slab_path) rc = dispatch_layout<bf16_t, float, true>(a, p, s, tw);

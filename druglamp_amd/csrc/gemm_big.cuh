@@ -54,6 +54,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+// One LDS-DMA instruction (64 lanes x 16 bytes -> 1 KB of LDS at lds_off + 16 * lane) as inline assembly.  Through
+// __builtin_amdgcn_global_load_lds the compiler books a FLAT access that may touch LDS: while one is pending in its
+// model (always, here: the asm waits above are invisible to it) it drains EVERY fragment read with lgkmcnt(0), the
+// read issued one instruction earlier included, and the prefetch distance of the fragment pipeline collapses.
+// Invisible DMA leaves it counting (lgkmcnt(2) with two younger reads in flight); ordering against the reads of
+// the buffer is by wait_vmcnt + wg_barrier, as before.
+__device__ __forceinline__ void dma16(const char* gsrc, uint32_t lds_off) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_off) : "memory");   // M0 is reserved: it cannot be listed as a clobber; nothing else in these kernels lives in it
+}
 // wave-level ordering point for cross-lane traffic through LDS (no instruction: the LDS queue is in order)
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -110,23 +119,22 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_kernel(const GemmP
       ws[i] = p.W + ((int64_t)gr * p.ldw) * 2 + kc * 16;
     }
   };
-  auto issue = [&](int kt, uint32_t buf) {
-    char* xb = smem + buf * STAGE;
+  // LDS byte address of the stage ring (M0 takes addresses, not pointers)
+  const uint32_t smem_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+  // one of the PER DMA instructions of a step (piece q: X pieces first)
+  auto issue_piece = [&](int kt, uint32_t buf, int q) {
+    const uint32_t sb = smem_lds + buf * STAGE;
     const int64_t kb = (int64_t)kt * ROWB;
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-      const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((wave * 64 + i * NT) * 16));
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs[i] + kb),
-                                       (__attribute__((address_space(3))) void*)(xb + off), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-      const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)(XB + (wave * 64 + i * NT) * 16));
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws[i] + kb),
-                                       (__attribute__((address_space(3))) void*)(xb + off), 16, 0, 0);
+    if (q < XCH) {
+      dma16(xs[q] + kb, __builtin_amdgcn_readfirstlane(sb + (uint32_t)((wave * 64 + q * NT) * 16)));
+    } else {
+      dma16(ws[q - XCH] + kb, __builtin_amdgcn_readfirstlane(sb + (uint32_t)(XB + (wave * 64 + (q - XCH) * NT) * 16)));
     }
   };
-
+  auto issue = [&](int kt, uint32_t buf) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) issue_piece(kt, buf, q);
+  };
   const int nk = p.K / BKE;            // whole steps (checked by the host)
   uint32_t it = blockIdx.x;
   if (it >= ntiles) return;
@@ -145,7 +153,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_kernel(const GemmP
 #pragma unroll
       for (int j = 0; j < WF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // One k-step.  FEED: the next step's PER DMA instructions go out one per item between the MFMA groups
+    // (issued back to back after the barrier they cost every wave ~100-185 cycles apiece with the matrix
+    // pipe idle: ~1200 cycles against the step's 1024 MFMA cycles per wave).
+    auto kstep = [&](auto feed, int kt) {
+      constexpr bool FEED = decltype(feed)::value;
       // step kt has landed once at most `later` younger steps' DMA instructions are outstanding
       const int later = (kt == 0) ? 0 : min(D - 1, nk - 1 - kt);
       if (later <= 0) wait_vmcnt<0>();
@@ -153,13 +165,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_kernel(const GemmP
       else wait_vmcnt<(D >= 3 ? 2 * PER : PER)>();
       wg_barrier();
       // every wave is past step kt-1: its buffer takes step kt+D
-      if (kt + D < nk) issue(kt + D, (gs + D) % NSTAGE);
+      constexpr int U = NKF * XF;
+      constexpr bool SPREAD = FEED && PER <= U;
+      if (FEED && !SPREAD) issue(kt + D, (gs + D) % NSTAGE);
       const char* cur = smem + (gs % NSTAGE) * STAGE;
       // Software-pipelined fragment stream: item u = (kf, i) needs X fragment fx[u] and the four W fragments of
       // its kf.  X fragments are read two items ahead, the next kf's W fragments during the last four items of kf 0,
       // and sched_group_barrier pins "reads of this item, then its 4 MFMAs" so that LDS latency hides under
       // the matrix pipe instead of in front of it.
-      constexpr int U = NKF * XF;
       auto rd_fx = [&](int u) { return lds_read16(cur, xoff + (u % XF) * 16 * ROWB + ((((u / XF) * 4 + g) ^ swz) << 4)); };
       auto rd_fw = [&](int kf, int j) { return lds_read16(cur, woff + j * 16 * ROWB + (((kf * 4 + g) ^ swz) << 4)); };
       u32x4 fx[U], fw[NKF][WF];
@@ -173,13 +186,21 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_kernel(const GemmP
         int nread = 0;
         if (u + 2 < U) { fx[u + 2] = rd_fx(u + 2); ++nread; }
         if (NKF == 2 && u >= XF - WF && u < XF) { fw[1][u - (XF - WF)] = rd_fw(1, u - (XF - WF)); ++nread; }
+        if (SPREAD && u < PER) issue_piece(kt + D, (gs + D) % NSTAGE, u);
 #pragma unroll
         for (int j = 0; j < WF; ++j) acc[u % XF][j] = Mma<T>::mma(fw[u / XF][j], fx[u], acc[u % XF][j]);
         if (nread == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         else if (nread == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (SPREAD && u < PER) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, WF, 0);
       }
       ++gs;
+    };
+    if (p.dbg & 2) {                   // timing study: no operand feed after the prologue (results are garbage)
+      for (int kt = 0; kt < nk; ++kt) kstep(std::false_type{}, kt);
+    } else {
+      for (int kt = 0; kt + D < nk; ++kt) kstep(std::true_type{}, kt);
+      for (int kt = max(nk - D, 0); kt < nk; ++kt) kstep(std::false_type{}, kt);
     }
 
     // ---- tile end: request the next tile's first stages, then the epilogue --------------------

@@ -417,6 +417,7 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
         ctx.save_for_backward(q2, k2, w, qp, kv, o, lse, ow)
         ctx.cfg = (Lq, Lk, B, E, H, scale, in_b is not None, out_b is not None)
         ctx.mark_non_differentiable(*([raw] if raw is not None else []))
+        ctx.set_materialize_grads(False)       # no zero-filled gradients for the non-differentiable outputs
         return y.view(B, Lq, E).transpose(0, 1), raw
 
     @staticmethod
@@ -700,6 +701,7 @@ class ProteinCNNFn(torch.autograd.Function):
         else:
             out = cur.reshape(B, LP, C)[:, _CNN_HALO:_CNN_HALO + Lv]
         ctx.mark_non_differentiable(*stats_out)
+        ctx.set_materialize_grads(False)       # no zero-filled gradients for the non-differentiable outputs
         return (out,) + tuple(stats_out)
 
     @staticmethod
@@ -731,8 +733,8 @@ class ProteinCNNFn(torch.autograd.Function):
             dWg, dbias = _wgrad(dpre[pl:pl + Mg], xin, C, k * C, Mg, C, C)
             grads[i * 6 + 0] = dWg.reshape(C, k, C).permute(0, 2, 1).contiguous()
             grads[i * 6 + 1] = dbias
-            grads[i * 6 + 2] = sums[C:].clone()
-            grads[i * 6 + 3] = sums[:C].clone()
+            grads[i * 6 + 2] = sums[C:]
+            grads[i * 6 + 3] = sums[:C]
             if i > 0 or ctx.needs_input_grad[0]:
                 Wd = _conv_weight(w, cdt, True)
                 dprev = torch.empty((R, C), dtype=cdt, device=dout.device)
@@ -776,11 +778,19 @@ class DenseFn(torch.autograd.Function):
         w = _padded_weight(weight, Np, Kp, cdt)
         b = None
         if bias is not None:
-            b = torch.zeros(Np, dtype=torch.float32, device=x.device)
-            b[:N] = bias.detach()
+            if N == Np and bias.dtype == torch.float32:
+                b = bias.detach()
+            else:
+                b = torch.zeros(Np, dtype=torch.float32, device=x.device)
+                b[:N] = bias.detach()
         r2 = None if residual is None else residual.reshape(M, Np).contiguous()
-        pre = torch.empty((M, Np), dtype=cdt, device=x.device) if act else None
-        y = ops.gemm(x2, w, M=M, N=Np, K=Kp, bias=b, act=1 if act else 0, pre_out=pre, residual=r2)
+        relu = act == "relu"
+        pre = torch.empty((M, Np), dtype=cdt, device=x.device) if (act and not relu) else None
+        y = ops.gemm(x2, w, M=M, N=Np, K=Kp, bias=b, act=2 if relu else (1 if act else 0), pre_out=pre, residual=r2)
+        if relu:
+            if residual is not None:
+                raise NotImplementedError("dense: relu with a residual (the mask could not be read off the output)")
+            pre = y                                    # relu'(pre) = [y > 0]
         ctx.save_for_backward(x2, w, pre)
         ctx.cfg = (x.shape, M, N, K, Np, Kp, bias is not None, residual is not None, act)
         return y.reshape(*x.shape[:-1], Np)
@@ -791,7 +801,9 @@ class DenseFn(torch.autograd.Function):
         xshape, M, N, K, Np, Kp, has_bias, has_res, act = ctx.cfg
         g = dy.reshape(M, Np).contiguous()
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
-        if act:
+        if act == "relu":
+            g = torch.ops.aten.threshold_backward(g, pre, 0)
+        elif act:
             g = ops.gelu_bwd(g, pre)
         dx = ops.gemm(g, w, M=M, N=Kp, K=Np, w_kslow=True, ldw=Kp).reshape(xshape) if ctx.needs_input_grad[0] else None
         dw = None
@@ -806,7 +818,50 @@ class DenseFn(torch.autograd.Function):
 
 
 def dense(x, weight, bias=None, residual=None, act=False):
+    """act: False, True (erf GELU, pre-activation saved) or "relu" (fused in the GEMM epilogue)."""
     return DenseFn.apply(x, weight, bias, residual, act)
+
+
+class TokenMeanFn(torch.autograd.Function):
+    """x (B, L, C) -> fp32 (B, C) mean over the tokens (DrugLAMP.py:73 `f.mean(dim=1)`).  Backward hands the
+    consumer a stride-0 expansion of g / L in x's dtype instead of materialising an fp32 (B, L, C) quotient."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.cfg = (x.shape, x.dtype)
+        return x.mean(dim=1, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (B, L, C), dt = ctx.cfg
+        return (g * (1.0 / L)).to(dt).unsqueeze(1).expand(B, L, C)
+
+
+class GraphAggregateFn(torch.autograd.Function):
+    """agg[b] = [ahat[b] @ feat[b, :Nr] ; feat[b, Nr:]] — the normalised neighbourhood sum of a batch of dense graphs
+    whose nodes >= Nr are virtual padding nodes with only a self loop (basic_model._GraphConvDense).  One Function
+    so that backward is one clone + one batched product instead of autograd's slice / cat / accumulate chain
+    (two zero fills, two slice copies and an add per layer)."""
+
+    @staticmethod
+    def forward(ctx, ahat, feat):
+        Nr = ahat.shape[-1]
+        ctx.save_for_backward(ahat)
+        if Nr == feat.shape[1]:
+            return torch.bmm(ahat, feat)
+        out = feat.clone()
+        out[:, :Nr] = torch.bmm(ahat, feat[:, :Nr])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ahat,) = ctx.saved_tensors
+        Nr = ahat.shape[-1]
+        if Nr == dout.shape[1]:
+            return None, torch.bmm(ahat.transpose(1, 2), dout)
+        dfeat = dout.clone()
+        dfeat[:, :Nr] = torch.bmm(ahat.transpose(1, 2), dout[:, :Nr])
+        return None, dfeat
 
 
 class EmbeddingFn(torch.autograd.Function):
@@ -896,6 +951,7 @@ class BatchNormRowsFn(torch.autograd.Function):
         ctx.save_for_backward(x, mean, rstd, g)
         ctx.training = training
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)       # no zero-filled gradients for the non-differentiable outputs
         return y, mean, var
 
     @staticmethod
@@ -907,7 +963,7 @@ class BatchNormRowsFn(torch.autograd.Function):
         dy = dy.contiguous()
         sums = ops.bn_bwd_reduce(dy, x, mean, rstd, 0, 0, 0)
         dx = ops.bn_bwd_apply(dy, x, mean, rstd, g, sums, 1.0 / R, False, 0, 0, 0)
-        return dx, sums[C:].clone(), sums[:C].clone(), None, None, None, None, None
+        return dx, sums[C:], sums[:C], None, None, None, None, None
 
 
 def batch_norm_rows(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor) -> torch.Tensor:

@@ -33,7 +33,7 @@ class DrugLAMP(DrugLAMPBase):
         mx, self.A_x_gca = self._gca_branch(self.x_gca, self.x_mhla, self.x_gca_norm, xpc, xdc)
         f, self.attn, self.guide_attn = self.pmma(mx, mv)
         with self._glue():
-            score = self.mlp_classifier(f.mean(dim=1))
+            score = self.mlp_classifier(Fn.TokenMeanFn.apply(f))
         score = score.float()
         if mode == "train":
             return vd, vpf, ssl, cp, score

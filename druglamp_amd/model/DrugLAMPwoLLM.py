@@ -17,7 +17,7 @@ class DrugLAMPwoLLM(DrugLAMPBase):
         mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, Fn.cast(vd, self.compute_dtype))
         f, self.attn, self.guide_attn = self.pmma(mv, mv)
         with self._glue():
-            score = self.mlp_classifier(f.mean(dim=1))
+            score = self.mlp_classifier(Fn.TokenMeanFn.apply(f))
         score = score.float()
         if mode == "train":
             return vd, vpf, ssl, None, score

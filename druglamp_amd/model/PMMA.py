@@ -129,6 +129,7 @@ class PairedMultimodelAttention(nn.Module):
         self.encoder = Encoder(config, vis)
         self.vis = vis
         self.compute_dtype = torch.float32
+        self.keep_compute_dtype = False
 
     def forward(self, prot, mol=None):
         if mol is None:
@@ -155,16 +156,24 @@ class PairedMultimodelAttention(nn.Module):
                 x = Fn.transformer_block(x, True, H, p, tr, 1e-6, blk.stream_params(0) + blk.stream_params(1))
             else:
                 if i == 2:
-                    x = torch.cat((x[0], x[1]), dim=-1).unsqueeze(0)   # [1, B, L, 2d]
+                    x = _concat_streams(x)                             # [1, B, L, 2d]
                 if self.vis:
                     w, _ = Fn.attention_maps(x, blk, H, paired=False)
                     attn_maps.append(w)
                     guided_maps.append(None)
                 x = Fn.transformer_block(x, False, H, p, tr, 1e-6, blk.stream_params(0))
         if x.shape[0] == 2:                                       # fewer than 3 layers configured
-            x = torch.cat((x[0], x[1]), dim=-1).unsqueeze(0)
-        encoded = Fn.layer_norm(x[0], enc.encoder_norm.weight, enc.encoder_norm.bias, 1e-6)
-        return Fn.cast(encoded, torch.float32), attn_maps, guided_maps
+            x = _concat_streams(x)
+        encoded = Fn.layer_norm(x.reshape(x.shape[1:]), enc.encoder_norm.weight, enc.encoder_norm.bias, 1e-6)
+        # fp32 out like the reference; the DrugLAMP models, which only pool `encoded`, ask for the compute dtype
+        return (encoded if self.keep_compute_dtype else Fn.cast(encoded, torch.float32)), attn_maps, guided_maps
+
+
+def _concat_streams(x):
+    """[2, B, L, d] -> [1, B, L, 2d] = cat((x[0], x[1]), -1) (encoder.py:50) as ONE strided copy, whose backward is
+    one strided copy as well (indexing x[0] / x[1] costs two zero fills, two slice copies and an add in backward)."""
+    S, B, L, d = x.shape
+    return x.permute(1, 2, 0, 3).reshape(1, B, L, S * d)
 
 
 class MultiHeadLinearAttention(nn.Module):

@@ -61,11 +61,8 @@ class _GraphConvDense(nn.Module):
         """ahat: normalised adjacency (B, Nr, Nr) with Nr <= N nodes.  Nodes >= Nr are virtual padding nodes whose
         only edge is their self loop (degree 1): for them the normalised aggregation is the identity, so only
         the real-atom block goes through the batched product."""
-        Nr = ahat.shape[-1]
-        agg = torch.bmm(ahat, feat[:, :Nr])
-        if Nr < feat.shape[1]:
-            agg = torch.cat((agg, feat[:, Nr:]), dim=1)
-        return F.relu(Fn.dense(agg, self.weight.t(), self.bias))            # feature transform on the HIP GEMM path
+        agg = Fn.GraphAggregateFn.apply(ahat, feat)
+        return Fn.dense(agg, self.weight.t(), self.bias, act="relu")        # feature transform + ReLU on the HIP GEMM path
 
 
 class _GCNLayerDense(nn.Module):
@@ -76,7 +73,7 @@ class _GCNLayerDense(nn.Module):
         self.bn_layer = nn.BatchNorm1d(out_feats)
 
     def forward(self, ahat, feats):
-        new = self.graph_conv(ahat, feats) + F.relu(Fn.dense(feats, self.res_connection.weight, self.res_connection.bias))
+        new = self.graph_conv(ahat, feats) + Fn.dense(feats, self.res_connection.weight, self.res_connection.bias, act="relu")
         B, N, C = new.shape
         return Fn.batch_norm_rows(self.bn_layer, new.reshape(B * N, C)).reshape(B, N, C)
 
@@ -244,6 +241,7 @@ class DrugLAMPBase(nn.Module):
         self.x_gca_norm = nn.LayerNorm(n_hidden * 2)
 
         self.pmma = PairedMultimodelAttention(config=model_cfg, vis=False)
+        self.pmma.keep_compute_dtype = True            # only pooled here (Fn.TokenMeanFn): no fp32 copy of (B, L, 512)
         self.mlp_classifier = MLP(dec["IN_DIM"] * 2, dec["HIDDEN_DIM"] * 2, dec["OUT_DIM"] * 2, binary=dec["BINARY"])
         self.A_v_gca = None
         self.A_x_gca = None

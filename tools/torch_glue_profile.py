@@ -15,7 +15,8 @@ batch, meta = make_batch(256, dev, seed=100, with_graph=True, llm_dtype=torch.bf
 for _ in range(3):
     trainer.training_step(batch, meta=meta, cur_epoch=1)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     trainer.training_step(batch, meta=meta, cur_epoch=1)
     torch.cuda.synchronize()
 agg = defaultdict(lambda: [0.0, 0])
@@ -29,6 +30,10 @@ for ev in prof.events():
         if "druglamp_amd" in fr and "ops.py" not in fr:
             site = fr.split("druglamp_amd/")[-1]
             break
+    if site == "?" and ev.stack:
+        site = "|".join(f.split("/")[-1] for f in ev.stack[:2])
+    if site == "?":
+        site = "thread %s seq %s" % (ev.thread, getattr(ev, "sequence_nr", "-"))
     key = (ev.name, str(ev.input_shapes)[:70], site[:70])
     agg[key][0] += ev.device_time_total
     agg[key][1] += 1
