@@ -88,7 +88,7 @@ SIGNATURES = {
                                 c_i32, c_vp]),
     "dl_layernorm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "dl_layernorm_bwd_workspace_bytes": (c_sz, [c_i64, c_i64]),
-    "dl_layernorm_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
+    "dl_layernorm_bwd": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                                  c_i32, c_i64, c_i64, c_i32, c_vp, c_sz, c_vp]),
     "dl_attn_fwd": (c_i32, [C.POINTER(AttnFwdArgs), c_vp]),
     "dl_attn_bwd": (c_i32, [C.POINTER(AttnBwdArgs), c_vp]),

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, in
 
 // partial layout: [nblocks][2][D]  (0: dgamma, 1: dbeta)
 template <typename T, int NV_>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int64_t lddy,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int64_t lddy, int64_t dy_share,
                                                      const T* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd,
@@ -101,6 +101,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
     const int64_t rowA = r0 + rr, rowB = r0 + rr + 4;
     if (rowA >= M) break;
     const bool hasB = rowB < M;
+    // dy_share consecutive rows of x take the same dy row (the gradient of a mean over tokens, never materialised)
+    const int64_t dyA = dy_share == 1 ? rowA : rowA / dy_share, dyB = dy_share == 1 ? rowB : rowB / dy_share;
     f32x4 xa[NV_], da[NV_], xb[NV_], db_[NV_], ra[NV_], rb[NV_];
 #pragma unroll
     for (int j = 0; j < NV_; ++j) {
@@ -108,11 +110,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
       ra[j] = f32x4{0.f, 0.f, 0.f, 0.f}; rb[j] = ra[j];
       if (c < nv) {
         xa[j] = load4<T>(x + rowA * ldx + c * 4);
-        da[j] = load4<T>(dy + rowA * lddy + c * 4);
+        da[j] = load4<T>(dy + dyA * lddy + c * 4);
         if (dres) ra[j] = load4<T>(dres + rowA * lddres + c * 4);
         if (hasB) {
           xb[j] = load4<T>(x + rowB * ldx + c * 4);
-          db_[j] = load4<T>(dy + rowB * lddy + c * 4);
+          db_[j] = load4<T>(dy + dyB * lddy + c * 4);
           if (dres) rb[j] = load4<T>(dres + rowB * lddres + c * 4);
         }
       }
@@ -203,20 +205,21 @@ extern "C" size_t dl_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
   return (size_t)nb * 2 * (size_t)D * sizeof(float);
 }
 
-extern "C" int dl_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx,
+extern "C" int dl_layernorm_bwd(const void* dy, int64_t lddy, int64_t dy_share, const void* x, int64_t ldx,
                                 const float* mean, const float* rstd, const float* gamma,
                                 const void* dres, int64_t lddres, void* dx, int64_t lddx, float* dgamma,
                                 float* dbeta, int32_t accumulate, int64_t M, int64_t D, int32_t dtype,
                                 void* workspace, size_t workspace_bytes, dl_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   DL_CHECK_ARG(dy && x && mean && rstd && gamma && dx, DL_ERR_ARG, "dl_layernorm_bwd: null pointer");
+  DL_CHECK_ARG(dy_share >= 1, DL_ERR_ARG, "dl_layernorm_bwd: dy_share=%ld must be >= 1", (long)dy_share);
   DL_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, DL_ERR_SHAPE,
                "dl_layernorm_bwd: D=%ld must be a multiple of 4 and <= %d", (long)D, 256 * LN_MAXV);
   DL_CHECK_ARG(workspace && workspace_bytes >= dl_layernorm_bwd_workspace_bytes(M, D),
                DL_ERR_WORKSPACE, "dl_layernorm_bwd: workspace too small");
   const int nb = (int)((M + LN_BWD_ROWS - 1) / LN_BWD_ROWS);
   const size_t smem = 4 * 2 * (size_t)D * sizeof(float);
-#define LN_BWD(TT, NVV) hipLaunchKernelGGL((ln_bwd_kernel<TT, NVV>), dim3(nb), dim3(256), smem, s, (const TT*)dy, lddy, \
+#define LN_BWD(TT, NVV) hipLaunchKernelGGL((ln_bwd_kernel<TT, NVV>), dim3(nb), dim3(256), smem, s, (const TT*)dy, lddy, dy_share, \
                                           (const TT*)x, ldx, mean, rstd, gamma, (const TT*)dres, lddres, (TT*)dx, lddx, \
                                           (float*)workspace, M, (int)D)
   const int nvg = (int)((D + 255) / 256);

@@ -376,7 +376,11 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, mean, rstd, w = ctx.saved_tensors
-        dx, dg, db = ops.layernorm_bwd(dy.reshape(x2.shape).contiguous(), x2, mean, rstd, w)
+        if dy.dim() == 3 and dy.stride(1) == 0 and dy.stride(2) == 1 and dy.shape[1] > 1:
+            # an expanded per-sample gradient (TokenMeanFn): every token row of a sample reads the same dy row
+            dx, dg, db = ops.layernorm_bwd(dy[:, 0], x2, mean, rstd, w, dy_share=dy.shape[1])
+        else:
+            dx, dg, db = ops.layernorm_bwd(dy.reshape(x2.shape).contiguous(), x2, mean, rstd, w)
         return dx.reshape(ctx.shape), dg, db, None
 
 

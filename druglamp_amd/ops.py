@@ -127,16 +127,19 @@ def layernorm_fwd(x2d, gamma, beta, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dres=None, need_param_grads=True, out=None):
+def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dres=None, need_param_grads=True, out=None, dy_share=1):
+    """dy_share > 1: dy2d has M / dy_share rows, each shared by dy_share consecutive rows of x2d."""
     L = _lib.lib()
     M, D = x2d.shape
+    if dy2d.shape[0] * dy_share != M:
+        raise ValueError("layernorm_bwd: dy has %d rows, x %d, dy_share %d" % (dy2d.shape[0], M, dy_share))
     dx = torch.empty_like(x2d) if out is None else out
     dgamma = dbeta = None
     if need_param_grads:
         gb = torch.empty((2, D), dtype=torch.float32, device=x2d.device)   # adjacent: one final-reduction launch
         dgamma, dbeta = gb[0], gb[1]
     ws = _ws.get(L.dl_layernorm_bwd_workspace_bytes(M, D), x2d.device)
-    check(L.dl_layernorm_bwd(dy2d.data_ptr(), dy2d.stride(0), x2d.data_ptr(), x2d.stride(0), mean.data_ptr(),
+    check(L.dl_layernorm_bwd(dy2d.data_ptr(), dy2d.stride(0), int(dy_share), x2d.data_ptr(), x2d.stride(0), mean.data_ptr(),
                              rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), 0 if dres is None else dres.stride(0),
                              dx.data_ptr(), dx.stride(0), _ptr(dgamma), _ptr(dbeta), 0, M, D, _dt(x2d),
                              ws.data_ptr(), ws.numel(), _stream()), "dl_layernorm_bwd")

@@ -127,13 +127,15 @@ int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean, const floa
  * LayerNorm over the last dim (eps 1e-6 inside PMMA: model/PMMA/block.py:23-27,
  * model/PMMA/encoder.py:31; eps 1e-5 for v/x_gca_norm: model/basic_model.py:115,118).
  * fwd: y = (x - mean) * rstd * gamma + beta ; mean/rstd [M] f32 saved for bwd (may be NULL).
- * bwd: dx = LN'(dy) (+ dres if given); dgamma/dbeta [D] f32 (+)= column reductions.
+ * bwd: dx = LN'(dy) (+ dres if given); dgamma/dbeta [D] f32 (+)= column reductions.  dy_share >= 1:
+ *      row r of x takes row r / dy_share of dy (1 = one dy row per x row; L = the gradient of a mean over
+ *      L tokens, `f.mean(dim=1)` at model/DrugLAMP.py:73, read in place instead of expanded to M rows).
  * ------------------------------------------------------------------------------------------ */
 int dl_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y,
                      int64_t ldy, float* mean, float* rstd, int64_t M, int64_t D, float eps,
                      int32_t dtype, dl_stream s);
 size_t dl_layernorm_bwd_workspace_bytes(int64_t M, int64_t D);
-int dl_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean,
+int dl_layernorm_bwd(const void* dy, int64_t lddy, int64_t dy_share, const void* x, int64_t ldx, const float* mean,
                      const float* rstd, const float* gamma, const void* dres, int64_t lddres,
                      void* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
                      int64_t M, int64_t D, int32_t dtype, void* workspace, size_t workspace_bytes,

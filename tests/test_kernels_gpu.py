@@ -250,3 +250,22 @@ def test_embedding_store_batches_equal_reference_collate_padding(dt):
         n = plen[k]
         reps = 2304 // n
         assert torch.equal(row[:reps * n], e.repeat(reps, 1)) and not row[reps * n:].any()
+
+
+def test_layernorm_bwd_shared_dy_rows_equal_expanded_dy():
+    """dy_share = L (gradient of a token mean read in place) against the same gradient expanded to every row."""
+    from druglamp_amd import ops
+    B, L, D = 5, 12, 512
+    g = torch.Generator().manual_seed(3)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(B * L, D, generator=g).cuda().to(dt)
+        w = torch.randn(D, generator=g).cuda()
+        b = torch.randn(D, generator=g).cuda()
+        dyb = torch.randn(B, D, generator=g).cuda().to(dt)
+        _, mean, rstd = ops.layernorm_fwd(x, w, b, 1e-6)
+        full = dyb.unsqueeze(1).expand(B, L, D).reshape(B * L, D).contiguous()
+        dx0, dg0, db0 = ops.layernorm_bwd(full, x, mean, rstd, w)
+        dx1, dg1, db1 = ops.layernorm_bwd(dyb, x, mean, rstd, w, dy_share=L)
+        assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    with pytest.raises(ValueError):
+        ops.layernorm_bwd(dyb, x, mean, rstd, w, dy_share=L + 1)
