@@ -35,7 +35,9 @@ void dl_prof_before(int family, hipStream_t s) {
   if (family < 0 || family >= NFAM || !g_prof[family].period) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfFamily& f = g_prof[family];
-  if (f.seen % f.period != 0) return;
+  // 1 launch in `period`, chosen by a multiplicative hash of the launch index: a plain "every period-th" would keep
+  // hitting the same launch slots of the step whenever period divides the launches per step
+  if (f.period > 1 && (((uint32_t)f.seen * 2654435761u) >> 12) % (uint32_t)f.period != 0) return;
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return;
   (void)hipEventRecord(e, s);

@@ -508,14 +508,17 @@ int pick_tw(const dl_gemm_args* a) {
 int auto_split(int64_t M, int64_t N, int64_t K, int bke, int bt) {
   const int64_t tiles = ((M + bt - 1) / bt) * ((N + bt - 1) / bt);
   if (tiles >= 192) return 1;
-  int64_t want = 512 / tiles;              // floor: tiles * splits must fit ONE round of 512 resident workgroups (a
+  static int round_wgs = -1, max_sp = -1;
+  if (round_wgs < 0) { const char* e = getenv("DL_SPLIT_ROUND"); round_wgs = e ? atoi(e) : 512; }
+  if (max_sp < 0) { const char* e = getenv("DL_SPLIT_MAX"); max_sp = e ? atoi(e) : 256; }
+  int64_t want = round_wgs / tiles;        // floor: tiles * splits must fit ONE round of 512 resident workgroups (a
                                            // 516-workgroup plan ran 4 of them alone in a second round: 768x256, +25 %)
   if (want < 1) want = 1;
   int64_t ksteps = (K + bke - 1) / bke;
   int64_t maxs = ksteps / 4;  // at least 4 k-steps per split
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
-  if (want > 256) want = 256;
+  if (want > max_sp) want = max_sp;
   return (int)(want < 1 ? 1 : want);
 }
 

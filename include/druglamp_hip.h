@@ -315,7 +315,8 @@ int dl_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * Kernel timing hooks used by bench.py for the roofline object: when enabled for a kernel
  * family, launches are bracketed by hipEventRecord on their own stream.
  * family: 0 gemm, 1 attn_fwd, 2 attn_bwd, 3 layernorm.
- * dl_prof_enable(family, on): on = 0 off; on = N >= 1 times every N-th launch of the family (an
+ * dl_prof_enable(family, on): on = 0 off; on = N >= 1 times one launch in N of the family, picked by a hash
+ * of the launch index so that no launch slot of a periodic step is favoured (an
  * event pair costs ~6 us of stream time on gfx950: N = 1 times everything, a larger N keeps the
  * measurement from slowing the step it measures).
  * dl_prof_collect synchronises the recorded events and returns, over the TIMED launches,

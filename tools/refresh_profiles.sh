@@ -1,0 +1,19 @@
+#!/bin/bash
+# Regenerate the artefacts under profiles/ on the GPU box (outputs land in gpurun_out/prof/; copy what is judged
+# into profiles/ afterwards).  usage: tools/refresh_profiles.sh [tag]
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/prof; rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+python3 "$ROOT/bench.py" 2>/dev/null | tail -1 > "$OUT/bench_line.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 > "$OUT/under_rocprof.log" 2>&1
+grep '"metric"' "$OUT/under_rocprof.log" | tail -1 > "$OUT/bench_line_under_rocprof.json"
+T=$(find "$OUT/trace" -name '*kernel_trace.csv' | head -1); S=$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)
+cp "$S" "$OUT/bench_kernel_stats.csv"
+python3 "$ROOT/tools/prof_summary.py" "$T" 0.25 > "$OUT/bench_timed_window_summary.txt" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o f -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pmc_f.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pmc_w.log" 2>&1
+F=$(find "$OUT/pmc_f" -name '*counter_collection.csv' | head -1); W=$(find "$OUT/pmc_w" -name '*counter_collection.csv' | head -1)
+python3 "$ROOT/tools/pmc_summary.py" "$F" "$W" "$OUT/pmc_summary.json" > "$OUT/pmc_summary.txt" 2>&1
+python3 "$ROOT/tools/gemm_shapes.py" > "$OUT/gemm_shapes.txt" 2>&1
+rm -rf "$OUT/trace" "$OUT/pmc_f" "$OUT/pmc_w"
+ls -la "$OUT"; head -c 600 "$OUT/bench_line.json"; echo; head -12 "$OUT/bench_timed_window_summary.txt"
