@@ -595,6 +595,18 @@ void launch_big(const GemmP& p, hipStream_t s) {
     return;
   }
   const uint32_t nblocks = ntiles < 256u ? ntiles : 256u;       // one 128 KB workgroup per CU
+  if (cfg == 3) {               // 16 waves of 64x64 (four per SIMD) on the same 256x256 tile and stage ring
+#define DL_BIG(E) hipLaunchKernelGGL((gemm_big_kernel<4, 4, 4, 128, 2, E>), dim3(nblocks), dim3(1024), 0, s, p)
+    switch (pick_epi(p, false)) {
+      case 0: DL_BIG(0); break;
+      case 2: DL_BIG(2); break;
+      case 3: DL_BIG(3); break;
+      case 4: DL_BIG(4); break;
+      default: DL_BIG(5); break;
+    }
+#undef DL_BIG
+    return;
+  }
   if (cfg == 2) {
 #define DL_BIG(E) hipLaunchKernelGGL((gemm_big_kernel<8, 2, 4, 64, 4, E>), dim3(nblocks), dim3(512), 0, s, p)
     switch (pick_epi(p, false)) {

@@ -104,12 +104,15 @@ class GradOverlap:
 
     The flat gradient buffer is cut into buckets of consecutive parameters, last parameter first (the
     order backward roughly finishes them in).  A post-accumulate hook on every parameter counts its
-    bucket down; the hook that completes a bucket packs that bucket's gradients into the flat buffer
-    (one multi-tensor copy) and starts an asynchronous all-reduce (sum) on each contiguous run.  Which
-    parameters a backward pass gives gradients to is learnt from the first pass of each `kind`
-    ("cls" / "ssl" / "cm": that pass runs un-overlapped); parameters outside the learnt set, and
-    buckets that stay incomplete, are reduced by `finish()` after backward.  Every rank runs the same
-    graph, so every rank issues the same collectives in the same order."""
+    bucket down; a complete bucket is packed into the flat buffer (one multi-tensor copy) and an
+    asynchronous all-reduce (sum) is started on each of its contiguous runs.  Buckets go out in strict
+    index order (a complete bucket waits for its predecessors), and `finish()` sends the rest after
+    backward, so every rank issues the same collectives in the same order whatever the timing.
+
+    Which parameters a backward pass of a `kind` ("cls" / "ssl" / "cm") reaches is agreed on by all
+    ranks during the first pass of that kind (one small all-reduce of a presence mask, the only host
+    sync; that pass reduces after backward).  Later passes reduce exactly the agreed set: a parameter
+    of the set without a local gradient contributes zeros, a gradient outside the set is an error."""
 
     def __init__(self, flat: FlatParams, bucket_bytes: int = 8 << 20):
         self.flat = flat
@@ -119,8 +122,10 @@ class GradOverlap:
         self.bucket_of: Dict[int, int] = {}
         self.buckets: List[List[int]] = []
         self.pending: List[int] = []
+        self.ready: set = set()
+        self.next_bucket = 0
         self.works: list = []
-        self.reduced: set = set()
+        self.reduced: set = set()          # parameter indices whose all-reduce has been started
         self.index = {id(p): i for i, p in enumerate(flat.params)}
         self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in flat.params if p.requires_grad]
 
@@ -138,13 +143,13 @@ class GradOverlap:
         for b, idx in enumerate(self.buckets):
             for i in idx:
                 self.bucket_of[i] = b
+        self.pending = [len(b) for b in self.buckets]
 
     def arm(self, kind: str):
         """Call right before the backward pass whose gradients the optimisers will consume."""
-        self.works, self.reduced, self.armed = [], set(), kind
+        self.works, self.reduced, self.ready, self.next_bucket, self.armed = [], set(), set(), 0, kind
         if kind in self.expected:
             self._plan(kind)
-            self.pending = [len(b) for b in self.buckets]
         else:
             self.buckets, self.bucket_of, self.pending = [], {}, []
 
@@ -156,30 +161,52 @@ class GradOverlap:
             return
         self.pending[b] -= 1
         if self.pending[b] == 0:
-            self._launch(self.buckets[b])
+            self.ready.add(b)
+            while self.next_bucket in self.ready:
+                self._launch(self.buckets[self.next_bucket])
+                self.next_bucket += 1
 
-    def _launch(self, idx: List[int], async_op: bool = True):
+    def _launch(self, idx: List[int]):
         fl = self.flat
-        torch._foreach_copy_([fl.grad_views[i] for i in idx], [fl.params[i].grad for i in idx])
+        local = [i for i in idx if fl.params[i].grad is not None]
+        absent = [i for i in idx if fl.params[i].grad is None]
+        if local:
+            torch._foreach_copy_([fl.grad_views[i] for i in local], [fl.params[i].grad for i in local])
+        if absent:
+            torch._foreach_zero_([fl.grad_views[i] for i in absent])
         for s, e, _ in fl.runs(idx, lambda i: 0):
-            w = dist.all_reduce(fl.grads[s:e], op=dist.ReduceOp.SUM, async_op=async_op)
-            if async_op:
-                self.works.append(w)
+            self.works.append(dist.all_reduce(fl.grads[s:e], op=dist.ReduceOp.SUM, async_op=True))
         self.reduced.update(idx)
 
+    def _agree(self, have: List[int]) -> frozenset:
+        """Union over ranks of the parameters that received a gradient."""
+        mask = torch.zeros(len(self.flat.params), dtype=torch.int32)
+        mask[have] = 1
+        mask = mask.to(self.flat.grads.device)
+        dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+        return frozenset(mask.cpu().nonzero().flatten().tolist())
+
     def finish(self) -> List[int]:
-        """After backward: reduce what the hooks did not, wait for everything; returns the indices with a gradient."""
+        """After backward: send the buckets the hooks did not, wait for everything; returns the indices the
+        optimisers step (the agreed set)."""
         kind, self.armed = self.armed, None
         have = [i for i, p in enumerate(self.flat.params) if p.grad is not None]
-        rest = [i for i in have if i not in self.reduced]
-        if rest:
-            self._launch(rest)
+        if kind not in self.expected:
+            self.expected[kind] = self._agree(have)
+            self._plan(kind)
+            self.next_bucket = 0
+        else:
+            extra = set(have) - self.expected[kind]
+            if extra:
+                raise RuntimeError("GradOverlap: %d parameters outside the set agreed for '%s' backward passes received a "
+                                   "gradient (first: index %d); the graph changed between steps" % (len(extra), kind, min(extra)))
+        for b in range(self.next_bucket, len(self.buckets)):
+            self._launch(self.buckets[b])
+        self.next_bucket = len(self.buckets)
         for w in self.works:
             w.wait()
         self.works = []
-        if kind is not None and self.expected.get(kind) != frozenset(have):
-            self.expected[kind] = frozenset(have)
-        return have
+        return sorted(self.expected[kind])
 
 
 class FusedAdamW:
