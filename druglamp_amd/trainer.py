@@ -14,8 +14,8 @@ What is new (MI355X-native):
     multi-tensor copy; each optimiser step is a handful of fused dl_adamw_step launches over
     contiguous runs instead of ~250 per-tensor updates;
   * gradient all-reduce = RCCL all-reduce (sum; the 1/world factor is folded into the AdamW kernel's
-    grad_scale) on 8 MB buckets of the flat buffer, started from inside backward as soon as a bucket's
-    gradients exist (GradOverlap), instead of Lightning's DDP wrapper.  Unlike the reference's DDP
+    grad_scale) on the flat buffer after backward, or (DL_GRAD_OVERLAP=1) on 8 MB buckets started from
+    inside backward as soon as a bucket's gradients exist (GradOverlap), instead of Lightning's DDP wrapper.  Unlike the reference's DDP
     (which only reduces the cls backward that ran under the wrapper), the gradients the optimisers
     consume are reduced whichever loss produced them, so replicas never drift;
   * a backward pass whose gradients the next zero_grad wipes before any optimiser steps (cls on SSL / CM
@@ -264,9 +264,15 @@ class Trainer:
         # the reference wipes the cls (and ssl) gradients with the next zero_grad before any optimiser steps
         # (header); a backward pass whose gradients nobody consumes is skipped unless asked for
         self.run_dead_backward = os.environ.get("DL_DEAD_BACKWARD", "0") == "1"
-        ov = os.environ.get("DL_GRAD_OVERLAP", "1")            # "0": reduce after backward; "force": also at world 1
+        # "1": bucketed all-reduce from inside backward (GradOverlap); "force": also at world 1 (RCCL sanity runs);
+        # default "0": one reduction after backward.  Off by default because the large-tile GEMMs are persistent with
+        # ONE workgroup per CU (all of its registers and 128 KB of LDS): every CU an RCCL channel workgroup sits on
+        # cannot take its GEMM workgroup until the collective's kernel retires, and with the static tile lists that
+        # GEMM then runs a second round — the 56 MB all-reduce (2-3 % of the step) is not worth that until the tile
+        # lists are handed out dynamically.
+        ov = os.environ.get("DL_GRAD_OVERLAP", "0")
         grouped = dist.is_available() and dist.is_initialized()
-        self.overlap = GradOverlap(self.flat) if (self.world > 1 and ov != "0") or (ov == "force" and grouped) else None
+        self.overlap = GradOverlap(self.flat) if (self.world > 1 and ov not in ("0", "")) or (ov == "force" and grouped) else None
 
     # -- helpers ------------------------------------------------------------------------------------
     def _zero_grad(self):
