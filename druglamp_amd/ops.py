@@ -24,7 +24,15 @@ def _dt(t: torch.Tensor) -> int:
         raise TypeError("druglamp_amd: unsupported dtype %s (float32 / bfloat16 only)" % t.dtype)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """The current torch stream's hipStream_t.  torch.cuda.current_stream() builds a Stream object through three
+    Python layers (9 us, ~260 times per step); the raw getter is the same handle in well under a microsecond."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

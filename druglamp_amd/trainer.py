@@ -305,7 +305,8 @@ class Trainer:
         """batch = (feat_d, feat_p, labels, llm_d, llm_p) as the reference's collate yields them.
         cur_epoch is 1-based (trainer.py:180).  Returns python floats of the losses (one host sync)."""
         m = self.model
-        m.train()
+        if not m.training:
+            m.train()                  # (walks every submodule: 0.7 ms per call)
         compute_ssl = self.use_ssl and (cur_epoch % self.ssl_epoch_step == 0)
         compute_cm = self.use_cm and (cur_epoch >= self.cm_init_epoch)
         feat_d, feat_p, labels, llm_d, llm_p = batch
