@@ -74,6 +74,20 @@ __device__ __forceinline__ void load_tile(const char* base, int64_t ld, int row0
   }
 }
 
+// XOR swizzle of the 16-byte chunks of k-row k of a K-slow operand tile.  bf16 tiles are read by ds_read_b64_tr_b16:
+// the 32 lanes of a lane group address k-rows {8g' + q : g' = g & 1, q = 0..3} and, per k-row, the 8-byte halves of two
+// adjacent chunks (h = 0, 1).  The swizzle has to turn (q, g', h) into distinct 16-byte slots of the 256-byte bank
+// space: with the former k & (CPR - 1), q and h both landed on chunk bit 0 (SQ_LDS_BANK_CONFLICT = half of all LDS
+// cycles of the weight-gradient kernels).  16 chunks per row (pitch 256 B): q -> bits 1..2, g' -> bit 3, h stays on
+// bit 0.  8 chunks per row (pitch 128 B: the k-row parity picks the bank-space half): q >> 1 -> bit 1, g' -> bit 2.
+template <typename T, int TW>
+__device__ __forceinline__ constexpr int kslow_swz(int k) {
+  constexpr int CPR = TileGeom<T, TW>::CPR_KSLOW;
+  if constexpr (sizeof(T) == 2 && CPR == 16) return ((k & 3) << 1) | (((k >> 3) & 1) << 3);
+  else if constexpr (sizeof(T) == 2 && CPR == 8) return (((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2);
+  else return k & (CPR - 1);
+}
+
 template <typename T, bool KSLOW, int TW>
 __device__ __forceinline__ void store_tile(char* lds, const u32x4 (&r)[TW]) {
   constexpr int EPC = Mma<T>::EPC;
@@ -87,7 +101,7 @@ __device__ __forceinline__ void store_tile(char* lds, const u32x4 (&r)[TW]) {
     } else {
       constexpr int CPR = 32 * TW / EPC;
       const int krow = c / CPR, cc = c % CPR;
-      lds_write16(lds, krow * TileGeom<T, TW>::PITCH_KSLOW + ((cc ^ (krow & (CPR - 1))) << 4), r[i]);
+      lds_write16(lds, krow * TileGeom<T, TW>::PITCH_KSLOW + ((cc ^ kslow_swz<T, TW>(krow)) << 4), r[i]);
     }
   }
 }
@@ -113,7 +127,7 @@ __device__ __forceinline__ void dma_tile(const char* base, int64_t ld, int row0,
     } else {
       // K-slow operand: LDS slot (k-row, physical chunk pc) receives the k-row's logical chunk pc ^ (krow & (CPR-1))
       constexpr int CPR = TileGeom<T, TW>::CPR_KSLOW;
-      const int krow = c / CPR, cc = (c % CPR) ^ (krow & (CPR - 1));
+      const int krow = c / CPR, cc = (c % CPR) ^ kslow_swz<T, TW>(krow);
       int gr = row0 + cc * EPC;
       gr = gr < nrows ? gr : nrows - EPC;
       src = base + ((int64_t)(k0 + krow) * ld + gr) * (int64_t)sizeof(T);
@@ -134,8 +148,8 @@ __device__ __forceinline__ u32x4 read_frag(const char* lds, int rb, int kf, int 
     constexpr int P = TileGeom<T, TW>::PITCH_KSLOW, CM = TileGeom<T, TW>::CPR_KSLOW - 1;
     const int kidx = kf * 32 + g * 8 + (il >> 2);
     const int cb = (rb + (il & 3) * 4) * 2;                 // byte column; chunk = cb >> 4
-    const u32x2 a = lds_read_tr16(lds, kidx * P + ((((cb >> 4) ^ (kidx & CM))) << 4) + (cb & 15));
-    const u32x2 b = lds_read_tr16(lds, (kidx + 4) * P + ((((cb >> 4) ^ ((kidx + 4) & CM))) << 4) + (cb & 15));
+    const u32x2 a = lds_read_tr16(lds, kidx * P + (((cb >> 4) ^ kslow_swz<T, TW>(kidx)) << 4) + (cb & 15));
+    const u32x2 b = lds_read_tr16(lds, (kidx + 4) * P + (((cb >> 4) ^ kslow_swz<T, TW>(kidx + 4)) << 4) + (cb & 15));
     u32x4 r = {a[0], a[1], b[0], b[1]};
     return r;
   } else {

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN >= 8 ? NWM * NWN / 4 : 2
 // Weight-gradient form: C[m][n] = sum_k X[k][m] W[k][n], both operands K-SLOW (rows of dY and of the layer
 // input), tens of thousands of k-rows, a small output.  Same 8-wave large tile and LDS-DMA ring as above;
 // operand tiles are [64 k-rows][BM or BN columns] with the 16-byte chunks of a k-row XOR-swizzled by
-// swz(k) = (k & 3) | ((k >> 3) & 3) << 2 so that the 16 k-rows one ds_read_b64_tr_b16 touches land on 16
+// swz(k) = (k & 3) << 1 | ((k >> 3) & 1) << 3 so that the 8-byte pieces the 32 lanes of a ds_read_b64_tr_b16 lane group touch land on 32
 // different chunk columns.  The K range is cut into `splits` slabs (fp32 partial outputs, reduced by
 // splitk_reduce_kernel in a fixed order); k-rows past the end of a slab's range are fed from a zero page,
 // so K needs no alignment.
@@ -298,7 +298,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int il = lane & 15, g = lane >> 4;
   const int wm = wave / NWN, wn = wave % NWN;
-  auto swz = [](int k) { return (k & 3) | (((k >> 3) & 3) << 2); };
+  // (q = k & 3 -> chunk bits 1..2, (k >> 3) & 1 -> bit 3; bit 0 is left to the two adjacent chunks a lane pair reads:
+  //  the former (k & 3) | ((k >> 3) & 3) << 2 put q on bit 0 as well = 2-way conflicts, half of all LDS cycles)
+  auto swz = [](int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); };
 
   const uint32_t per_split = (uint32_t)p.mt * p.nt;
   const uint32_t ntiles = per_split * p.splits;

@@ -2,7 +2,7 @@
 # SQ counter passes over one GEMM shape: where the waves' cycles go.  usage: tools/gemm_pmc.sh M N K  (on the GPU box)
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out/gemm_pmc_$1_$2_$3
+OUT=$ROOT/gpurun_out/gemm_pmc_$1_$2_$3_${5:-nn}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_BF16 \
