@@ -10,7 +10,7 @@
 //                         the LDS transpose read.  alpha/l/lse scaling of O^T is lane-local.
 //   dK/dV kernel        : S[q][key] = Q K^T  (A = Q from LDS, B = K kept in registers), so that
 //                         P and dS are directly the B operands of dV^T = dO^T P and dK^T = Q^T dS.
-// LDS tiles are [rows][head_dim] with 16-byte chunks XOR-swizzled by (row & 7); the same image
+// LDS tiles are [rows][head_dim] with 16-byte chunks XOR-swizzled by ATile::swz(row); the same image
 // serves ds_read_b128 (K-contiguous fragments) and ds_read_b64_tr_b16 / ds_read_b32 (transposed
 // fragments).
 #include <stdlib.h>
@@ -45,7 +45,7 @@ __device__ __forceinline__ void dma_rows(char* lds, const T* base, int64_t row_s
   const char* zero = reinterpret_cast<const char*>(attn_zero_page);
   for (int c0 = 0; c0 < nchunks; c0 += NT) {
     const int c = c0 + tid;
-    const int row = c / TL::CPR, ch = (c % TL::CPR) ^ (row & 7);
+    const int row = c / TL::CPR, ch = (c % TL::CPR) ^ TL::swz(row);
     const char* src = (c < nchunks && row < valid_rows) ? reinterpret_cast<const char*>(base + (int64_t)row * row_stride + ch * TL::EPC) : zero;
     const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((c0 + wave * 64) * 16));
     if (c0 + wave * 64 < nchunks)
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_res_kernel(const AttnP p)
     const char* zero = reinterpret_cast<const char*>(attn_zero_page);
     for (int c0 = 0; c0 < nchunks; c0 += NT) {
       const int c = c0 + tid;
-      const int row = c / TL::CPR, ch = (c % TL::CPR) ^ (row & 7);
+      const int row = c / TL::CPR, ch = (c % TL::CPR) ^ TL::swz(row);
       const bool ok = c < nchunks && row < p.Lk;
       const char* ksrc = ok ? reinterpret_cast<const char*>(Kb + (int64_t)row * p.k_rs + ch * TL::EPC) : zero;
       const char* vsrc = ok ? reinterpret_cast<const char*>(Vb + (int64_t)row * p.v_rs + ch * TL::EPC) : zero;

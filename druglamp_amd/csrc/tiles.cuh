@@ -1,5 +1,5 @@
 // tiles.cuh — LDS tile image + MFMA fragment loaders shared by the attention and NT-Xent kernels.
-// Tiles are [rows][HD] with 16-byte chunks XOR-swizzled by (row & 7); the same image serves
+// Tiles are [rows][HD] with 16-byte chunks XOR-swizzled by ATile::swz(row); the same image serves
 // ds_read_b128 (K-contiguous fragments) and ds_read_b64_tr_b16 / ds_read_b32 (transposed fragments).
 #pragma once
 #include <math.h>
@@ -15,9 +15,19 @@ template <typename T, int HD> struct ATile {
   static constexpr int RB = HD * ES;       // bytes per row
   static constexpr int CPR = RB / 16;      // 16-byte chunks per row
   static constexpr int EPC = 16 / ES;
+  // XOR swizzle of a row's 16-byte chunks.  128-byte rows (bf16, head_dim 64): row & 7 — the row parity supplies
+  // the fourth bank-space bit.  256-byte rows (bf16, head_dim 128) fill the 256-byte bank space on their own: the
+  // 16 lanes of a ds_read_b128 group (rows il, chunk pair g) and the 32 lanes of a ds_read_b64_tr_b16 group (rows
+  // 4g + q, adjacent chunks h) need FOUR swizzle bits, and row & 7 left both 2-way conflicted (SQ_LDS_BANK_CONFLICT
+  // = 42-46 % of the LDS cycles of the head_dim-128 kernels): row bits 0..1 -> chunk bits 1..2, row bit 2 -> bit 3,
+  // chunk bit 0 stays with g / h.
+  __device__ static __forceinline__ int swz(int row) {
+    if constexpr (ES == 2 && CPR == 16) return ((row & 3) << 1) | (((row >> 2) & 1) << 3);
+    else return row & 7;
+  }
   __device__ static __forceinline__ int off(int row, int col) {
     const int b = col * ES;
-    return row * RB + ((((b >> 4) ^ (row & 7))) << 4) + (b & 15);
+    return row * RB + ((((b >> 4) ^ swz(row))) << 4) + (b & 15);
   }
 };
 
@@ -43,7 +53,7 @@ template <typename T, int HD, int NR> struct Stager {
     for (int i = 0; i < NCH; ++i) {
       const int c = threadIdx.x + i * ATT_THREADS;
       const int row = c / TL::CPR, ch = c % TL::CPR;
-      if (c < NR * TL::CPR) lds_write16(lds, row * TL::RB + ((ch ^ (row & 7)) << 4), r[i]);
+      if (c < NR * TL::CPR) lds_write16(lds, row * TL::RB + ((ch ^ TL::swz(row)) << 4), r[i]);
     }
   }
 };
@@ -53,7 +63,7 @@ template <typename T, int HD>
 __device__ __forceinline__ u32x4 frag_kc(const char* lds, int rowbase, int kf, int il, int g) {
   using TL = ATile<T, HD>;
   const int row = rowbase + il;
-  return lds_read16(lds, row * TL::RB + (((kf * 4 + g) ^ (row & 7)) << 4));
+  return lds_read16(lds, row * TL::RB + (((kf * 4 + g) ^ TL::swz(row)) << 4));
 }
 // K-contiguous fragment straight from global memory (kept in registers for a whole kernel)
 template <typename T>
