@@ -331,7 +331,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void cnn_sitepool_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dz, int L, int C,
                                                                 int halo, int S) {
   extern __shared__ __attribute__((aligned(16))) char sp_smem[];
-  float* g = reinterpret_cast<float*>(sp_smem);              // [C][RR]
+  // [C][RR]; row q is rotated by 2 * (q >> 3): the 16 channel chunks a wave reads at once have q = (72 ch + const)
+  // mod C, i.e. q >> 3 takes 16 distinct values, and without the rotation all of them sat on the same bank
+  // (SQ_LDS_BANK_CONFLICT = 93 % of this kernel's LDS cycles)
+  static_assert(SP_RR == 32, "rotation below assumes 32 site rows per workgroup");
+  float* g = reinterpret_cast<float*>(sp_smem);
   const int n_site = L / S;
   const int b = blockIdx.y, r0 = blockIdx.x * SP_RR, tid = threadIdx.x;
   const int LP = L + 2 * halo;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256) void cnn_sitepool_bwd_kernel(const T* __restri
   const T* db = dout + (int64_t)b * n_site * C;
   for (int e = tid; e < C * SP_RR; e += 256) {
     const int q = e / SP_RR, i = e % SP_RR;
-    g[e] = (r0 + i < n_site) ? to_f32(db[(int64_t)n_site * q + r0 + i]) * inv : 0.f;
+    g[q * SP_RR + ((i + 2 * (q >> 3)) & 31)] = (r0 + i < n_site) ? to_f32(db[(int64_t)n_site * q + r0 + i]) * inv : 0.f;
   }
   __syncthreads();
   T* zb = dz + (int64_t)b * LP * C;
@@ -350,7 +354,10 @@ __global__ __launch_bounds__(256) void cnn_sitepool_bwd_kernel(const T* __restri
     const int l = n_site * k + r0 + i;
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = g[(((ch * 8 + e) * S + k) % C) * SP_RR + i];
+    for (int e = 0; e < 8; ++e) {
+      const int q = ((ch * 8 + e) * S + k) % C;
+      v[e] = g[q * SP_RR + ((i + 2 * (q >> 3)) & 31)];
+    }
     T* dst = zb + (int64_t)(halo + l) * C + ch * 8;
     store4<T>(dst, f32x4{v[0], v[1], v[2], v[3]});
     store4<T>(dst + 4, f32x4{v[4], v[5], v[6], v[7]});
