@@ -327,6 +327,20 @@ __global__ __launch_bounds__(256) void cnn_sitepool_fwd_kernel(const T* __restri
   }
 }
 
+// Two (or S) equally shaped row streams [S][R][row] <-> one [R][S * row] buffer (encoder.py:50, `cat((prot, mol), -1)`
+// before the self-attention layers, and its gradient): 16-byte chunks, both sides contiguous per (row, stream) segment.
+__global__ __launch_bounds__(256) void interleave_streams_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst,
+                                                                  int64_t R, int cpr, int S, int inverse, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int j = (int)(idx % cpr);
+    const int64_t rs = idx / cpr;
+    const int s = (int)(rs % S);
+    const int64_t r = rs / S;
+    const int64_t split = ((int64_t)s * R + r) * cpr + j;       // position in the [S][R][row] layout
+    if (inverse) dst[split] = src[idx]; else dst[idx] = src[split];
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cnn_sitepool_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dz, int L, int C,
                                                                 int halo, int S) {
@@ -649,6 +663,22 @@ extern "C" int dl_cast(const void* src, int32_t sdt, void* dst, int32_t ddt, int
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
   else { dl_set_error("dl_cast: bad dtypes"); return DL_ERR_ARG; }
   DL_CHECK_LAUNCH("dl_cast");
+  return DL_OK;
+}
+
+extern "C" int dl_interleave_streams(const void* src, void* dst, int64_t R, int64_t row_bytes, int32_t S, int32_t inverse,
+                                     dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(src && dst && R > 0 && S > 0 && row_bytes > 0, DL_ERR_ARG, "dl_interleave_streams: bad args");
+  DL_CHECK_ARG(row_bytes % 16 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, DL_ERR_ALIGN,
+               "dl_interleave_streams: rows must be whole 16-byte chunks and 16-byte aligned");
+  const int cpr = (int)(row_bytes / 16);
+  const int64_t total = R * S * cpr;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(interleave_streams_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, R, cpr,
+                     (int)S, (int)inverse, total);
+  DL_CHECK_LAUNCH("dl_interleave_streams");
   return DL_OK;
 }
 

@@ -443,6 +443,23 @@ def embed_pad(ids: torch.Tensor, weight: torch.Tensor, fill: torch.Tensor, halo:
     return out
 
 
+def interleave_streams(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+    """x [S, ..., d] -> [..., S * d] (cat of the streams along the last dim); inverse: x [..., S * d] with S = 2 -> [2, ..., d]."""
+    _need_gpu(x)
+    x = x.contiguous()
+    if not inverse:
+        S, d = x.shape[0], x.shape[-1]
+        R = x[0].numel() // d
+        out = torch.empty(x.shape[1:-1] + (S * d,), dtype=x.dtype, device=x.device)
+    else:
+        S, d = 2, x.shape[-1] // 2
+        R = x.numel() // (S * d)
+        out = torch.empty((S,) + x.shape[:-1] + (d,), dtype=x.dtype, device=x.device)
+    check(_lib.lib().dl_interleave_streams(x.data_ptr(), out.data_ptr(), R, d * x.element_size(), S, int(inverse), _stream()),
+          "dl_interleave_streams")
+    return out
+
+
 def gather_pad(store: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tensor, S: int, repeat: bool) -> torch.Tensor:
     """store (rows, F), offsets (B,) int64, lengths (B,) int32 -> (B, S, F); see dl_gather_pad."""
     _need_gpu(store, offsets, lengths)

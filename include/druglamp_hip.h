@@ -205,6 +205,14 @@ int dl_token_gate_bwd(const void* dout, const void* v, const float* gate, void* 
                       int32_t dtype, dl_stream s);
 
 /* ------------------------------------------------------------------------------------------
+ * Stream concatenation of the PMMA encoder (model/PMMA/encoder.py:50: `cat((prot, mol), -1)` before
+ * the self-attention layers) and its gradient.  src [S][R][row_bytes] -> dst [R][S * row_bytes];
+ * inverse = 1 goes the other way (src [R][S * row_bytes] -> dst [S][R][row_bytes]).
+ * ------------------------------------------------------------------------------------------ */
+int dl_interleave_streams(const void* src, void* dst, int64_t R, int64_t row_bytes, int32_t S, int32_t inverse,
+                          dl_stream s);
+
+/* ------------------------------------------------------------------------------------------
  * Elementwise helpers on the path.
  * ------------------------------------------------------------------------------------------ */
 /* y = dropout(x + pe[row % L]) — Embeddings.forward prot branch (model/PMMA/embed.py:51-52). */

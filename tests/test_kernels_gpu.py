@@ -269,3 +269,13 @@ def test_layernorm_bwd_shared_dy_rows_equal_expanded_dy():
         assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
     with pytest.raises(ValueError):
         ops.layernorm_bwd(dyb, x, mean, rstd, w, dy_share=L + 1)
+
+
+def test_interleave_streams_equals_cat_and_inverts():
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(2, 3, 7, 64, generator=g).cuda().to(dt)
+        y = ops.interleave_streams(x)
+        assert torch.equal(y, torch.cat((x[0], x[1]), dim=-1))
+        assert torch.equal(ops.interleave_streams(y, inverse=True), x)
