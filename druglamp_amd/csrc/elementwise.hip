@@ -341,6 +341,18 @@ __global__ __launch_bounds__(256) void interleave_streams_kernel(const u32x4* __
   }
 }
 
+// dst[r] = [a[r] | b[r]] for two row-major buffers of ca / cb 16-byte chunks per row (inverse: split dst back into a, b)
+__global__ __launch_bounds__(256) void concat2_kernel(u32x4* __restrict__ a, u32x4* __restrict__ b, u32x4* __restrict__ dst,
+                                                       int ca, int cb, int inverse, int64_t total) {
+  const int cw = ca + cb;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int j = (int)(idx % cw);
+    const int64_t r = idx / cw;
+    u32x4* side = j < ca ? a + r * ca + j : b + r * cb + (j - ca);
+    if (inverse) *side = dst[idx]; else dst[idx] = *side;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cnn_sitepool_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dz, int L, int C,
                                                                 int halo, int S) {
@@ -679,6 +691,22 @@ extern "C" int dl_interleave_streams(const void* src, void* dst, int64_t R, int6
   hipLaunchKernelGGL(interleave_streams_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, R, cpr,
                      (int)S, (int)inverse, total);
   DL_CHECK_LAUNCH("dl_interleave_streams");
+  return DL_OK;
+}
+
+extern "C" int dl_concat2(void* a, void* b, void* cat, int64_t R, int64_t a_row_bytes, int64_t b_row_bytes, int32_t inverse,
+                          dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(a && b && cat && R > 0 && a_row_bytes > 0 && b_row_bytes > 0, DL_ERR_ARG, "dl_concat2: bad args");
+  DL_CHECK_ARG(a_row_bytes % 16 == 0 && b_row_bytes % 16 == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)cat) & 15) == 0,
+               DL_ERR_ALIGN, "dl_concat2: rows must be whole 16-byte chunks and 16-byte aligned");
+  const int ca = (int)(a_row_bytes / 16), cb = (int)(b_row_bytes / 16);
+  const int64_t total = R * (ca + cb);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(concat2_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, (u32x4*)a, (u32x4*)b, (u32x4*)cat, ca, cb,
+                     (int)inverse, total);
+  DL_CHECK_LAUNCH("dl_concat2");
   return DL_OK;
 }
 

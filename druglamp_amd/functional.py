@@ -826,6 +826,19 @@ def dense(x, weight, bias=None, residual=None, act=False):
     return DenseFn.apply(x, weight, bias, residual, act)
 
 
+class Concat2Fn(torch.autograd.Function):
+    """cat((a, b), -1) and its gradient as one dl_concat2 launch each."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.wa = a.shape[-1]
+        return ops.concat2(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.split2(g, ctx.wa)
+
+
 class TokenMeanFn(torch.autograd.Function):
     """x (B, L, C) -> fp32 (B, C) mean over the tokens (DrugLAMP.py:73 `f.mean(dim=1)`).  Backward hands the
     consumer a stride-0 expansion of g / L in x's dtype instead of materialising an fp32 (B, L, C) quotient."""

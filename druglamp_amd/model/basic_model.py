@@ -289,7 +289,12 @@ class DrugLAMPBase(nn.Module):
         """PGCA -> concat -> MHLA + residual -> LayerNorm (DrugLAMP.py:55-71).  Returns (m, raw logits)."""
         m, raw = gca(prot_sites.permute(1, 0, 2), drug_nodes.permute(1, 0, 2), drug_nodes.permute(1, 0, 2),
                      need_weights=self.keep_raw_attention, need_raw=True)
-        m = torch.cat((prot_sites, m.permute(1, 0, 2)), 2)
+        g = m.permute(1, 0, 2)
+        if prot_sites.is_cuda and prot_sites.dtype == g.dtype and (prot_sites.shape[-1] * g.element_size()) % 16 == 0 \
+                and (g.shape[-1] * g.element_size()) % 16 == 0:
+            m = Fn.Concat2Fn.apply(prot_sites, g)
+        else:
+            m = torch.cat((prot_sites, g), 2)
         m = mhla(m, add_residual=True)                                  # mhla(h) + h in one launch set
         # inputs arrive in the compute dtype and stay in it (the LayerNorm kernel keeps fp32 statistics either way):
         # no fp32 round trips between PGCA, MHLA, LayerNorm and PMMA

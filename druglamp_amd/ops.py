@@ -460,6 +460,30 @@ def interleave_streams(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
     return out
 
 
+def concat2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """cat((a, b), -1) for two tensors with equal leading shape."""
+    _need_gpu(a, b)
+    a, b = a.contiguous(), b.contiguous()
+    R = a.numel() // a.shape[-1]
+    out = torch.empty(a.shape[:-1] + (a.shape[-1] + b.shape[-1],), dtype=a.dtype, device=a.device)
+    check(_lib.lib().dl_concat2(a.data_ptr(), b.data_ptr(), out.data_ptr(), R, a.shape[-1] * a.element_size(),
+                                b.shape[-1] * b.element_size(), 0, _stream()), "dl_concat2")
+    return out
+
+
+def split2(cat: torch.Tensor, wa: int):
+    """inverse of concat2: (cat[..., :wa], cat[..., wa:]) as two contiguous tensors."""
+    _need_gpu(cat)
+    cat = cat.contiguous()
+    wb = cat.shape[-1] - wa
+    R = cat.numel() // cat.shape[-1]
+    a = torch.empty(cat.shape[:-1] + (wa,), dtype=cat.dtype, device=cat.device)
+    b = torch.empty(cat.shape[:-1] + (wb,), dtype=cat.dtype, device=cat.device)
+    check(_lib.lib().dl_concat2(a.data_ptr(), b.data_ptr(), cat.data_ptr(), R, wa * cat.element_size(), wb * cat.element_size(),
+                                1, _stream()), "dl_concat2")
+    return a, b
+
+
 def gather_pad(store: torch.Tensor, offsets: torch.Tensor, lengths: torch.Tensor, S: int, repeat: bool) -> torch.Tensor:
     """store (rows, F), offsets (B,) int64, lengths (B,) int32 -> (B, S, F); see dl_gather_pad."""
     _need_gpu(store, offsets, lengths)

@@ -279,3 +279,15 @@ def test_interleave_streams_equals_cat_and_inverts():
         y = ops.interleave_streams(x)
         assert torch.equal(y, torch.cat((x[0], x[1]), dim=-1))
         assert torch.equal(ops.interleave_streams(y, inverse=True), x)
+
+
+def test_concat2_equals_cat_and_splits_back():
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(6)
+    for dt in (torch.float32, torch.bfloat16):
+        a = torch.randn(3, 5, 128, generator=g).cuda().to(dt)
+        b = torch.randn(3, 5, 64, generator=g).cuda().to(dt)
+        y = ops.concat2(a, b)
+        assert torch.equal(y, torch.cat((a, b), dim=-1))
+        a2, b2 = ops.split2(y, 128)
+        assert torch.equal(a2, a) and torch.equal(b2, b)
