@@ -341,6 +341,32 @@ __global__ __launch_bounds__(256) void interleave_streams_kernel(const u32x4* __
   }
 }
 
+// ahat[b][i][j] = din[i] * adj[b][j][i] * dout[j], dout[j] = clamp(sum_i adj[b][j][i], 1)^-1/2 (out-degree of source j),
+// din[i] = clamp(sum_j adj[b][j][i], 1)^-1/2 (in-degree of destination i): dgl GraphConv norm='both' on a dense batched
+// graph (basic_model.py:591-617 via dgl 1.0.2 GraphConv), one workgroup per sample, the fp32 adjacency tile in LDS.
+template <typename TO>
+__global__ __launch_bounds__(256) void norm_adj_kernel(const float* __restrict__ adj, TO* __restrict__ ahat, int n) {
+  extern __shared__ __attribute__((aligned(16))) char na_smem[];
+  float* a = reinterpret_cast<float*>(na_smem);               // [n][n + 1]
+  float* dout = a + (size_t)n * (n + 1);                      // [n]
+  float* din = dout + n;                                      // [n]
+  const int b = blockIdx.x, tid = threadIdx.x, P = n + 1;
+  const float* src = adj + (int64_t)b * n * n;
+  for (int e = tid; e < n * n; e += 256) a[(e / n) * P + e % n] = src[e];
+  __syncthreads();
+  for (int r = tid; r < 2 * n; r += 256) {
+    float sum = 0.f;
+    if (r < n) { for (int i = 0; i < n; ++i) sum += a[r * P + i]; dout[r] = rsqrtf(fmaxf(sum, 1.f)); }
+    else { const int c = r - n; for (int j = 0; j < n; ++j) sum += a[j * P + c]; din[c] = rsqrtf(fmaxf(sum, 1.f)); }
+  }
+  __syncthreads();
+  TO* dst = ahat + (int64_t)b * n * n;
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e / n, j = e % n;
+    dst[e] = from_f32<TO>(a[j * P + i] * din[i] * dout[j]);
+  }
+}
+
 // dst[r] = [a[r] | b[r]] for two row-major buffers of ca / cb 16-byte chunks per row (inverse: split dst back into a, b)
 __global__ __launch_bounds__(256) void concat2_kernel(u32x4* __restrict__ a, u32x4* __restrict__ b, u32x4* __restrict__ dst,
                                                        int ca, int cb, int inverse, int64_t total) {
@@ -691,6 +717,23 @@ extern "C" int dl_interleave_streams(const void* src, void* dst, int64_t R, int6
   hipLaunchKernelGGL(interleave_streams_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4*)src, (u32x4*)dst, R, cpr,
                      (int)S, (int)inverse, total);
   DL_CHECK_LAUNCH("dl_interleave_streams");
+  return DL_OK;
+}
+
+extern "C" int dl_norm_adjacency(const float* adj, void* ahat, int64_t B, int32_t n, int32_t out_dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(adj && ahat && B > 0 && n > 0, DL_ERR_ARG, "dl_norm_adjacency: bad args");
+  const size_t lds = ((size_t)n * (n + 1) + 2 * (size_t)n) * sizeof(float);
+  DL_CHECK_ARG(lds <= 150 * 1024, DL_ERR_SHAPE, "dl_norm_adjacency: n=%d does not fit the LDS tile (n <= 190)", n);
+  if (out_dtype == DL_BF16) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)norm_adj_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((norm_adj_kernel<bf16_t>), dim3((uint32_t)B), dim3(256), lds, s, adj, (bf16_t*)ahat, (int)n);
+  } else if (out_dtype == DL_F32) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)norm_adj_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((norm_adj_kernel<float>), dim3((uint32_t)B), dim3(256), lds, s, adj, (float*)ahat, (int)n);
+  }
+  else { dl_set_error("dl_norm_adjacency: bad out_dtype"); return DL_ERR_ARG; }
+  DL_CHECK_LAUNCH("dl_norm_adjacency");
   return DL_OK;
 }
 

@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as Fn
+from .. import ops
 from ..configs import get_model_defaults
 from .cross_modality import CrossModality
 from .PGCA import GuidedCrossAttention
@@ -51,6 +52,8 @@ class _GraphConvDense(nn.Module):
     def normalised_adjacency(adj, dtype):
         """ahat[b][i][j] = din[i] * adj[b][j][i] * dout[j] (D^-1/2 A^T D^-1/2 with clamped degrees) — computed ONCE per
         batch and shared by every layer (the adjacency carries no gradient)."""
+        if adj.is_cuda and adj.dtype == torch.float32 and adj.shape[-1] <= 190 and dtype in (torch.float32, torch.bfloat16):
+            return ops.norm_adjacency(adj, dtype)                       # one launch instead of eight
         with torch.no_grad():
             a = adj.float()
             dout = a.sum(dim=-1).clamp(min=1).pow(-0.5)                 # out-degree of the source node j

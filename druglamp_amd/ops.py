@@ -460,6 +460,16 @@ def interleave_streams(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
     return out
 
 
+def norm_adjacency(adj: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """(B, n, n) fp32 adjacency -> normalised, transposed adjacency in `dtype` (dl_norm_adjacency)."""
+    _need_gpu(adj)
+    adj = adj.contiguous()
+    B, n, _ = adj.shape
+    out = torch.empty((B, n, n), dtype=dtype, device=adj.device)
+    check(_lib.lib().dl_norm_adjacency(adj.data_ptr(), out.data_ptr(), B, n, _DT[dtype], _stream()), "dl_norm_adjacency")
+    return out
+
+
 def concat2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """cat((a, b), -1) for two tensors with equal leading shape."""
     _need_gpu(a, b)

@@ -211,6 +211,10 @@ int dl_token_gate_bwd(const void* dout, const void* v, const float* gate, void* 
  * ------------------------------------------------------------------------------------------ */
 int dl_interleave_streams(const void* src, void* dst, int64_t R, int64_t row_bytes, int32_t S, int32_t inverse,
                           dl_stream s);
+/* Symmetric-normalised, transposed adjacency of a batch of dense graphs: ahat[b][i][j] = din[i] * adj[b][j][i] * dout[j]
+ * with clamped degrees^-1/2 (MolecularGCN: model/basic_model.py:137-153, 591-617 — dgl GraphConv norm='both').
+ * adj (B, n, n) fp32, ahat (B, n, n) out_dtype; n <= 190. */
+int dl_norm_adjacency(const float* adj, void* ahat, int64_t B, int32_t n, int32_t out_dtype, dl_stream s);
 /* cat[r] = [a[r] | b[r]] for two row-major buffers (model/DrugLAMP.py:57,66: `cat((prot_sites, guided), 2)` in front of
  * the MHLA blocks); inverse = 1 splits cat back into a and b (the gradient). */
 int dl_concat2(void* a, void* b, void* cat, int64_t R, int64_t a_row_bytes, int64_t b_row_bytes, int32_t inverse,

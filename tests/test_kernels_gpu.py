@@ -291,3 +291,20 @@ def test_concat2_equals_cat_and_splits_back():
         assert torch.equal(y, torch.cat((a, b), dim=-1))
         a2, b2 = ops.split2(y, 128)
         assert torch.equal(a2, a) and torch.equal(b2, b)
+
+
+def test_norm_adjacency_matches_the_torch_formula():
+    """dl_norm_adjacency against D^-1/2 A^T D^-1/2 with clamped degrees (the dense restatement of dgl's GraphConv norm)."""
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(8)
+    for n in (128, 37):
+        adj = (torch.rand(4, n, n, generator=g) < 0.1).float()
+        adj[3].zero_()                                             # isolated nodes: degrees clamp to 1
+        adj = adj.cuda()
+        dout = adj.sum(-1).clamp(min=1).pow(-0.5)
+        din = adj.sum(-2).clamp(min=1).pow(-0.5)
+        want = adj.transpose(1, 2) * din.unsqueeze(-1) * dout.unsqueeze(-2)
+        got = ops.norm_adjacency(adj, torch.float32)
+        assert (got - want).abs().max() <= 1e-6
+        got16 = ops.norm_adjacency(adj, torch.bfloat16).float()
+        assert (got16 - want).abs().max() <= 4e-3
