@@ -189,3 +189,38 @@ def test_gcn_dense_restatement_vs_plain_torch():
     gr = torch.autograd.grad((x * g).sum(), [gcn.init_transform.weight, gcn.gnn.gnn_layers[1].graph_conv.weight], retain_graph=True)
     go = torch.autograd.grad((out * g).sum(), [gcn.init_transform.weight, gcn.gnn.gnn_layers[1].graph_conv.weight])
     assert relerr(go[0], gr[0]) <= 1e-3 and relerr(go[1], gr[1]) <= 1e-3
+
+
+def test_skipping_dead_backward_passes_leaves_the_same_parameters(monkeypatch):
+    """On an SSL + CM step the reference wipes the cls (and ssl) gradients before any optimiser steps; Trainer does not
+    run those backward passes.  With DL_DEAD_BACKWARD=1 it does: the parameter arenas must be bit-identical."""
+    from druglamp_amd import ops
+    from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
+    from druglamp_amd.model import MInterface
+    from druglamp_amd.synthetic import make_batch
+    from druglamp_amd.trainer import Trainer
+
+    def run(dead):
+        monkeypatch.setenv("DL_DEAD_BACKWARD", "1" if dead else "0")
+        torch.manual_seed(4321)
+        ops.manual_seed(99)
+        cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP2C2P")
+        model = MInterface("DrugLAMP2C2P", cfg).load_model(n_drug_feature=384, n_prot_feature=640).cuda()
+        tr = Trainer(model, cfg, device=torch.device("cuda", 0), compute_dtype=torch.bfloat16)
+        tr.set_lrs(1e-3, 1e-3, 1e-3)
+        assert tr.run_dead_backward == dead
+        batch, meta = make_batch(8, torch.device("cuda", 0), seed=7, with_graph=True, llm_dtype=torch.bfloat16)
+        ep = max(tr.cm_init_epoch, tr.ssl_epoch_step)
+        while ep % tr.ssl_epoch_step:
+            ep += 1
+        outs = []
+        for e in (1, ep, ep):                      # a cls-only step, then two steps with the SSL and CM heads
+            torch.manual_seed(50 + e)              # SSL mask draws
+            outs.append({k: float(v) for k, v in tr.training_step(batch, meta=meta, cur_epoch=e).items()})
+        assert "ssl" in outs[-1] and "cm" in outs[-1]
+        return tr.flat.arena.detach().clone(), outs
+
+    a0, o0 = run(False)
+    a1, o1 = run(True)
+    assert o0 == o1
+    assert torch.equal(a0, a1)
