@@ -224,3 +224,27 @@ def test_skipping_dead_backward_passes_leaves_the_same_parameters(monkeypatch):
     a1, o1 = run(True)
     assert o0 == o1
     assert torch.equal(a0, a1)
+
+
+@pytest.mark.parametrize("B", [3, 5])
+def test_odd_batch_sizes_match_the_oracle(B):
+    """Tile-edge sanity: batch sizes that divide nothing, graph input through the dense GCN, score against the CPU oracle."""
+    from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
+    from druglamp_amd.model import MInterface
+    from druglamp_amd.synthetic import make_batch
+    from oracle import druglamp_oracle as O
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(B)
+    cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP")
+    model = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
+    (feat_d, vp, y, xd, xp), _ = make_batch(B, dev, seed=B, with_graph=True)
+    model.eval()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        vd = model.drug_extractor(feat_d).float().cpu()
+        ref = O.model_forward(sd, "DrugLAMP", vd, vp.cpu(), xd.cpu(), xp.cpu())["score"]
+    for cdt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 5e-2)):
+        model.set_compute_dtype(cdt)
+        with torch.no_grad():
+            _, _, _, _, score = model(feat_d, vp, xd.to(cdt), xp.to(cdt))
+        assert float((score.float().cpu() - ref).abs().max()) <= tol
