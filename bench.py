@@ -6,9 +6,16 @@
 
 A "step" = trainer.Trainer.training_step on one synthetic batch that is already resident in HBM:
 DrugLAMP forward (dense MolecularGCN, ProteinCNN, adaptors, PGCA x2, MHLA x2, PMMA, classifier) +
-BCE backward + gradient all-reduce (RCCL, N > 1) + fused AdamW.  Per-GPU batch 256 (the batch
-BASELINE.json's metric is quoted on); N ranks process N x 256 pairs per step (weak scaling, like the
-reference's DDP which keeps SOLVER.BATCH_SIZE per rank).  Prints ONE JSON line on rank 0.
+BCE backward + gradient all-reduce (RCCL, N > 1) + fused AdamW.
+
+BASELINE.json's metric is quoted on a GLOBAL batch of 256 pairs on 1/2/4/8 GPUs (B = 256 / n_gpu per rank):
+that is what `--gpus N` measures ("scaling": "strong", per-GPU batch 256 / N); the line also carries a short weak-scaling
+measurement (256 pairs per GPU, the reference DDP's "fixed SOLVER.BATCH_SIZE per rank" regime) under "weak" when N > 1.
+`--batch B` fixes the per-GPU batch instead ("scaling": "weak").  `--epoch E` picks the step kind the reference's epoch
+gating gives (trainer.py:192-221: SSL heads every RS.EPOCH_STEP-th epoch, CM head from RS.INIT_EPOCH) and
+`--global-batch-cm` turns on RS.GLOBAL_BATCH (cross-modal triplets over the all-gathered global batch, config C3).
+Per-GPU batches <= 128 replay the cls step as a hipGraph (`--graph auto`; the eager step is host-enqueue bound there).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
@@ -68,9 +75,15 @@ def cpu_baseline(batch_size: int, steps: int, budget_s: float = 25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--global-batch", type=int, default=256, help="pairs per step over all GPUs (BASELINE.json: 256)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch; 0 = global batch / gpus (strong scaling)")
+    ap.add_argument("--epoch", type=int, default=1, help="1-based epoch the step belongs to (selects cls / +SSL / +CM steps)")
+    ap.add_argument("--global-batch-cm", action="store_true", help="RS.GLOBAL_BATCH: CM latents all-gathered over the ranks")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay cls steps as a hipGraph (auto: per-GPU batch <= 128)")
+    ap.add_argument("--no-weak", action="store_true", help="skip the extra weak-scaling measurement at N > 1")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model", default="DrugLAMP")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -107,47 +120,79 @@ def main():
 
     from druglamp_amd import ops
     L = _lib.lib()
+    scaling = "weak" if args.batch > 0 else "strong"
+    if args.batch <= 0:
+        assert args.global_batch % world == 0, "--global-batch must be divisible by --gpus"
+        args.batch = args.global_batch // world
+    use_graph = args.graph == "on" or (args.graph == "auto" and args.batch <= 128)
     torch.manual_seed(1234)                       # identical initial weights on every rank
     ops.manual_seed(1000 + rank)                  # ... but rank-specific dropout streams
     cfg = load_yaml_into(get_cfg_defaults(), args.model)
+    if args.global_batch_cm:
+        cfg["RS"]["GLOBAL_BATCH"] = True
     model = MInterface(args.model, cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    trainer = Trainer(model, cfg, device=dev, compute_dtype=cdt)
+    trainer = Trainer(model, cfg, device=dev, compute_dtype=cdt, graph_steps=use_graph)
     trainer.set_lrs(cfg["SOLVER"]["LR"], cfg["SOLVER"]["SSL_LR"], cfg["SOLVER"]["CM_LR"])
-    batch, meta = make_batch(args.batch, dev, seed=100 + rank, with_graph=True, llm_dtype=cdt)
+    ep = args.epoch
+    kinds = ["cls"] + (["ssl"] if trainer.use_ssl and ep % trainer.ssl_epoch_step == 0 else []) + \
+        (["cm"] if trainer.use_cm and ep >= trainer.cm_init_epoch else [])
+    graphed = use_graph and kinds == ["cls"]
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.training_step(batch, meta=meta, cur_epoch=1)
-    timing = not args.no_kernel_timing
-    sync()
-    if timing:
-        for fam in (0, 1, 2):
-            L.dl_prof_enable(fam, max(args.time_every, 1))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.training_step(batch, meta=meta, cur_epoch=1)
-    sync()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t)
+    def measure(per_gpu_batch, steps, warmup, with_events):
+        """W untimed + K timed steps at one per-GPU batch; returns (seconds, max over ranks; family statistics)."""
+        batch, meta = make_batch(per_gpu_batch, dev, seed=100 + rank, with_graph=True, llm_dtype=cdt)
+        for _ in range(max(warmup, trainer.graph_warmup + 1 if graphed else 0)):
+            trainer.training_step(batch, meta=meta, cur_epoch=ep)
+        batch = trainer.static_batch(batch)       # inputs stay resident: the graph's own input tensors (no per-step copy)
+        sync()
+        if with_events:
+            for fam in (0, 1, 2):
+                L.dl_prof_enable(fam, max(args.time_every, 1))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.training_step(batch, meta=meta, cur_epoch=ep)
+        sync()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        stats = {}
+        if with_events:
+            for fam, name in ((0, "gemm"), (1, "attn_fwd"), (2, "attn_bwd")):
+                n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+                L.dl_prof_collect(fam, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
+                na, fla, bya = C.c_int64(), C.c_double(), C.c_double()
+                L.dl_prof_totals(fam, C.byref(na), C.byref(fla), C.byref(bya))
+                # (timed launches, their ms / flops / bytes, all launches of the region, their flops / bytes)
+                stats[name] = (n.value, ms.value, fl.value, by.value, na.value, fla.value, bya.value)
+                L.dl_prof_enable(fam, 0)
+        return float(t), stats
 
-    fam_stats = {}
-    if timing:
-        for fam, name in ((0, "gemm"), (1, "attn_fwd"), (2, "attn_bwd")):
-            n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
-            L.dl_prof_collect(fam, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by))
-            na, fla, bya = C.c_int64(), C.c_double(), C.c_double()
-            L.dl_prof_totals(fam, C.byref(na), C.byref(fla), C.byref(bya))
-            # (timed launches, their ms / flops / bytes, all launches of the timed region, their flops / bytes)
-            fam_stats[name] = (n.value, ms.value, fl.value, by.value, na.value, fla.value, bya.value)
-            L.dl_prof_enable(fam, 0)
+    timing = not args.no_kernel_timing
+    # HIP events bracket library launches as they are enqueued; the nodes of a replayed graph cannot be bracketed, so a
+    # graphed run takes its kernel timings from a separate instrumented pass of eager steps (same process, same data)
+    dt, fam_stats = measure(args.batch, args.steps, args.warmup, timing and not graphed)
+    events_steps, events_dt, events_note = args.steps, dt, "HIP events over the timed region"
+    if timing and graphed:
+        trainer.graph_steps = False
+        events_steps = min(args.steps, 20)
+        events_dt, fam_stats = measure(args.batch, events_steps, 2, True)
+        trainer.graph_steps = True
+        events_note = ("HIP events over %d EAGER steps run right after the timed region (the timed region replays a hipGraph, "
+                       "whose nodes cannot be bracketed by events; same kernels, same data)" % events_steps)
+    weak = None
+    if world > 1 and scaling == "strong" and not args.no_weak:
+        wsteps = max(10, min(args.steps // 4, 50))
+        wdt, _ = measure(args.global_batch, wsteps, 3, False)
+        weak = {"per_gpu_batch": args.global_batch, "global_batch": args.global_batch * world, "steps": wsteps,
+                "ms_per_step": round(wdt / wsteps * 1e3, 3), "value": round(args.global_batch * world * wsteps / wdt, 2),
+                "unit": "pairs/s"}
 
     if rank == 0:
         pairs = args.batch * world * args.steps
@@ -156,25 +201,34 @@ def main():
         out = {
             "metric": "drug-protein pairs/sec training step",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%s training step (fwd+bwd+grad all-reduce+AdamW), BindingDB-shaped synthetic pairs "
+            "config": {"workload": "%s training step (%s; fwd+bwd+grad all-reduce+AdamW), BindingDB-shaped synthetic pairs "
                                    "(512 drug nodes/tokens, 2304 protein tokens, pre-extracted 384-d/640-d LLM embeddings), "
-                                   "per-GPU batch %d" % (args.model, args.batch),
-                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+                                   "global batch %d = %d per GPU x %d%s%s" % (
+                                       args.model, "+".join(kinds) + " step, epoch %d" % ep, args.batch * world, args.batch, world,
+                                       ", cls step replayed as a hipGraph" if graphed else "",
+                                       ", CM latents all-gathered (RS.GLOBAL_BATCH)" if args.global_batch_cm else ""),
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "step_kind": "+".join(kinds), "epoch": ep, "hip_graph": bool(graphed)},
             "hot_path_tflops_per_gpu": round(value * HOT_FLOPS_PER_PAIR_STEP / world / 1e12, 2),
             "hot_path_frac_of_peak": round(value * HOT_FLOPS_PER_PAIR_STEP / world / 1e12 / peak, 4),
         }
         if timing and fam_stats["gemm"][0] > 0:
             n, ms, fl, by, n_all, fl_all, by_all = fam_stats["gemm"]
-            ms_all = ms * n_all / n            # family time over the whole timed region, from the timed sample
+            ms_all = ms * n_all / n            # family time over the whole instrumented region, from the timed sample
+            dt_ev, steps_ev = events_dt, events_steps
             ach = fl / (ms * 1e-3) / 1e12
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
-            if os.path.exists(pmc) and args.batch == 256 and args.dtype == "bf16" and args.model == "DrugLAMP":
-                # HBM bytes per dl_gemm launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-                # workload (tools/pmc_summary.py; x2 gfx950 read correction), committed under profiles/
-                traffic = round(json.load(open(pmc))["families"]["gemm"]["traffic_bytes_per_launch"])
+            traffic, traffic_source = None, None
+            for pmc_name in ("r2_pmc_summary.json", "r1_pmc_summary.json"):
+                pmc = os.path.join(ROOT, "profiles", pmc_name)
+                if os.path.exists(pmc) and args.batch == 256 and args.dtype == "bf16" and args.model == "DrugLAMP" and kinds == ["cls"]:
+                    # HBM bytes per dl_gemm launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+                    # workload (tools/pmc_summary.py; x2 gfx950 read correction), committed under profiles/ — a
+                    # recorded counter measurement of the same command, NOT re-measured by this run
+                    traffic = round(json.load(open(pmc))["families"]["gemm"]["traffic_bytes_per_launch"])
+                    traffic_source = "profiles/%s (rocprofv3 --pmc passes of this command, recorded earlier; not measured by this run)" % pmc_name
+                    break
             # Which roofline binds the family: the algorithmic bytes of all launches at the HBM peak vs their flops at
             # the dense MFMA peak.  For this workload (most products have K <= 512) the HBM floor is the larger one.
             t_hbm = by_all / (HBM_PEAK_GBPS * 1e9)
@@ -186,19 +240,22 @@ def main():
             out["roofline"] = {"kernel": "dl_gemm (all layouts: fwd / dgrad / wgrad)", "bound": bound}
             out["roofline"].update(hbm_obj if bound == "hbm" else mfma_obj)
             out["roofline"].update({
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_source,
+                "timing_source": events_note,
                 "algorithmic_bytes_per_launch": round(by_all / n_all), "algorithmic_flops_per_launch": round(fl_all / n_all),
                 "launches": n_all, "timed_launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
-                "time_share_of_step": round(ms_all / (dt * 1e3), 3),
-                "floor_ms_per_step": {"hbm": round(t_hbm * 1e3 / args.steps, 3), "mfma": round(t_mfma * 1e3 / args.steps, 3),
-                                      "measured": round(ms_all / args.steps, 3)},
+                "time_share_of_step": round(ms_all / (dt_ev * 1e3), 3),
+                "floor_ms_per_step": {"hbm": round(t_hbm * 1e3 / steps_ev, 3), "mfma": round(t_mfma * 1e3 / steps_ev, 3),
+                                      "measured": round(ms_all / steps_ev, 3)},
                 "mfma": mfma_obj, "hbm": hbm_obj})
             for name in ("attn_fwd", "attn_bwd"):
                 n2, ms2, fl2, _, n2_all, _, _ = fam_stats[name]
                 if n2:
                     out["roofline"][name] = {"achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2), "launches": n2_all,
                                              "timed_launches": n2, "avg_launch_us": round(ms2 * 1e3 / n2, 2),
-                                             "time_share_of_step": round(ms2 * n2_all / n2 / (dt * 1e3), 3)}
+                                             "time_share_of_step": round(ms2 * n2_all / n2 / (events_dt * 1e3), 3)}
+        if weak is not None:
+            out["weak"] = weak
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(out), flush=True)

@@ -12,7 +12,9 @@ import torch  # noqa: F401  (must be imported BEFORE the dlopen below: the libra
 #                            torch already loaded instead of bringing up a second, device-less copy)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdruglamp_hip.so")
+# DL_USE_STUDY_LIB=1 (tools/ only) loads the -DDL_STUDY build, the only one that reads study switches from the environment
+LIB_PATH = os.path.join(_HERE, "lib", "libdruglamp_hip_study.so" if os.environ.get("DL_USE_STUDY_LIB") == "1"
+                        else "libdruglamp_hip.so")
 
 DL_F32, DL_BF16 = 0, 1
 
@@ -37,6 +39,8 @@ class GemmArgs(C.Structure):
         ("accumulate", c_i32),
         ("split_k", c_i32), ("workspace", c_vp), ("workspace_bytes", c_sz),
         ("x_colsum", c_vp),
+        ("dropout_seed_offset", c_vp),
+        ("algo", c_i32),
     ]
 
 
@@ -50,6 +54,7 @@ class AttnFwdArgs(C.Structure):
         ("n_problems", c_i32), ("n_heads", c_i32), ("n_segments", c_i32), ("partner_shift", c_i32),
         ("Lq", c_i32), ("Lk", c_i32), ("head_dim", c_i32), ("dtype", c_i32),
         ("scale", c_f32),
+        ("algo", c_i32),
     ]
 
 
@@ -69,6 +74,7 @@ class AttnBwdArgs(C.Structure):
         ("n_problems", c_i32), ("n_heads", c_i32), ("n_segments", c_i32), ("partner_shift", c_i32),
         ("Lq", c_i32), ("Lk", c_i32), ("head_dim", c_i32), ("dtype", c_i32),
         ("scale", c_f32),
+        ("algo", c_i32),
     ]
 
 
@@ -94,8 +100,8 @@ SIGNATURES = {
     "dl_attn_bwd": (c_i32, [C.POINTER(AttnBwdArgs), c_vp]),
     "dl_token_gate_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "dl_token_gate_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
-    "dl_add_rowmod_dropout": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_u64, c_i32, c_vp]),
-    "dl_dropout_apply": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_u64, c_i32, c_vp]),
+    "dl_add_rowmod_dropout": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_u64, c_vp, c_i32, c_vp]),
+    "dl_dropout_apply": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_u64, c_vp, c_i32, c_vp]),
     "dl_fill_pool": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "dl_cnn_sitepool_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "dl_cnn_sitepool_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),

@@ -2,6 +2,9 @@
 
     python -m druglamp_amd.build        # incremental
     python -m druglamp_amd.build -f     # force rebuild
+    python -m druglamp_amd.build --study   # additionally libdruglamp_hip_study.so (-DDL_STUDY: reads the tile-study /
+                                           # timing-decomposition switches from the environment; tools/ only, loaded with
+                                           # DL_USE_STUDY_LIB=1 — the product library never reads the environment)
 
 The shared object lands in druglamp_amd/lib/ (git-ignored; it travels to the GPU box with the
 gpurun snapshot).  No cmake, no torch extension machinery: the C ABI has no torch types.
@@ -40,22 +43,29 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJDIR, src[:-4] + ".o")
+def _compile(src, force, objdir=OBJDIR, extra=()):
+    obj = os.path.join(objdir, src[:-4] + ".o")
     path = os.path.join(CSRC, src)
     if force or _stale(obj, [path] + _headers()):
-        cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+        cmd = [HIPCC] + FLAGS + list(extra) + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     return obj
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    os.makedirs(OBJDIR, exist_ok=True)
+def build(force: bool = False, verbose: bool = True, study: bool = False) -> str:
+    objdir = OBJDIR + ("_study" if study else "")
+    lib = LIB.replace(".so", "_study.so") if study else LIB
+    extra = ("-DDL_STUDY",) if study else ()
+    os.makedirs(objdir, exist_ok=True)
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+        objs = list(ex.map(lambda s: _compile(s, force, objdir, extra), srcs))
+    return _link(lib, objs, force, verbose)
+
+
+def _link(LIB, objs, force, verbose):
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -70,3 +80,5 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 if __name__ == "__main__":
     build(force="-f" in sys.argv)
+    if "--study" in sys.argv:
+        build(force="-f" in sys.argv, study=True)

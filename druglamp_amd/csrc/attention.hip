@@ -13,7 +13,6 @@
 // LDS tiles are [rows][head_dim] with 16-byte chunks XOR-swizzled by ATile::swz(row); the same image
 // serves ds_read_b128 (K-contiguous fragments) and ds_read_b64_tr_b16 / ds_read_b32 (transposed
 // fragments).
-#include <stdlib.h>
 #include "tiles.cuh"
 
 namespace {
@@ -31,6 +30,7 @@ struct AttnP {
   int64_t do_ps, do_hs, do_rs, do_ss, dq_ps, dq_hs, dq_rs, dk_ps, dk_hs, dk_rs, dv_ps, dv_hs, dv_rs;
   int P, H, S, shift, Lq, Lk;
   float scale;
+  int algo;
 };
 
 __device__ __attribute__((aligned(16))) const uint32_t attn_zero_page[4] = {0u, 0u, 0u, 0u};
@@ -716,10 +716,9 @@ int check_common(const char* who, int dtype, int head_dim, int nseg, int P, int 
 template <typename T, int HD>
 int launch_fwd(const AttnP& p, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
-    // K/V-resident form for short key sequences (DL_ATTN_RES=0 disables it for A/B studies)
-    const char* e = getenv("DL_ATTN_RES");
+    // K/V-resident form for short key sequences (algo = DL_ATTN_ALGO_STREAM keeps a call on the streaming form)
     // (measured: at head_dim 128 the 128 KB image leaves one workgroup per CU and ties with the streaming form)
-    if (HD == 64 && p.Lk <= 256 && !(e && atoi(e) == 0)) {
+    if (HD == 64 && p.Lk <= 256 && p.algo != DL_ATTN_ALGO_STREAM) {
       constexpr int NW = HD == 64 ? 4 : 8;            // 64 KB -> two workgroups per CU; 128 KB -> one of 8 waves
       hipLaunchKernelGGL((attn_fwd_res_kernel<T, HD, 2, NW>), dim3((uint32_t)p.H, (uint32_t)p.P), dim3(64 * NW), 0, s, p);
       return DL_OK;
@@ -742,8 +741,7 @@ int launch_bwd(const AttnP& p, hipStream_t s) {
   const dim3 gk((uint32_t)((p.Lk + KVB - 1) / KVB), (uint32_t)p.H, (uint32_t)p.P);
   if constexpr (sizeof(T) == 2 && HD == 64) {
     // LDS-resident forms (64 KB images, two workgroups per CU); Delta comes out of the dQ kernel
-    const char* e = getenv("DL_ATTN_RES");
-    if (p.Lk <= 256 && p.Lq <= 256 && !(e && atoi(e) == 0)) {
+    if (p.Lk <= 256 && p.Lq <= 256 && p.algo != DL_ATTN_ALGO_STREAM) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, QT, true>), gq, dim3(ATT_THREADS), 0, s, p);
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD, KT, true>), gk, dim3(ATT_THREADS), 0, s, p);
       return DL_OK;
@@ -777,7 +775,7 @@ extern "C" int dl_attn_fwd(const dl_attn_fwd_args* a, dl_stream stream) {
   p.v_ps = a->v_ps; p.v_hs = a->v_hs; p.v_rs = a->v_rs; p.o_ps = a->o_ps; p.o_hs = a->o_hs; p.o_rs = a->o_rs;
   p.o_ss = a->o_ss;
   p.P = a->n_problems; p.H = a->n_heads; p.S = a->n_segments; p.shift = a->partner_shift;
-  p.Lq = a->Lq; p.Lk = a->Lk; p.scale = a->scale;
+  p.Lq = a->Lq; p.Lk = a->Lk; p.scale = a->scale; p.algo = a->algo;
   dl_prof_before(1, s);
   if (a->dtype == DL_BF16) rc = a->head_dim == 64 ? launch_fwd<bf16_t, 64>(p, s) : launch_fwd<bf16_t, 128>(p, s);
   else rc = a->head_dim == 64 ? launch_fwd<float, 64>(p, s) : launch_fwd<float, 128>(p, s);
@@ -812,7 +810,7 @@ extern "C" int dl_attn_bwd(const dl_attn_bwd_args* a, dl_stream stream) {
   p.dq_ps = a->dq_ps; p.dq_hs = a->dq_hs; p.dq_rs = a->dq_rs; p.dk_ps = a->dk_ps; p.dk_hs = a->dk_hs;
   p.dk_rs = a->dk_rs; p.dv_ps = a->dv_ps; p.dv_hs = a->dv_hs; p.dv_rs = a->dv_rs;
   p.P = a->n_problems; p.H = a->n_heads; p.S = a->n_segments; p.shift = a->partner_shift;
-  p.Lq = a->Lq; p.Lk = a->Lk; p.scale = a->scale;
+  p.Lq = a->Lq; p.Lk = a->Lk; p.scale = a->scale; p.algo = a->algo;
   dl_prof_before(2, s);
   if (a->dtype == DL_BF16) rc = a->head_dim == 64 ? launch_bwd<bf16_t, 64>(p, s) : launch_bwd<bf16_t, 128>(p, s);
   else rc = a->head_dim == 64 ? launch_bwd<float, 64>(p, s) : launch_bwd<float, 128>(p, s);

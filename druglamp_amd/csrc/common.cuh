@@ -32,6 +32,23 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define DL_LDS __attribute__((address_space(3)))
 
+// Study switches (tile forms that were measured and rejected, "skip the stores" timing decompositions ...) exist only
+// in a -DDL_STUDY build (`python -m druglamp_amd.build --study` -> libdruglamp_hip_study.so, used by tools/).  The
+// product library never reads the environment: dl_study_env() is the constant default there, so no stray variable
+// can change which kernel runs or make a kernel skip work.
+#ifdef DL_STUDY
+#include <stdlib.h>
+static inline int dl_study_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static constexpr int dl_study_env(const char*, int dflt) { return dflt; }
+#endif
+// kernel-side view of a study bit field: the constant 0 in the product build, so the study branches are compiled out
+#ifdef DL_STUDY
+#define DL_DBG(p) ((p).dbg)
+#else
+#define DL_DBG(p) 0
+#endif
+
 extern "C" void dl_set_error(const char* fmt, ...);
 // profiling hooks (api.hip)
 void dl_prof_before(int family, hipStream_t s);
@@ -302,6 +319,12 @@ __device__ __forceinline__ uint64_t dl_splitmix(uint64_t seed, uint64_t idx) {
 __host__ __device__ __forceinline__ uint32_t dl_dropout_thr16(float p) {
   float t = p * 65536.0f + 0.5f;
   return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)t);
+}
+// Effective dropout seed: the by-value seed of the call plus an optional DEVICE-resident offset.  A training step
+// captured in a hipGraph bakes every by-value argument; the offset (one uint64 the host-side step loop bumps with a
+// tiny in-graph kernel) is what gives each replay fresh masks, and forward / backward of one replay read the same value.
+__device__ __forceinline__ uint64_t dl_eff_seed(uint64_t seed, const uint64_t* __restrict__ off) {
+  return off ? seed + *off : seed;
 }
 // element (row, col) of a logical [rows][ncols] tensor, col % 4 == 0: returns 4 keep flags scaled
 __device__ __forceinline__ f32x4 dl_dropout4(f32x4 v, uint64_t seed, uint64_t row, uint64_t col,

@@ -99,7 +99,7 @@ __global__ void gate_bwd_rows_kernel(const T* __restrict__ dout, const T* __rest
 template <typename T>
 __global__ void add_rowmod_dropout_kernel(const T* __restrict__ x, const T* __restrict__ pe, T* __restrict__ y,
                                           int64_t M, int D, int64_t L, uint32_t thr16, float inv_keep,
-                                          uint64_t seed) {
+                                          uint64_t seed, const uint64_t* __restrict__ seed_off) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n4 = M * (D / 4);
   if (i >= n4) return;
@@ -107,20 +107,21 @@ __global__ void add_rowmod_dropout_kernel(const T* __restrict__ x, const T* __re
   const int col = (int)(i % (D / 4)) * 4;
   f32x4 v = load4<T>(x + row * D + col);
   if (pe) v += load4<T>(pe + (row % L) * D + col);
-  if (thr16) v = dl_dropout4(v, seed, (uint64_t)row, (uint64_t)col, (uint64_t)D, thr16, inv_keep);
+  if (thr16) v = dl_dropout4(v, dl_eff_seed(seed, seed_off), (uint64_t)row, (uint64_t)col, (uint64_t)D, thr16, inv_keep);
   store4<T>(y + row * D + col, v);
 }
 
 template <typename T>
 __global__ void dropout_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows, int D, int64_t ldx,
-                                     int64_t ldy, uint32_t thr16, float inv_keep, uint64_t seed) {
+                                     int64_t ldy, uint32_t thr16, float inv_keep, uint64_t seed,
+                                     const uint64_t* __restrict__ seed_off) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n4 = rows * (D / 4);
   if (i >= n4) return;
   const int64_t row = i / (D / 4);
   const int col = (int)(i % (D / 4)) * 4;
   f32x4 v = load4<T>(x + row * ldx + col);
-  v = dl_dropout4(v, seed, (uint64_t)row, (uint64_t)col, (uint64_t)D, thr16, inv_keep);
+  v = dl_dropout4(v, dl_eff_seed(seed, seed_off), (uint64_t)row, (uint64_t)col, (uint64_t)D, thr16, inv_keep);
   store4<T>(y + row * ldy + col, v);
 }
 
@@ -613,7 +614,7 @@ extern "C" int dl_token_gate_bwd(const void* dout, const void* v, const float* g
 }
 
 extern "C" int dl_add_rowmod_dropout(const void* x, const void* pe, void* y, int64_t M, int64_t D, int64_t L,
-                                     float p, uint64_t seed, int32_t dtype, dl_stream stream) {
+                                     float p, uint64_t seed, const uint64_t* seed_offset, int32_t dtype, dl_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   DL_CHECK_ARG(x && y && M > 0 && D > 0 && D % 4 == 0 && L > 0, DL_ERR_ARG, "dl_add_rowmod_dropout: bad args");
   DL_CHECK_ARG(p >= 0.f && p < 1.f, DL_ERR_ARG, "dl_add_rowmod_dropout: bad p");
@@ -622,16 +623,16 @@ extern "C" int dl_add_rowmod_dropout(const void* x, const void* pe, void* y, int
   const int64_t n4 = M * D / 4;
   if (dtype == DL_BF16)
     hipLaunchKernelGGL((add_rowmod_dropout_kernel<bf16_t>), dim3(nblk(n4)), dim3(256), 0, s, (const bf16_t*)x,
-                       (const bf16_t*)pe, (bf16_t*)y, M, (int)D, L, thr, inv, seed);
+                       (const bf16_t*)pe, (bf16_t*)y, M, (int)D, L, thr, inv, seed, seed_offset);
   else
     hipLaunchKernelGGL((add_rowmod_dropout_kernel<float>), dim3(nblk(n4)), dim3(256), 0, s, (const float*)x,
-                       (const float*)pe, (float*)y, M, (int)D, L, thr, inv, seed);
+                       (const float*)pe, (float*)y, M, (int)D, L, thr, inv, seed, seed_offset);
   DL_CHECK_LAUNCH("dl_add_rowmod_dropout");
   return DL_OK;
 }
 
 extern "C" int dl_dropout_apply(const void* x, void* y, int64_t n_rows, int64_t D, int64_t ldx, int64_t ldy,
-                                float p, uint64_t seed, int32_t dtype, dl_stream stream) {
+                                float p, uint64_t seed, const uint64_t* seed_offset, int32_t dtype, dl_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   DL_CHECK_ARG(x && y && n_rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, DL_ERR_ARG,
                "dl_dropout_apply: bad args");
@@ -639,10 +640,10 @@ extern "C" int dl_dropout_apply(const void* x, void* y, int64_t n_rows, int64_t 
   const int64_t n4 = n_rows * D / 4;
   if (dtype == DL_BF16)
     hipLaunchKernelGGL((dropout_apply_kernel<bf16_t>), dim3(nblk(n4)), dim3(256), 0, s, (const bf16_t*)x,
-                       (bf16_t*)y, n_rows, (int)D, ldx, ldy, dl_dropout_thr16(p), 1.0f / (1.0f - p), seed);
+                       (bf16_t*)y, n_rows, (int)D, ldx, ldy, dl_dropout_thr16(p), 1.0f / (1.0f - p), seed, seed_offset);
   else
     hipLaunchKernelGGL((dropout_apply_kernel<float>), dim3(nblk(n4)), dim3(256), 0, s, (const float*)x, (float*)y,
-                       n_rows, (int)D, ldx, ldy, dl_dropout_thr16(p), 1.0f / (1.0f - p), seed);
+                       n_rows, (int)D, ldx, ldy, dl_dropout_thr16(p), 1.0f / (1.0f - p), seed, seed_offset);
   DL_CHECK_LAUNCH("dl_dropout_apply");
   return DL_OK;
 }

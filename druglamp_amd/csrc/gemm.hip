@@ -41,7 +41,7 @@ struct GemmP {
   int act;
   char* pre_out; int64_t ldp;
   const char* dact_pre; int64_t lddp;
-  uint32_t drop_thr16; float drop_inv_keep; uint64_t seed;
+  uint32_t drop_thr16; float drop_inv_keep; uint64_t seed; const uint64_t* seed_off;
   int accumulate;
   float* slabs;   // split mode: [splits][M][N] f32
   float* cs_slabs; // split mode, optional: [splits][M] partial column sums of the K-slow X operand
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   u32x4 rx[TW], rw[TW];
   uint32_t it = blockIdx.x;
   if (it >= ntiles) return;
-  if ((p.dbg & 4) && (blockIdx.x >= gridDim.x / 2)) { for (int z = 0; z < (p.dbg >> 4); ++z) __builtin_amdgcn_s_sleep(127); }
+  if ((DL_DBG(p) & 4) && (blockIdx.x >= gridDim.x / 2)) { for (int z = 0; z < (DL_DBG(p) >> 4); ++z) __builtin_amdgcn_s_sleep(127); }
   int split, m0, n0, kbeg, kend;
   locate(it, split, m0, n0, kbeg, kend);
   if constexpr (!XD) load_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg, kend, rx);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
       char* cur = smem + (kt & 1) * 2 * TB;
       char* nxt = smem + ((kt + 1) & 1) * 2 * TB;
       const bool more = (kt + 1 < nk);
-      if (more && !(p.dbg & 2)) {
+      if (more && !(DL_DBG(p) & 2)) {
         if constexpr (XD) dma_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, nxt);
         else load_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, kend, rx);
         if constexpr (WD) dma_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, nxt + TB);
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
     const int row = c / (BN / 8), cc = (c % (BN / 8)) * 8;
     const int m = cm0 + row, n = cn0 + cc;
     if (m >= p.M || n >= p.N) continue;
-    if ((p.dbg & 1)) continue;
+    if ((DL_DBG(p) & 1)) continue;
     if constexpr (SIMPLE && !SPLIT) {
       // bias-only epilogue, N % 8 == 0: straight LDS -> (bias) -> convert -> one 16-byte store
       f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4);
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
         a0 *= gelu_grad4<T>(q0); a1 *= gelu_grad4<T>(q1);
       }
       if (EPI != 5 && p.drop_thr16) {
-        a0 = dl_dropout4(a0, p.seed, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
-        a1 = dl_dropout4(a1, p.seed, (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+        a0 = dl_dropout4(a0, dl_eff_seed(p.seed, p.seed_off), (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+        a1 = dl_dropout4(a1, dl_eff_seed(p.seed, p.seed_off), (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
       }
       if constexpr (EPI == 3) {
         const T* src = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n;
@@ -432,8 +432,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
       }
       if (p.drop_thr16) {
         f32x4 d0 = {v[0], v[1], v[2], v[3]}, d1 = {v[4], v[5], v[6], v[7]};
-        d0 = dl_dropout4(d0, p.seed, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
-        d1 = dl_dropout4(d1, p.seed, (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+        d0 = dl_dropout4(d0, dl_eff_seed(p.seed, p.seed_off), (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+        d1 = dl_dropout4(d1, dl_eff_seed(p.seed, p.seed_off), (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[r] = d0[r]; v[4 + r] = d1[r]; }
       }
@@ -522,9 +522,7 @@ int pick_tw(const dl_gemm_args* a) {
 int auto_split(int64_t M, int64_t N, int64_t K, int bke, int bt) {
   const int64_t tiles = ((M + bt - 1) / bt) * ((N + bt - 1) / bt);
   if (tiles >= 192) return 1;
-  static int round_wgs = -1, max_sp = -1;
-  if (round_wgs < 0) { const char* e = getenv("DL_SPLIT_ROUND"); round_wgs = e ? atoi(e) : 512; }
-  if (max_sp < 0) { const char* e = getenv("DL_SPLIT_MAX"); max_sp = e ? atoi(e) : 256; }
+  const int round_wgs = dl_study_env("DL_SPLIT_ROUND", 512), max_sp = dl_study_env("DL_SPLIT_MAX", 256);
   int64_t want = round_wgs / tiles;        // floor: tiles * splits must fit ONE round of 512 resident workgroups (a
                                            // 516-workgroup plan ran 4 of them alone in a second round: 768x256, +25 %)
   if (want < 1) want = 1;
@@ -575,21 +573,16 @@ int pick_epi(const GemmP& p, bool split) {
 // N wide enough for a 256-column tile and enough tiles to give every CU one.  Measured against the
 // alternatives the template allows (64-byte rows x 4 stages; 256x128 tiles, two workgroups per CU) the
 // 128-byte x 2-stage 256x256 form won on every shape of the path; narrow outputs (N <= 128) stay on
-// gemm_kernel.  DL_GEMM_BIG=0 disables the path (tile studies).
+// gemm_kernel.  dl_gemm_args.algo = DL_GEMM_ALGO_TILE128 keeps a call off the path (bitwise A/B tests).
 bool big_eligible(const dl_gemm_args* a, const GemmP& p, int sp) {
-  const char* e = getenv("DL_GEMM_BIG");
-  if (e && atoi(e) == 0) return false;
+  if (a->algo == DL_GEMM_ALGO_TILE128) return false;
   if (sp > 1 || a->in_dtype != DL_BF16 || a->out_dtype != DL_BF16 || a->x_kslow || a->w_kslow) return false;
   if (pick_epi(p, false) == 1) return false;
   if (a->K % 64 != 0 || a->N <= 128) return false;
   const int64_t tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
   return tiles >= 192;
 }
-int big_cfg() {
-  static int cfg = -1;
-  if (cfg < 0) { const char* e = getenv("DL_GEMM_BIGCFG"); cfg = e ? atoi(e) : 0; }
-  return cfg;
-}
+int big_cfg() { return dl_study_env("DL_GEMM_BIGCFG", 0); }
 void launch_big(const GemmP& p, hipStream_t s) {
   const uint32_t ntiles = (uint32_t)p.mt * p.nt;
   const int cfg = big_cfg();
@@ -647,8 +640,7 @@ void launch_big(const GemmP& p, hipStream_t s) {
 // Large-tile weight-gradient path (gemm_big_tt_kernel): bf16 operands, both K-slow, plain fp32 output through
 // split-K slabs.  Returns the slab count (0 = not eligible); *bm_out is the tile height (256 or 128).
 int big_tt_plan(const dl_gemm_args* a, int* bm_out) {
-  const char* e = getenv("DL_GEMM_BIG");
-  if (e && atoi(e) == 0) return 0;
+  if (a->algo == DL_GEMM_ALGO_TILE128) return 0;
   if (a->in_dtype != DL_BF16 || !a->x_kslow || !a->w_kslow || a->split_k != 0) return 0;
   const bool plain = !a->bias && !a->residual && !a->act && !a->pre_out && !a->dact_pre && a->dropout_p <= 0.f;
   if (!plain || a->M % 8 != 0 || a->N % 8 != 0 || a->N < 192 || a->M < 96 || a->K < 4096) return 0;
@@ -717,7 +709,7 @@ template <typename T, typename TO, bool SPLIT>
 int dispatch_layout(const dl_gemm_args* a, const GemmP& p, hipStream_t s, int tw) {
   // LDS-DMA staging needs whole K steps per split and at least one K-contiguous operand
   const int bke = BKB / (int)sizeof(T);
-  const bool dma = (a->K % bke == 0) && (p.k_per_split % bke == 0) && !(p.dbg & 8);
+  const bool dma = (a->K % bke == 0) && (p.k_per_split % bke == 0) && !(DL_DBG(p) & 8);
   if (!a->x_kslow && !a->w_kslow) { if (dma) launch<T, TO, false, false, SPLIT, true>(p, s, tw); else launch<T, TO, false, false, SPLIT, false>(p, s, tw); }
   else if (!a->x_kslow && a->w_kslow) { if (dma) launch<T, TO, false, true, SPLIT, true>(p, s, tw); else launch<T, TO, false, true, SPLIT, false>(p, s, tw); }
   else if (a->x_kslow && a->w_kslow) { if (dma) launch<T, TO, true, true, SPLIT, true>(p, s, tw); else launch<T, TO, true, true, SPLIT, false>(p, s, tw); }
@@ -773,6 +765,7 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   }
   DL_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, DL_ERR_ARG, "dl_gemm: dropout_p out of range");
   DL_CHECK_ARG(a->dropout_p == 0.f || a->N % 8 == 0, DL_ERR_SHAPE, "dl_gemm: dropout needs N %% 8 == 0");
+  DL_CHECK_ARG(a->algo == DL_GEMM_ALGO_AUTO || a->algo == DL_GEMM_ALGO_TILE128, DL_ERR_ARG, "dl_gemm: bad algo %d", a->algo);
 
   const int sp = resolve_split(a);
   int tt_bm = 0;
@@ -811,11 +804,11 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   p.dact_pre = (const char*)a->dact_pre; p.lddp = a->lddp;
   p.drop_thr16 = a->dropout_p > 0.f ? dl_dropout_thr16(a->dropout_p) : 0u;
   p.drop_inv_keep = a->dropout_p > 0.f ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
-  p.seed = a->dropout_seed;
+  p.seed = a->dropout_seed; p.seed_off = a->dropout_seed_offset;
   p.accumulate = a->accumulate;
   p.slabs = (float*)a->workspace;
   p.cs_slabs = a->x_colsum ? (float*)a->workspace + (size_t)sp * a->M * a->N : nullptr;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DL_GEMM_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+  p.dbg = dl_study_env("DL_GEMM_DBG", 0);     // 0 in the product build (kernels compile the study branches out)
 
   dl_prof_before(0, s);
   int rc = DL_OK;

@@ -37,8 +37,8 @@ __device__ __forceinline__ void big_epilogue8(const GemmP& p, int m, int n, f32x
     a1 *= gelu_grad4<T>(f32x4{bf16lo(ext[2]), bf16hi(ext[2]), bf16lo(ext[3]), bf16hi(ext[3])});
   }
   if (EPI != 5 && EPI != 0 && p.drop_thr16) {
-    a0 = dl_dropout4(a0, p.seed, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
-    a1 = dl_dropout4(a1, p.seed, (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+    a0 = dl_dropout4(a0, dl_eff_seed(p.seed, p.seed_off), (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+    a1 = dl_dropout4(a1, dl_eff_seed(p.seed, p.seed_off), (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
   }
   if constexpr (EPI == 3) {
     a0 += f32x4{bf16lo(ext[0]), bf16hi(ext[0]), bf16lo(ext[1]), bf16hi(ext[1])};
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN >= 8 ? NWM * NWN / 4 : 2
       }
       ++gs;
     };
-    if (p.dbg & 2) {                   // timing study: no operand feed after the prologue (results are garbage)
+    if (DL_DBG(p) & 2) {                   // timing study: no operand feed after the prologue (results are garbage)
       for (int kt = 0; kt < nk; ++kt) kstep(std::false_type{}, kt);
     } else {
       for (int kt = 0; kt + D < nk; ++kt) kstep(std::true_type{}, kt);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN >= 8 ? NWM * NWN / 4 : 2
           const f32x4 a0 = __builtin_bit_cast(f32x4, lds_read16(st, r * 256 + (((2 * c8) ^ r) << 4)));
           const f32x4 a1 = __builtin_bit_cast(f32x4, lds_read16(st, r * 256 + (((2 * c8 + 1) ^ r) << 4)));
           const int m = m_of(item);
-          if (m < p.M && n_ok && !(p.dbg & 1)) big_epilogue8<EPI>(p, m, n_lane, a0, a1, b0, b1, ext[item]);
+          if (m < p.M && n_ok && !(DL_DBG(p) & 1)) big_epilogue8<EPI>(p, m, n_lane, a0, a1, b0, b1, ext[item]);
         }
         wave_sync();
       }

@@ -203,18 +203,13 @@ class MLP(nn.Module):
     compute_dtype = torch.float32
 
     def forward(self, x):
-        if x.is_cuda:
-            # HIP path: GELU in the GEMM epilogue, BatchNorm1d by the dl_bn_* kernels (fp32 statistics, running
-            # statistics updated in the finalize kernel).  On (256, <=1024) inputs the torch layers are ~40 small
-            # launches of 8-20 us each; these are ~30 of 3-5 us.
-            x = Fn.cast(x, self.compute_dtype)
-            for fc, bn in ((self.fc1, self.bn1), (self.fc2, self.bn2), (self.fc3, self.bn3)):
-                x = Fn.batch_norm_rows(bn, Fn.dense(x, fc.weight, fc.bias, act=True))
-            return Fn.dense(x, self.fc4.weight, self.fc4.bias)[:, :self.fc4.out_features]
-        x = self.bn1(F.gelu(self.fc1(x)))
-        x = self.bn2(F.gelu(self.fc2(x)))
-        x = self.bn3(F.gelu(self.fc3(x)))
-        return self.fc4(x)
+        # HIP path only (ops._need_gpu rejects host tensors): GELU in the GEMM epilogue, BatchNorm1d by the dl_bn_*
+        # kernels (fp32 statistics, running statistics updated in the finalize kernel).  On (256, <=1024) inputs the
+        # torch layers are ~40 small launches of 8-20 us each; these are ~30 of 3-5 us.
+        x = Fn.cast(x, self.compute_dtype)
+        for fc, bn in ((self.fc1, self.bn1), (self.fc2, self.bn2), (self.fc3, self.bn3)):
+            x = Fn.batch_norm_rows(bn, Fn.dense(x, fc.weight, fc.bias, act=True))
+        return Fn.dense(x, self.fc4.weight, self.fc4.bias)[:, :self.fc4.out_features]
 
 
 class DrugLAMPBase(nn.Module):

@@ -135,12 +135,16 @@ class SSL(nn.Module):
                 return Fn.dense(h, lin.weight, lin.bias)[..., :n_cls]
             return lin(h[..., :lin.in_features])
 
+        def ce(lg):
+            # the reference's F.cross_entropy(logits.transpose(1, 2), labels, ignore_index=0) (:93-99) = mean over the
+            # non-ignored tokens of the batch; taken here over the flattened (B*L, C) rows: same value, but torch's
+            # (B, C, L) form (nll_loss2d) sums with atomics and differs in the last bit from run to run
+            return F.cross_entropy(lg.float().reshape(-1, lg.shape[-1]), labels.reshape(-1), ignore_index=pad_token_id)
+
         if mode != "xp":
-            logits = head(self.to_logits, extractor(masked_seq, fill_bit))
-            loss = loss + F.cross_entropy(logits.float().transpose(1, 2), labels, ignore_index=pad_token_id)
+            loss = loss + ce(head(self.to_logits, extractor(masked_seq, fill_bit)))
         if mode != "vp":
-            llm_logits = head(self.llm_to_logits, xp)
-            loss = loss + F.cross_entropy(llm_logits.float().transpose(1, 2), labels, ignore_index=pad_token_id)
+            loss = loss + ce(head(self.llm_to_logits, xp))
         return loss / 2 if mode == "double" else loss
 
     def forward(self, vp, xp, fill_bit_p, vd, xd, p_mode="double", mask=None, replace=None):

@@ -72,7 +72,7 @@ _ws2 = _Workspace()  # second buffer so that two scratch users can be live insid
 def gemm(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_kslow=False, w_kslow=False,
          ldx: Optional[int] = None, ldw: Optional[int] = None, bias=None, residual=None, res_row_mod=0,
          res_before_dropout=False, act=0, pre_out=None, dact_pre=None, dropout_p=0.0, seed=0, out=None,
-         out_dtype=None, accumulate=False, split_k=-1, x_colsum=None) -> torch.Tensor:
+         out_dtype=None, accumulate=False, split_k=-1, x_colsum=None, algo=0) -> torch.Tensor:
     """C[M,N] = epilogue(sum_k X[m,k] W[n,k]); see include/druglamp_hip.h (dl_gemm)."""
     _need_gpu(x, w)
     L = _lib.lib()
@@ -102,6 +102,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_kslow=Fa
     a.accumulate = int(accumulate)
     a.split_k = split_k
     a.x_colsum = _ptr(x_colsum)
+    a.dropout_seed_offset = _seed_offset_ptr(x.device) if dropout_p > 0 else None
+    a.algo = algo
     nbytes = L.dl_gemm_workspace_bytes(C.byref(a))
     if nbytes:
         ws = _ws.get(nbytes, x.device)
@@ -165,7 +167,7 @@ def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 def attn_fwd(q, k, v, *, n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, scale,
-             q_strides, k_strides, v_strides, out, o_strides, o_ss, need_lse=True, raw_logits=None):
+             q_strides, k_strides, v_strides, out, o_strides, o_ss, need_lse=True, raw_logits=None, algo=0):
     """Strides are (problem, head, row) in elements.  Returns the LSE tensor (or None)."""
     _need_gpu(q, k, v, out)
     a = AttnFwdArgs()
@@ -183,13 +185,14 @@ def attn_fwd(q, k, v, *, n_problems, n_heads, n_segments, partner_shift, Lq, Lk,
     a.n_problems, a.n_heads, a.n_segments, a.partner_shift = n_problems, n_heads, n_segments, partner_shift
     a.Lq, a.Lk, a.head_dim, a.dtype = Lq, Lk, head_dim, _dt(q)
     a.scale = float(scale)
+    a.algo = algo
     check(_lib.lib().dl_attn_fwd(C.byref(a), _stream()), "dl_attn_fwd")
     return lse
 
 
 def attn_bwd(q, k, v, o, do, lse, *, n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, scale,
              q_strides, k_strides, v_strides, o_strides, o_ss, do_strides, do_ss, dq, dq_strides, dk, dk_strides,
-             dv, dv_strides):
+             dv, dv_strides, algo=0):
     _need_gpu(q, k, v, o, do)
     a = AttnBwdArgs()
     delta = torch.empty_like(lse)
@@ -209,6 +212,7 @@ def attn_bwd(q, k, v, o, do, lse, *, n_problems, n_heads, n_segments, partner_sh
     a.n_problems, a.n_heads, a.n_segments, a.partner_shift = n_problems, n_heads, n_segments, partner_shift
     a.Lq, a.Lk, a.head_dim, a.dtype = Lq, Lk, head_dim, _dt(q)
     a.scale = float(scale)
+    a.algo = algo
     check(_lib.lib().dl_attn_bwd(C.byref(a), _stream()), "dl_attn_bwd")
 
 
@@ -216,7 +220,7 @@ def dropout_apply(x2d: torch.Tensor, p: float, seed: int) -> torch.Tensor:
     y = torch.empty_like(x2d)
     rows, D = x2d.shape
     check(_lib.lib().dl_dropout_apply(x2d.data_ptr(), y.data_ptr(), rows, D, x2d.stride(0), y.stride(0), float(p),
-                                      int(seed), _dt(x2d), _stream()), "dl_dropout_apply")
+                                      int(seed), _seed_offset_ptr(x2d.device), _dt(x2d), _stream()), "dl_dropout_apply")
     return y
 
 
@@ -229,6 +233,32 @@ _seed_gen.manual_seed(0x5EED)
 
 def manual_seed(seed: int) -> None:
     _seed_gen.manual_seed(int(seed))
+
+
+# Device-resident seed offset (one uint64 per device): every dropout site keys its mask by (site seed + offset), the
+# kernels read the offset when they RUN.  Eager steps leave it at 0; a hipGraph-captured step (trainer.GraphedStep)
+# bumps it with an in-graph add so that each replay of the frozen launch arguments still draws fresh masks.
+_seed_offsets = {}
+_seed_offset_on = False
+
+
+def seed_offset_tensor(device) -> torch.Tensor:
+    key = (device.type, device.index)
+    t = _seed_offsets.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64, device=device)
+        _seed_offsets[key] = t
+    return t
+
+
+def use_seed_offset(on: bool) -> None:
+    """Route dropout sites through the device-resident offset (needed while capturing / replaying a graphed step)."""
+    global _seed_offset_on
+    _seed_offset_on = bool(on)
+
+
+def _seed_offset_ptr(device):
+    return seed_offset_tensor(device).data_ptr() if _seed_offset_on else None
 
 
 def next_seed() -> int:
@@ -247,7 +277,8 @@ def add_rowmod_dropout(x2d: torch.Tensor, pe2d: Optional[torch.Tensor], p: float
     y = torch.empty_like(x2d)
     Lr = pe2d.shape[0] if pe2d is not None else 1
     check(_lib.lib().dl_add_rowmod_dropout(x2d.data_ptr(), _ptr(pe2d), y.data_ptr(), M, D, Lr, float(p), int(seed),
-                                           _dt(x2d), _stream()), "dl_add_rowmod_dropout")
+                                           _seed_offset_ptr(x2d.device) if p > 0 else None, _dt(x2d), _stream()),
+          "dl_add_rowmod_dropout")
     return y
 
 

@@ -227,11 +227,79 @@ class FusedAdamW:
             self.steps[i] += 1
 
 
+class GraphedStep:
+    """The cls-only part of a training step — forward, BCE, backward, gradient packing — captured ONCE per batch shape
+    into a hipGraph (torch.cuda.CUDAGraph drives hipStreamBeginCapture on a side stream; every libdruglamp_hip launch
+    goes to torch's current stream, so the whole launch sequence — ~260 library launches + ~100 torch launches — lands
+    in the graph) and replayed with one host call per step.  At 32-64 pairs per GPU the eager step is bound by the
+    7-9 ms the host needs to enqueue it; the replay costs the host < 1 ms.
+
+    What stays outside the graph, on purpose: the gradient all-reduce (RCCL) and the fused AdamW launches (their step
+    counts and learning rates are by-value arguments that change from step to step).
+    What makes a replay a NEW step although every launch argument is frozen:
+      * inputs are copied into the graph's static input tensors (skipped when the caller hands over those very
+        tensors, Trainer.static_batch — a loader can assemble the next batch in place);
+      * dropout masks are keyed by (site seed + *device offset*): the first node of the graph bumps the offset
+        (ops.seed_offset_tensor), forward and backward of one replay read the same value;
+      * the weight images are refreshed from the fp32 masters by the dl_weight_prep launch at the head of the graph;
+      * BatchNorm running statistics are updated by the in-graph dl_bn_finalize launches."""
+
+    def __init__(self, trainer: "Trainer", batch):
+        """Capture only records (nothing executes): the caller has already run eager steps of this shape, so lazy
+        allocations, weight-image tables and workspaces exist, and the parameter epoch is stale (the previous step's
+        AdamW bumped it), which puts the weight-image refresh at the head of the captured forward."""
+        self.tr = trainer
+        dev = trainer.device
+        self.static = self._clone(batch)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.out, self.idx = self._body()
+        self.replays = 0
+
+    @staticmethod
+    def _clone(batch):
+        return tuple(tuple(t.clone() for t in b) if isinstance(b, (tuple, list)) else b.clone() for b in batch)
+
+    def _is_static(self, batch) -> bool:
+        flat = lambda bt: [t for b in bt for t in (b if isinstance(b, (tuple, list)) else (b,))]   # noqa: E731
+        return all(a is b for a, b in zip(flat(batch), flat(self.static)))
+
+    @staticmethod
+    def signature(batch):
+        return tuple(tuple((tuple(t.shape), t.dtype) for t in b) if isinstance(b, (tuple, list)) else (tuple(b.shape), b.dtype)
+                     for b in batch)
+
+    def _body(self):
+        tr, m = self.tr, self.tr.model
+        ops.seed_offset_tensor(tr.device).add_(1)
+        feat_d, feat_p, labels, llm_d, llm_p = self.static
+        _, _, _, _, score = m(feat_d, feat_p, llm_d, llm_p)
+        tr._zero_grad()
+        _, cls_loss = binary_cross_entropy(score, labels) if tr.n_class == 1 else cross_entropy_logits(score, labels)
+        cls_loss.backward()
+        return {"cls": cls_loss.detach()}, tr.flat.pack_grads()
+
+    def run(self, batch):
+        if not self._is_static(batch):                  # copy into the static inputs (device-to-device)
+            for dst, src in zip(self.static, batch):
+                if isinstance(dst, tuple):
+                    for d, s_ in zip(dst, src):
+                        d.copy_(s_)
+                else:
+                    dst.copy_(src)
+        self.graph.replay()
+        self.replays += 1
+        return self.out, self.idx
+
+
 class Trainer:
-    """ExpModule restated (trainer.py:39-292).  `cfg` is the merged config tree."""
+    """ExpModule restated (trainer.py:39-292).  `cfg` is the merged config tree.
+    graph_steps=True: cls-only steps run as hipGraph replays (GraphedStep); SSL / CM steps and the first step of every
+    new batch shape stay eager."""
     overlap = None
 
-    def __init__(self, model, cfg, device=None, compute_dtype=torch.float32):
+    def __init__(self, model, cfg, device=None, compute_dtype=torch.float32, graph_steps: bool = False):
         self.model = model
         self.cfg = cfg
         self.device = device or next(model.parameters()).device
@@ -273,6 +341,13 @@ class Trainer:
         ov = os.environ.get("DL_GRAD_OVERLAP", "0")
         grouped = dist.is_available() and dist.is_initialized()
         self.overlap = GradOverlap(self.flat) if (self.world > 1 and ov not in ("0", "")) or (ov == "force" and grouped) else None
+        # hook-driven collectives cannot be launched from inside a graph replay: graphed steps reduce after the replay
+        self.graph_steps = bool(graph_steps) and self.overlap is None
+        self._graphs: Dict[tuple, GraphedStep] = {}
+        self._eager_seen: Dict[tuple, int] = {}
+        self.graph_warmup = 2            # eager (real) steps of a batch shape before its graph is captured
+        if self.graph_steps:
+            ops.use_seed_offset(True)    # one dropout-seed regime for eager and replayed steps
 
     # -- helpers ------------------------------------------------------------------------------------
     def _zero_grad(self):
@@ -309,6 +384,11 @@ class Trainer:
             m.train()                  # (walks every submodule: 0.7 ms per call)
         compute_ssl = self.use_ssl and (cur_epoch % self.ssl_epoch_step == 0)
         compute_cm = self.use_cm and (cur_epoch >= self.cm_init_epoch)
+        if self.graph_steps and not compute_ssl and not compute_cm and not self.run_dead_backward:
+            sig = GraphedStep.signature(batch)
+            if sig in self._graphs or self._eager_seen.get(sig, 0) >= self.graph_warmup:
+                return self._graphed_step(batch, sig)
+            self._eager_seen[sig] = self._eager_seen.get(sig, 0) + 1
         feat_d, feat_p, labels, llm_d, llm_p = batch
         _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p)
         self._zero_grad()
@@ -354,6 +434,24 @@ class Trainer:
             self.opt_cm.step(idx, scale)
         Fn.bump_param_epoch()
         return out
+
+    def _graphed_step(self, batch, sig) -> Dict[str, float]:
+        g = self._graphs.get(sig)
+        if g is None:
+            g = self._graphs[sig] = GraphedStep(self, batch)     # records only; the replay below is the step
+        out, idx = g.run(batch)
+        if self.world > 1 and idx:
+            for s, e, _ in self.flat.runs(idx, lambda i: 0):
+                dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM)
+        self.opt.step(idx, 1.0 / self.world)
+        Fn.bump_param_epoch()
+        return out
+
+    def static_batch(self, batch):
+        """The captured graph's own input tensors for batches of this shape (or `batch` itself while no graph exists):
+        a producer that fills them in place — and passes them back — saves the per-step input copy."""
+        g = self._graphs.get(GraphedStep.signature(batch))
+        return batch if g is None else g.static
 
     def on_train_epoch_end(self, cur_epoch: int):
         compute_ssl = self.use_ssl and (cur_epoch % self.ssl_epoch_step == 0)

@@ -81,7 +81,12 @@ typedef struct {
                                         x_colsum[m] = sum_k X[k][m], m < M (the bias gradient that accompanies
                                         dW = dY^T x, reference nn.Linear backward) from the X fragments the kernel
                                         streams anyway; fp32 [M] or NULL.  Counted in dl_gemm_workspace_bytes. */
+  const uint64_t* dropout_seed_offset; /* DEVICE pointer or NULL: the mask is keyed by dropout_seed + *offset, read when
+                                        the kernel runs — lets a hipGraph-captured step draw fresh masks per replay */
+  int32_t algo;                      /* DL_GEMM_ALGO_AUTO, or DL_GEMM_ALGO_TILE128: never take the 256-wide persistent
+                                        kernels (gemm_big.cuh) — outputs are bit-identical either way (tested) */
 } dl_gemm_args;
+enum { DL_GEMM_ALGO_AUTO = 0, DL_GEMM_ALGO_TILE128 = 1 };
 
 size_t dl_gemm_workspace_bytes(const dl_gemm_args* a);
 int dl_gemm(const dl_gemm_args* a, dl_stream s);
@@ -170,7 +175,10 @@ typedef struct {
   int64_t q_ps, q_hs, q_rs, k_ps, k_hs, k_rs, v_ps, v_hs, v_rs, o_ps, o_hs, o_rs, o_ss;
   int32_t n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, dtype;
   float scale;
+  int32_t algo;   /* DL_ATTN_ALGO_AUTO, or DL_ATTN_ALGO_STREAM: key tiles streamed through LDS whatever the lengths
+                     (the form every long sequence takes; AUTO keeps K/V LDS-resident when Lk <= 256 at head_dim 64) */
 } dl_attn_fwd_args;
+enum { DL_ATTN_ALGO_AUTO = 0, DL_ATTN_ALGO_STREAM = 1 };
 int dl_attn_fwd(const dl_attn_fwd_args* a, dl_stream s);
 
 /* Backward.  dO is addressed like O (do_* strides); Delta has the shape of LSE and is scratch
@@ -186,6 +194,7 @@ typedef struct {
   int64_t do_ps, do_hs, do_rs, do_ss, dq_ps, dq_hs, dq_rs, dk_ps, dk_hs, dk_rs, dv_ps, dv_hs, dv_rs;
   int32_t n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, dtype;
   float scale;
+  int32_t algo;   /* as in dl_attn_fwd_args */
 } dl_attn_bwd_args;
 int dl_attn_bwd(const dl_attn_bwd_args* a, dl_stream s);
 
@@ -225,10 +234,11 @@ int dl_concat2(void* a, void* b, void* cat, int64_t R, int64_t a_row_bytes, int6
  * ------------------------------------------------------------------------------------------ */
 /* y = dropout(x + pe[row % L]) — Embeddings.forward prot branch (model/PMMA/embed.py:51-52). */
 int dl_add_rowmod_dropout(const void* x, const void* pe, void* y, int64_t M, int64_t D,
-                          int64_t L, float p, uint64_t seed, int32_t dtype, dl_stream s);
-/* y = dropout_mask(seed)(x) / (1-p) — regenerates a forward mask for the backward pass. */
+                          int64_t L, float p, uint64_t seed, const uint64_t* seed_offset, int32_t dtype, dl_stream s);
+/* y = dropout_mask(seed)(x) / (1-p) — regenerates a forward mask for the backward pass.
+ * seed_offset (here and above): DEVICE pointer or NULL, see dl_gemm_args.dropout_seed_offset. */
 int dl_dropout_apply(const void* x, void* y, int64_t n_rows, int64_t D, int64_t ldx, int64_t ldy,
-                     float p, uint64_t seed, int32_t dtype, dl_stream s);
+                     float p, uint64_t seed, const uint64_t* seed_offset, int32_t dtype, dl_stream s);
 /* LLM feature ingest (input side of the path): ONE pass over the pre-extracted embedding tensor
  * x [B][S][F] produces the reference's fill bit (1 where the embedding row sums to exactly 0,
  * model/DrugLAMP.py:11-19) and the fill-bit-augmented, site-pooled features

@@ -300,8 +300,13 @@ def gen_train_steps():
 
     S.get_mask_subset_with_prob, S.prob_mask_like = subset, like
     torch.manual_seed(11)
-    rec = {"cls": [], "ssl": [], "cm": [], "cm_weight": [], "delta": [], "pnorm": []}
+    rec = {"cls": [], "ssl": [], "cm": [], "cm_weight": [], "delta": [], "pnorm": [], "dsample": []}
     cm_weight = 1.0
+    n_total = sum(p.numel() for p in params)
+    # fixed sub-sample of the flattened parameter vector: the per-step UPDATE of these elements is stored so that a
+    # wrong update direction / wrong optimiser ordering is visible (a norm of the update is not: with AdamW from zero
+    # moments it is ~ lr * sqrt(N) whatever the gradient)
+    didx = (torch.arange(4096, dtype=torch.int64) * (n_total // 4096) + (torch.arange(4096, dtype=torch.int64) * 2654435761 % 97))
     names = [n for n, p in m.named_parameters()]
     for step, cur_epoch in enumerate([1, 5, 5, 6]):
         compute_ssl = cur_epoch % 5 == 0
@@ -338,10 +343,12 @@ def gen_train_steps():
         rec["cls"].append(cls_loss.item()); rec["ssl"].append(ssl_v); rec["cm"].append(cm_v)
         rec["cm_weight"].append(cm_weight)
         rec["delta"].append((after - before).norm().item()); rec["pnorm"].append(after.norm().item())
+        rec["dsample"].append((after - before)[didx].numpy())
     S.get_mask_subset_with_prob, S.prob_mask_like = real_subset, real_like
     save("train_steps", sd=sd_spec(m), cls=np.asarray(rec["cls"]), ssl=np.asarray(rec["ssl"]), cm=np.asarray(rec["cm"]),
          cm_weight=np.asarray(rec["cm_weight"]), delta=np.asarray(rec["delta"]), pnorm=np.asarray(rec["pnorm"]),
-         masks=np.stack(masks["mask"]), replaces=np.stack(masks["replace"]))
+         masks=np.stack(masks["mask"]), replaces=np.stack(masks["replace"]),
+         didx=didx.numpy(), dsample=np.stack(rec["dsample"]), n_total=np.int64(n_total))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,104 @@
+"""hipGraph-replayed training steps (trainer.GraphedStep) against the eager step.
+
+The graph holds forward + BCE + backward + gradient packing of a cls step (reference step: trainer.py:196-200,225);
+all-reduce and AdamW stay eager.  Checked here:
+  * with dropout off, N graphed steps leave the parameter arena, the AdamW moments, the BatchNorm running statistics
+    and the losses BIT-IDENTICAL to N eager steps (same kernels, same order, same arguments);
+  * a different batch passed to a captured graph is copied into its static inputs (result == eager on that batch);
+  * with dropout on, every replay draws fresh masks (device-side seed offset) although the launch arguments are frozen,
+    and a replay's forward and backward agree on the masks (finite-difference-free check: with lr = 0 two replays give
+    different losses; with the offset frozen they give identical ones).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _make(p_drop, graph, seed=4321, kind="DrugLAMP"):
+    from druglamp_amd import ops
+    from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
+    from druglamp_amd.model import MInterface
+    from druglamp_amd.trainer import Trainer
+    torch.manual_seed(seed)
+    ops.manual_seed(77)
+    ops.seed_offset_tensor(DEV).zero_()
+    cfg = load_yaml_into(get_cfg_defaults(), kind)
+    model = MInterface(kind, cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(DEV)
+    model.pmma.p_drop = p_drop
+    model.pmma.embeddings.p_drop = p_drop
+    tr = Trainer(model, cfg, device=DEV, compute_dtype=torch.bfloat16, graph_steps=graph)
+    tr.set_lrs(1e-3, 1e-3, 1e-3)
+    return tr
+
+
+def _state(tr):
+    bufs = torch.cat([b.detach().float().flatten() for b in tr.model.buffers()])
+    return tr.flat.arena.clone(), tr.opt.exp_avg.clone(), tr.opt.exp_avg_sq.clone(), bufs
+
+
+def test_graphed_steps_are_bit_identical_to_eager_steps_without_dropout():
+    from druglamp_amd import ops
+    from druglamp_amd.synthetic import make_batch
+    batch, meta = make_batch(8, DEV, seed=7, with_graph=True, llm_dtype=torch.bfloat16)
+    other, meta2 = make_batch(8, DEV, seed=8, with_graph=True, llm_dtype=torch.bfloat16)
+    seq = [batch, batch, batch, batch, other, batch]          # steps 3.. are replays; step 5 brings new data
+    res = {}
+    try:
+        for graph in (False, True):
+            tr = _make(0.0, graph)
+            losses = [float(tr.training_step(b, meta=meta, cur_epoch=1)["cls"]) for b in seq]
+            if graph:
+                assert len(tr._graphs) == 1 and next(iter(tr._graphs.values())).replays == len(seq) - tr.graph_warmup
+            res[graph] = (losses, _state(tr))
+    finally:
+        ops.use_seed_offset(False)
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    for a, b in zip(res[False][1], res[True][1]):
+        assert torch.equal(a, b)
+
+
+def test_graph_replays_draw_fresh_dropout_masks():
+    from druglamp_amd import ops
+    from druglamp_amd.synthetic import make_batch
+    batch, meta = make_batch(8, DEV, seed=7, with_graph=True, llm_dtype=torch.bfloat16)
+    try:
+        tr = _make(0.1, True)
+        tr.set_lrs(0.0, 0.0, 0.0)                  # parameters frozen: only the masks can change the loss
+        tr.opt.wd = 0.0
+        for _ in range(tr.graph_warmup):
+            tr.training_step(batch, meta=meta, cur_epoch=1)
+        a = float(tr.training_step(batch, meta=meta, cur_epoch=1)["cls"])       # capture + first replay
+        b = float(tr.training_step(batch, meta=meta, cur_epoch=1)["cls"])
+        assert a != b, "two replays produced the same loss: the dropout masks did not change"
+        g = next(iter(tr._graphs.values()))
+        off = ops.seed_offset_tensor(DEV)
+        # same offset -> same masks -> same loss and the same gradients (forward / backward mask agreement is what
+        # makes the packed gradient reproducible)
+        off.fill_(41)
+        g.graph.replay()
+        l1, g1 = float(g.out["cls"]), tr.flat.grads.clone()
+        off.fill_(41)
+        g.graph.replay()
+        l2, g2 = float(g.out["cls"]), tr.flat.grads.clone()
+        assert l1 == l2 and torch.equal(g1, g2)
+        assert int(off) == 42
+    finally:
+        ops.use_seed_offset(False)
+
+
+def test_ssl_and_cm_steps_stay_eager_when_graphs_are_on():
+    from druglamp_amd import ops
+    from druglamp_amd.synthetic import make_batch
+    batch, meta = make_batch(8, DEV, seed=7, with_graph=True, llm_dtype=torch.bfloat16)
+    try:
+        tr = _make(0.1, True, kind="DrugLAMP2C2P")
+        for ep in (1, 1, 1, 5, 1):
+            torch.manual_seed(50 + ep)
+            out = tr.training_step(batch, meta=meta, cur_epoch=ep)
+            assert all(torch.isfinite(v).all() for v in out.values())
+            assert ("cm" in out) == (ep >= tr.cm_init_epoch)
+        assert len(tr._graphs) == 1 and next(iter(tr._graphs.values())).replays == 2
+    finally:
+        ops.use_seed_offset(False)

@@ -55,7 +55,7 @@ def test_fill_pool_matches_reference_formulation(dtype, odt, site_len, S, F):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(49152, 512, 256), (49000, 520, 192)])
-def test_large_tile_gemm_is_bitwise_equal_to_the_128_tile_path(M, N, K, monkeypatch):
+def test_large_tile_gemm_is_bitwise_equal_to_the_128_tile_path(M, N, K):
     """The 256x256 persistent kernel (gemm_big.cuh) and gemm_kernel accumulate every output element in the same
     k order and share epilogue math and dropout counters: outputs must be identical bit for bit, for every
     specialised epilogue, including ragged M / N edges."""
@@ -76,8 +76,8 @@ def test_large_tile_gemm_is_bitwise_equal_to_the_128_tile_path(M, N, K, monkeypa
     for name, kw in cases.items():
         got = {}
         for mode in ("0", "1"):
-            monkeypatch.setenv("DL_GEMM_BIG", mode)
-            k2 = dict(kw)
+            k2 = dict(kw, algo=1 if mode == "0" else 0)       # DL_GEMM_ALGO_TILE128 / AUTO (an explicit argument)
+
             pre = None
             if k2.get("pre_out"):
                 pre = torch.zeros(M, N, device="cuda", dtype=dt)
@@ -91,14 +91,13 @@ def test_large_tile_gemm_is_bitwise_equal_to_the_128_tile_path(M, N, K, monkeypa
             assert torch.equal(got["0"][1], got["1"][1]), name
     # and against an fp64 reference for the plain case
     ref = x[:512].double() @ w.double().t()
-    monkeypatch.setenv("DL_GEMM_BIG", "1")
     out = ops.gemm(x, w, M=M, N=N, K=K)
     assert (out[:512].double() - ref).abs().max() <= 2e-2 * ref.abs().max()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(1536, 512, 16384), (128, 768, 262147), (1280, 520, 9000)])
-def test_large_tile_weight_gradient_matches_fp64_and_the_128_tile_path(M, N, K, monkeypatch):
+def test_large_tile_weight_gradient_matches_fp64_and_the_128_tile_path(M, N, K):
     """gemm_big_tt_kernel (both operands K-slow, split-K slabs, zero-page K tail) against an fp64 reference on a
     row sample and against the 128-tile split-K path (different slab count -> fp32 summation order only)."""
     from druglamp_amd import ops
@@ -108,9 +107,8 @@ def test_large_tile_weight_gradient_matches_fp64_and_the_128_tile_path(M, N, K, 
     x = (torch.randn(K, N, generator=g) * 0.5).to(dt).cuda()
     outs = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("DL_GEMM_BIG", mode)
         outs[mode] = ops.gemm(dy, x, M=M, N=N, K=K, x_kslow=True, w_kslow=True, ldx=M, ldw=N,
-                              out_dtype=torch.float32, split_k=0).clone()
+                              out_dtype=torch.float32, split_k=0, algo=1 if mode == "0" else 0).clone()
         torch.cuda.synchronize()
     ref = dy[:, :96].double().t() @ x.double()
     scale = ref.abs().max()

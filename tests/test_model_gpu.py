@@ -119,6 +119,9 @@ def test_ssl_cm_losses():
         assert abs(got - n_ref) <= 5e-3 * n_ref + 1e-5 * scale, ("cm", k, got, n_ref)
 
 
+from tests.test_oracle_train import check_update_sample  # noqa: E402
+
+
 def test_training_step_sequence():
     """trainer.Trainer (flat arena, fused AdamW runs) against the reference-driven sequence."""
     from druglamp_amd.trainer import Trainer
@@ -157,6 +160,9 @@ def test_training_step_sequence():
         assert tr.cm_weight == g["cm_weight"][step]
         delta = float((after - before).norm())
         assert abs(delta - g["delta"][step]) <= 3e-2 * g["delta"][step], (step, delta, g["delta"][step])
+        # the update itself, element by element on the golden's fixed sub-sample (direction + magnitudes): a norm alone
+        # would pass with a wrong update direction (AdamW from zero moments moves every element by ~lr)
+        check_update_sample(after - before, g, step, cos_min=0.999, frac_min=0.99)
         before = after
 
 

@@ -11,6 +11,18 @@ def _unpack(bits, shape):
     return torch.from_numpy(np.unpackbits(bits)[:int(np.prod(shape))].reshape(shape).astype(bool))
 
 
+def check_update_sample(update, g, step, cos_min, frac_min, tol=2e-2):
+    """The per-step parameter UPDATE on the golden's fixed 4096-element sub-sample: direction (cosine) and the share
+    of elements within `tol` of the largest reference update (AdamW updates are ~lr in magnitude; the few elements
+    whose gradient is ~eps flip sign with rounding and are what the share allows for)."""
+    assert update.numel() == int(g["n_total"]), (update.numel(), int(g["n_total"]))
+    got = update.double().cpu()[torch.from_numpy(g["didx"])]
+    ref = torch.from_numpy(g["dsample"][step]).double()
+    cos = float((got * ref).sum() / (got.norm() * ref.norm() + 1e-300))
+    frac = float(((got - ref).abs() <= tol * ref.abs().max()).double().mean())
+    assert cos >= cos_min and frac >= frac_min, (step, cos, frac)
+
+
 def test_training_step_sequence():
     g = load("train_steps")
     sd = det_state_dict(g)
@@ -37,4 +49,5 @@ def test_training_step_sequence():
         assert rec["cm_weight"] == g["cm_weight"][step]
         delta = float((after - before).norm())
         assert abs(delta - g["delta"][step]) <= 2e-2 * g["delta"][step], (step, delta, g["delta"][step])
+        check_update_sample(after - before, g, step, cos_min=0.9999, frac_min=0.995)
         before = after

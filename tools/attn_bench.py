@@ -1,4 +1,4 @@
-"""Attention kernels at the path's three shapes: resident vs streaming forms (DL_ATTN_RES) — time + max diff."""
+"""Attention kernels at the path's three shapes: resident vs streaming forms (algo argument of dl_attn_fwd / dl_attn_bwd) — time + max diff."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from druglamp_amd import ops
@@ -20,17 +20,17 @@ for name, P, H, S, shift, Lq, Lk, hd in cases:
     do = (torch.randn(S, P * Lq, d, device=dev) * 0.1).to(dt)
     res = {}
     for mode in ("0", "1"):
-        os.environ["DL_ATTN_RES"] = mode
+        algo = 1 if mode == "0" else 0          # DL_ATTN_ALGO_STREAM / AUTO
         o = torch.zeros(S, P * Lq, d, device=dev, dtype=dt)
         f = lambda: ops.attn_fwd(q, k, v, n_problems=P, n_heads=H, n_segments=S, partner_shift=shift, Lq=Lq, Lk=Lk, head_dim=hd,
-                                 scale=hd ** -0.5, q_strides=qs, k_strides=ks, v_strides=ks, out=o, o_strides=(Lq * d, hd, d), o_ss=P * Lq * d)
+                                 scale=hd ** -0.5, q_strides=qs, k_strides=ks, v_strides=ks, out=o, o_strides=(Lq * d, hd, d), o_ss=P * Lq * d, algo=algo)
         lse = f(); torch.cuda.synchronize()
         tf = timeit(f)
         dq = torch.zeros(P * Lq, d, device=dev, dtype=dt); dk = torch.zeros(P * Lk, d, device=dev, dtype=dt); dv = torch.zeros_like(dk)
         fb = lambda: ops.attn_bwd(q, k, v, o, do, lse, n_problems=P, n_heads=H, n_segments=S, partner_shift=shift, Lq=Lq, Lk=Lk, head_dim=hd,
                                   scale=hd ** -0.5, q_strides=qs, k_strides=ks, v_strides=ks, o_strides=(Lq * d, hd, d), o_ss=P * Lq * d,
                                   do_strides=(Lq * d, hd, d), do_ss=P * Lq * d, dq=dq, dq_strides=(Lq * d, hd, d), dk=dk,
-                                  dk_strides=(Lk * d, hd, d), dv=dv, dv_strides=(Lk * d, hd, d))
+                                  dk_strides=(Lk * d, hd, d), dv=dv, dv_strides=(Lk * d, hd, d), algo=algo)
         fb(); torch.cuda.synchronize()
         tb = timeit(fb)
         res[mode] = (o.clone(), lse.clone(), dq.clone(), dk.clone(), dv.clone(), tf, tb)

@@ -26,8 +26,7 @@ for (M, N, K) in shapes:
     for name, kw in cases.items():
         outs, ts = {}, {}
         for mode in ("0", "1"):
-            os.environ["DL_GEMM_BIG"] = mode
-            k2 = dict(kw)
+            k2 = dict(kw, algo=1 if mode == "0" else 0)
             pre = None
             if k2.get("pre_out"):
                 pre = torch.zeros(M, N, device=dev, dtype=dt); k2["pre_out"] = pre

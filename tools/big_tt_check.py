@@ -15,8 +15,8 @@ for (M, N, K) in shapes:
     dy = (torch.randn(K, M, device=dev) * 0.5).to(dt); x = (torch.randn(K, N, device=dev) * 0.5).to(dt)
     outs, ts = {}, {}
     for mode in ("0", "1"):
-        os.environ["DL_GEMM_BIG"] = mode
-        f = lambda: ops.gemm(dy, x, M=M, N=N, K=K, x_kslow=True, w_kslow=True, ldx=M, ldw=N, out_dtype=torch.float32, split_k=0)
+        f = lambda mode=mode: ops.gemm(dy, x, M=M, N=N, K=K, x_kslow=True, w_kslow=True, ldx=M, ldw=N, out_dtype=torch.float32, split_k=0,
+                                       algo=1 if mode == "0" else 0)
         outs[mode] = f().clone(); torch.cuda.synchronize()
         ts[mode] = timeit(f)
     ref = dy[:, :64].double().t() @ x.double()
