@@ -63,8 +63,11 @@ def get_cfg_defaults() -> CfgNode:
     return c
 
 
-def get_lamp_config(hidden_size: int) -> CfgNode:
-    """PMMA hyper-parameters (default_config.py:67-84)."""
+def get_lamp_config(hidden_size: int, feat_len: int = 256) -> CfgNode:
+    """PMMA hyper-parameters (default_config.py:67-84).  `feat_len` (the number of protein sites, = the length of
+    both PMMA streams and of the positional tables, embed.py:32-33) is hard-coded to 256 in the reference; here it
+    follows PROTEIN.SEQ_LEN // PROTEIN.SITE_LEN (default 2304 // 9 = 256) so that long-protein configurations
+    (BASELINE config 5: SEQ_LEN = 9216 -> 1024 sites) are a yaml change."""
     c = CN()
     c.n_output = 1
     c.hidden_size = hidden_size * 2
@@ -74,12 +77,12 @@ def get_lamp_config(hidden_size: int) -> CfgNode:
     c.classifier = "token"
     c.representation_size = None
     c.mol_len = 512
-    c.feat_len = 256
+    c.feat_len = int(feat_len)
     return c
 
 
-def get_model_defaults(hidden_size: int) -> CfgNode:
-    c = get_lamp_config(hidden_size)
+def get_model_defaults(hidden_size: int, feat_len: int = 256) -> CfgNode:
+    c = get_lamp_config(hidden_size, feat_len)
     c.mol_len = c.feat_len
     return c
 

@@ -226,7 +226,11 @@ class DrugLAMPBase(nn.Module):
                              drug_ssl_type="simsiam", n_hidden=n_hidden)
         self.cm_model = CrossModality(use_cm=True, hidden_size=n_hidden, max_margin=cfg["RS"]["MAX_MARGIN"],
                                       n_re=cfg["RS"]["RESET_EPOCH"], global_batch=bool(cfg["RS"].get("GLOBAL_BATCH", False)))
-        model_cfg = CONFIGS["LAMP"](n_hidden)
+        if self.seq_len_q % self.site_len:
+            raise ValueError("PROTEIN.SEQ_LEN (%d) must be a multiple of PROTEIN.SITE_LEN (%d)" % (self.seq_len_q, self.site_len))
+        # the reference hard-codes 256 sites in get_lamp_config (default_config.py:83) although every forward derives
+        # the site count from SEQ_LEN // SITE_LEN (DrugLAMP.py:35): here the PMMA tables follow the config
+        model_cfg = CONFIGS["LAMP"](n_hidden, feat_len=self.seq_len_q // self.site_len)
 
         self.lin_d1 = nn.Linear(n_drug_feature + 1, 2 * n_hidden)
         self.act_d = nn.GELU()

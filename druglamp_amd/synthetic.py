@@ -6,27 +6,29 @@ from __future__ import annotations
 import torch
 
 
-def make_batch(B: int, device, seed: int = 0, with_graph: bool = True, llm_dtype=torch.float32, adj_nodes: int = 128):
+def make_batch(B: int, device, seed: int = 0, with_graph: bool = True, llm_dtype=torch.float32, adj_nodes: int = 128,
+               seq_len: int = 2304, max_prot_len: int = 1022):
     """Returns (feat_d, feat_p, labels, llm_d, llm_p), meta.
     feat_d: (node_feats (B,512,75), adjacency (B,adj_nodes,adj_nodes)) dense batched graphs (real-atom block;
             nodes beyond it are self-looped virtual padding nodes) when with_graph, else pre-extracted GCN features (B,512,128);
-    feat_p: (B,2304) float64 residue codes tiled like repeat_integer_label_protein;
+    feat_p: (B,seq_len) float64 residue codes tiled like repeat_integer_label_protein (seq_len = PROTEIN.SEQ_LEN, 2304;
+            long-protein configurations use 9216 with max_prot_len 4094);
     llm_d : (B,512,384) ChemBERTa-shaped token embeddings, zero after the last token;
     llm_p : (B,2304,640) ESM-2-shaped embeddings of an (Lp+2)-token protein tiled to 2304, zero tail."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     n_atom = torch.randint(10, 81, (B,), generator=g)
     n_tok = torch.randint(12, 129, (B,), generator=g)
-    Lp = torch.randint(100, 1023, (B,), generator=g)
+    Lp = torch.randint(100, min(max_prot_len, seq_len - 2) + 1, (B,), generator=g)
     xd = torch.randn(B, 512, 384, generator=g)
-    xp = torch.zeros(B, 2304, 640)
-    vp = torch.zeros(B, 2304, dtype=torch.float64)
+    xp = torch.zeros(B, seq_len, 640)
+    vp = torch.zeros(B, seq_len, dtype=torch.float64)
     for b in range(B):
         xd[b, int(n_tok[b]):] = 0
         L = int(Lp[b])
         blk = torch.randn(L + 2, 640, generator=g)
         seq = torch.randint(1, 26, (L,), generator=g).double()
-        reps = 2304 // (L + 2)
+        reps = seq_len // (L + 2)
         for r in range(reps):
             xp[b, r * (L + 2):(r + 1) * (L + 2)] = blk
             vp[b, r * (L + 2) + 1:r * (L + 2) + 1 + L] = seq

@@ -12,22 +12,23 @@ import numpy as np
 from . import detgen
 
 
-def model_inputs(tag: str, B: int, salt: int = 0):
-    """Synthetic pre-extracted inputs with the padding structure of the real collate (utils.py:326-334)."""
+def model_inputs(tag: str, B: int, salt: int = 0, seq_len: int = 2304, lp_range=(100, 600)):
+    """Synthetic pre-extracted inputs with the padding structure of the real collate (utils.py:326-334).
+    seq_len = PROTEIN.SEQ_LEN (the reference hard-codes 9 * 256 in its collate, utils.py:333)."""
     rs = np.random.RandomState(1234 + salt)
     vd = detgen.normalish(tag + ".vd", (B, 512, 128), salt).copy()
     xd = detgen.normalish(tag + ".xd", (B, 512, 384), salt).copy()
-    xp = np.zeros((B, 2304, 640), dtype=np.float32)
-    vp = np.zeros((B, 2304), dtype=np.float64)
+    xp = np.zeros((B, seq_len, 640), dtype=np.float32)
+    vp = np.zeros((B, seq_len), dtype=np.float64)
     for b in range(B):
         n_atom = int(rs.randint(10, 80))
         vd[b, n_atom:] = 0
         n_tok = int(rs.randint(12, 128))
         xd[b, n_tok:] = 0
-        Lp = int(rs.randint(100, 600))
+        Lp = int(rs.randint(*lp_range))
         seq = rs.randint(1, 26, size=Lp).astype(np.float64)
         blk = detgen.normalish("%s.xp%d" % (tag, b), (Lp + 2, 640), salt)
-        reps = 2304 // (Lp + 2)
+        reps = seq_len // (Lp + 2)
         for r in range(reps):
             xp[b, r * (Lp + 2):(r + 1) * (Lp + 2)] = blk
             vp[b, r * (Lp + 2) + 1: r * (Lp + 2) + 1 + Lp] = seq

@@ -96,6 +96,45 @@ def gen_pmma():
         save(tag, **out)
 
 
+def gen_pmma_long():
+    """BASELINE config 5 (long proteins: 1024 sites).  The reference's PMMA accepts any feat_len (embed.py:32-33)."""
+    from model.PMMA import PairedMultimodelAttention
+    tag, L = "pmma_L1024", 1024
+    m = fill_module(PairedMultimodelAttention(pmma_config(L), vis=True)).eval()
+    prot = T(tag + ".prot", (2, L, 256)).requires_grad_(True)
+    mol = T(tag + ".mol", (2, L, 256)).requires_grad_(True)
+    enc, w, gw = m(prot, mol)
+    G = T(tag + ".G", tuple(enc.shape))
+    (enc * G).sum().backward()
+    save(tag, sd=sd_spec(m), gradnorm=grad_norms(m), w0=w[0][:, :, :4, :8], gw0=gw[0][:, :, :4, :8], w3=w[3][:, :, :4, :8],
+         gw1_tail=gw[1][:, :, -4:, -8:], encoded=sub(enc), dprot=sub(prot.grad), dmol=sub(mol.grad),
+         dW_l0_query=m.encoder.layer_with_mol[0].attn.query.weight.grad[:8, :16],
+         dW_l3_fc2=m.encoder.layer_with_mol[3].ffn.fc2.weight.grad[:8, :16],
+         dpe_mol=m.embeddings.pe_mol.grad[0, -4:, :16])
+
+
+def gen_model_long():
+    """Whole DrugLAMP at PROTEIN.SEQ_LEN = 9216 (1024 sites): eval score + train-mode BCE gradient norms."""
+    from model.basic_model import binary_cross_entropy
+    kind, S = "DrugLAMP", 9216
+    torch.manual_seed(0)
+    m = build_model(kind, seq_len=S)
+    fill_module(m)
+    vd, vp, xd, xp, y = model_inputs("modelL." + kind, 2, seq_len=S, lp_range=(1000, 4000))
+    m.eval()
+    with torch.no_grad():
+        vd_o, vp_o, ssl, cm, score = m(vd, vp, xd, xp)
+    out = dict(sd=sd_spec(m), score=score, vp=sub(vp_o), A_v=m.A_v_gca[:, :, :4, :8], A_x=m.A_x_gca[:, :, -4:, -8:])
+    vd, vp, xd, xp, y = model_inputs("modelLtrain." + kind, 4, seq_len=S, lp_range=(1000, 4000))
+    m.train()
+    m.zero_grad()
+    vd_o, vp_o, ssl, cm, score_t = m(vd, vp, xd, xp)
+    n, loss = binary_cross_entropy(score_t, y)
+    loss.backward()
+    out.update(score_train=score_t, cls_loss=loss, gradnorm=grad_norms(m))
+    save("model_L1024", **out)
+
+
 def gen_pgca():
     from model.PGCA.guided_cross_attention_model import GuidedCrossAttention
     m = fill_module(GuidedCrossAttention(embed_dim=128, num_heads=1)).eval()
@@ -172,15 +211,35 @@ class _PassThrough(torch.nn.Module):
         return x
 
 
-def model_inputs(tag, B, salt=0):
-    return tuple(torch.from_numpy(a) for a in synth.model_inputs(tag, B, salt))
+def model_inputs(tag, B, salt=0, **kw):
+    return tuple(torch.from_numpy(a) for a in synth.model_inputs(tag, B, salt, **kw))
 
 
-def build_model(kind):
+def build_model(kind, seq_len=2304):
     import importlib
     cfg = ref_harness.default_cfg()
     Model = getattr(importlib.import_module("model." + kind), kind)
-    m = Model(n_drug_feature=384, n_prot_feature=640, n_hidden=128, **cfg)
+    if seq_len != 2304:
+        # long-protein configuration (BASELINE config 5): every forward of the reference already derives the site count
+        # from PROTEIN.SEQ_LEN // SITE_LEN (DrugLAMP.py:35); only the PMMA table length is hard-coded
+        # (default_config.py:83 feat_len = 256).  The harness overrides that one number through the reference's own
+        # CONFIGS hook (basic_model.py:13-15,98) — the reference's modules run unmodified.
+        import model.basic_model as BM
+        from configs import get_model_defaults
+        cfg.PROTEIN.SEQ_LEN = seq_len
+
+        def lamp(hidden):
+            c = get_model_defaults(hidden)
+            c.feat_len = c.mol_len = seq_len // cfg.PROTEIN.SITE_LEN
+            return c
+        old = BM.CONFIGS["LAMP"]
+        BM.CONFIGS["LAMP"] = lamp
+        try:
+            m = Model(n_drug_feature=384, n_prot_feature=640, n_hidden=128, **cfg)
+        finally:
+            BM.CONFIGS["LAMP"] = old
+    else:
+        m = Model(n_drug_feature=384, n_prot_feature=640, n_hidden=128, **cfg)
     m.drug_extractor = _PassThrough()
     for mod in m.modules():
         if isinstance(mod, torch.nn.Dropout):
@@ -352,8 +411,8 @@ def gen_train_steps():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pmma", "pgca", "mhla", "losses", "models", "sslcm", "train"]
+    which = sys.argv[1:] or ["pmma", "pgca", "mhla", "losses", "models", "sslcm", "train", "pmma_long", "model_long"]
     table = dict(pmma=gen_pmma, pgca=gen_pgca, mhla=gen_mhla, losses=gen_losses, models=gen_models, sslcm=gen_ssl_cm,
-                 train=gen_train_steps)
+                 train=gen_train_steps, pmma_long=gen_pmma_long, model_long=gen_model_long)
     for w in which:
         table[w]()

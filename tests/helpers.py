@@ -34,8 +34,8 @@ def T(name, shape, scale=1.0, salt=0):
     return torch.from_numpy(detgen.normalish(name, shape, salt) * np.float32(scale))
 
 
-def model_inputs(tag, B, salt=0):
-    return tuple(torch.from_numpy(a) for a in synth.model_inputs(tag, B, salt))
+def model_inputs(tag, B, salt=0, **kw):
+    return tuple(torch.from_numpy(a) for a in synth.model_inputs(tag, B, salt, **kw))
 
 
 def relerr(a, b):

@@ -181,3 +181,57 @@ def test_collate_padding_restatement_matches_reference_functions():
     assert np.array_equal(collate.tail_pad(tail_in, ms), g["tail_out"])
     assert np.array_equal(collate.repeat_pad(rep_in, ms), g["rep_out"])
     assert not g["rep_out"][list(g["rep_lens"]).index(60)].any()
+
+
+# ---- BASELINE config 5: long proteins (PROTEIN.SEQ_LEN = 9216 -> 1024 sites) ---------------------------------------
+def test_pmma_long_forward_backward():
+    """PMMA at feat_len = mol_len = 1024 (reference embed.py:32-33 accepts any length) — the oracle pinned at the length
+    where K/V no longer fit LDS and the HIP path has to stream key tiles."""
+    g = load("pmma_L1024")
+    sd = det_state_dict(g)
+    for v in sd.values():
+        v.requires_grad_(True)
+    prot = T("pmma_L1024.prot", (2, 1024, 256)).requires_grad_(True)
+    mol = T("pmma_L1024.mol", (2, 1024, 256)).requires_grad_(True)
+    enc, maps = O.pmma_forward(sd, prot, mol, return_maps=True)
+    check_sub(enc, g, "encoded", TOL)
+    assert relerr(maps[0][0][:, :, :4, :8], g["w0"]) <= TOL
+    assert relerr(maps[0][1][:, :, :4, :8], g["gw0"]) <= TOL
+    assert relerr(maps[1][1][:, :, -4:, -8:], g["gw1_tail"]) <= TOL
+    assert relerr(maps[3][0][:, :, :4, :8], g["w3"]) <= TOL
+    (enc * T("pmma_L1024.G", tuple(enc.shape))).sum().backward()
+    check_sub(prot.grad, g, "dprot", TOL)
+    check_sub(mol.grad, g, "dmol", TOL)
+    assert relerr(sd["encoder.layer_with_mol.0.attn.query.weight"].grad[:8, :16], g["dW_l0_query"]) <= TOL
+    assert relerr(sd["encoder.layer_with_mol.3.ffn.fc2.weight"].grad[:8, :16], g["dW_l3_fc2"]) <= TOL
+    assert relerr(sd["embeddings.pe_mol"].grad[0, -4:, :16], g["dpe_mol"]) <= TOL
+    for k, n in gradnorms(g).items():
+        assert abs(float(sd[k].grad.double().norm()) - n) <= 1e-4 * max(n, 1e-6), k
+
+
+def test_model_long_forward_and_gradients():
+    """Whole DrugLAMP at SEQ_LEN = 9216 / 1024 sites against the reference run with the same config."""
+    g = load("model_L1024")
+    sd = det_state_dict(g)
+    S = 9216
+    vd, vp, xd, xp, y = model_inputs("modelL.DrugLAMP", 2, seq_len=S, lp_range=(1000, 4000))
+    with torch.no_grad():
+        out = O.model_forward(sd, "DrugLAMP", vd, vp, xd, xp, bn_training=False, seq_len=S)
+    assert relerr(out["score"], g["score"]) <= 1e-4
+    check_sub(out["vp"], g, "vp", 1e-4)
+    assert relerr(out["A_v"][:, :, :4, :8], g["A_v"]) <= 1e-4
+    assert relerr(out["A_x"][:, :, -4:, -8:], g["A_x"]) <= 1e-4
+    for k, v in sd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    vd, vp, xd, xp, y = model_inputs("modelLtrain.DrugLAMP", 4, seq_len=S, lp_range=(1000, 4000))
+    out = O.model_forward(sd, "DrugLAMP", vd, vp, xd, xp, bn_training=True, seq_len=S)
+    assert relerr(out["score"], g["score_train"]) <= 1e-3
+    n, loss = O.bce_loss(out["score"], y)
+    assert abs(float(loss) - float(g["cls_loss"])) <= 1e-4
+    loss.backward()
+    worst = 0.0
+    for k, n_ref in gradnorms(g).items():
+        got = float(sd[k].grad.double().norm()) if sd[k].grad is not None else 0.0
+        worst = max(worst, abs(got - n_ref) / max(n_ref, 1e-5))
+    assert worst <= 2e-3, worst
