@@ -44,7 +44,7 @@ struct AttnF8P {
 
 struct QuantP {
   const char* X; int64_t ps, hs, rs;      // bf16 source, element strides
-  uint8_t* X8; uint8_t* sX;               // [P][H][LP][HD], [P][H][LP][HD/32]   (rows)   or V8T / sV (transposed)
+  uint8_t* X8; uint8_t* sX;               // [P][LP][H][HD], [P][LP][H][HD/32]   (rows)   or V8T / sV (transposed)
   int P, H, L, LP, NT;
 };
 
@@ -58,101 +58,96 @@ __device__ __forceinline__ uint32_t e8m0_for(float amax) {
 }
 __device__ __forceinline__ float inv_scale_of(uint32_t sb) { return __builtin_bit_cast(float, (254u - sb) << 23); }
 
-// ---- quantisation of row operands (Q, K): one thread per (row, 64-element group, block b) -------------------------
-// elements of block b of group kf: kf*64 + 16b + [0,16) and kf*64 + 32 + 16b + [0,16)
+// ---- quantisation of row operands (Q, K): one thread per 16-byte chunk (8 bf16) of a row ----------------------------
+// Within a 64-element group (8 consecutive lanes, chunk c = lane & 7) block b = (c >> 1) & 1 holds chunks {2b, 2b+1, 4+2b,
+// 5+2b} (elements 16b..16b+15 and 32+16b..32+16b+15): the block maximum is two lane exchanges (c ^ 1, c ^ 4).  Loads are
+// 1 KB and stores 512 B contiguous per wave.
 template <int HD>
 __global__ void attn_quant_rows_kernel(const QuantP p) {
-  constexpr int BPR = HD / 32;                       // blocks per row
+  constexpr int CPRW = HD / 8;                       // 16-byte bf16 chunks per row
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)p.P * p.H * p.LP * BPR;
-  if (idx >= total) return;
-  const int blk = (int)(idx % BPR);
-  int64_t t = idx / BPR;
-  const int row = (int)(t % p.LP); t /= p.LP;
-  const int h = (int)(t % p.H);
-  const int pr = (int)(t / p.H);
-  const int kf = blk >> 1, b = blk & 1;
-  uint8_t* dst = p.X8 + (((int64_t)pr * p.H + h) * p.LP + row) * HD + kf * 64 + b * 16;
-  uint8_t* sdst = p.sX + (((int64_t)pr * p.H + h) * p.LP + row) * BPR + blk;
-  if (row >= p.L) {
-    *reinterpret_cast<u32x4*>(dst) = u32x4{0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(dst + 32) = u32x4{0u, 0u, 0u, 0u};
-    *sdst = 127;
-    return;
+  const int64_t total = (int64_t)p.P * p.H * p.LP * CPRW;
+  const bool live = idx < total;
+  const int64_t id = live ? idx : total - 1;         // (all lanes take part in the exchanges)
+  const int j = (int)(id % CPRW);
+  int64_t t = id / CPRW;
+  const int h = (int)(t % p.H); t /= p.H;            // heads fastest: a wave walks contiguous source memory
+  const int row = (int)(t % p.LP);
+  const int pr = (int)(t / p.LP);
+  const int c = j & 7, kf = j >> 3, b = (c >> 1) & 1;
+  f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+  if (row < p.L) {
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(p.X) + (int64_t)pr * p.ps + (int64_t)h * p.hs + (int64_t)row * p.rs + j * 8;
+    const u32x4 w = *reinterpret_cast<const u32x4*>(src);
+    x0 = f32x4{bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
+    x1 = f32x4{bf16lo(w[2]), bf16hi(w[2]), bf16lo(w[3]), bf16hi(w[3])};
   }
-  const bf16_t* src = reinterpret_cast<const bf16_t*>(p.X) + (int64_t)pr * p.ps + (int64_t)h * p.hs + (int64_t)row * p.rs +
-                      kf * 64 + b * 16;
-  float v[32];
-#pragma unroll
-  for (int piece = 0; piece < 2; ++piece)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const f32x4 x = load4<bf16_t>(src + piece * 32 + c * 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[piece * 16 + c * 4 + j] = x[j];
-    }
   float amax = 0.f;
 #pragma unroll
-  for (int j = 0; j < 32; ++j) amax = fmaxf(amax, fabsf(v[j]));
-  const uint32_t sb = e8m0_for(amax);
+  for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(x0[e]), fabsf(x1[e])));
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+  const uint32_t sb = row < p.L ? e8m0_for(amax) : 127u;
   const float inv = inv_scale_of(sb);
-#pragma unroll
-  for (int piece = 0; piece < 2; ++piece) {
-    u32x4 w;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      int word = 0;
-      word = __builtin_amdgcn_cvt_pk_fp8_f32(v[piece * 16 + c * 4 + 0] * inv, v[piece * 16 + c * 4 + 1] * inv, word, false);
-      word = __builtin_amdgcn_cvt_pk_fp8_f32(v[piece * 16 + c * 4 + 2] * inv, v[piece * 16 + c * 4 + 3] * inv, word, true);
-      w[c] = (uint32_t)word;
-    }
-    *reinterpret_cast<u32x4*>(dst + piece * 32) = w;
-  }
-  *sdst = (uint8_t)sb;
+  int w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x0[0] * inv, x0[1] * inv, w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x0[2] * inv, x0[3] * inv, w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x1[0] * inv, x1[1] * inv, w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x1[2] * inv, x1[3] * inv, w1, true);
+  if (!live) return;
+  const int64_t rbase = ((int64_t)pr * p.LP + row) * p.H + h;      // [P][LP][H][HD]: rows of one head are H * HD bytes apart
+  *reinterpret_cast<u32x2*>(p.X8 + rbase * HD + j * 8) = u32x2{(uint32_t)w0, (uint32_t)w1};
+  if ((c & 5) == 0) p.sX[rbase * (HD / 32) + kf * 2 + b] = (uint8_t)sb;
 }
 
-// ---- quantisation of V, transposed and key-permuted: one thread per (tile, d, kt) ----------------------------------
-// V8T[(tile*HD + d)*64 + h*32 + kt*16 + r] = V[tile*64 + kt*32 + (r & 3) + 8 (r >> 2) + 4 h][d];  block kt = keys kt*32..+31
+// ---- quantisation of V, transposed and key-permuted: one workgroup per (problem, head, 64-key tile) ------------------
+// V8T[(tile*HD + d)*64 + h*32 + kt*16 + r] = V[tile*64 + kt*32 + (r & 3) + 8 (r >> 2) + 4 h][d];  block kt = keys kt*32..+31.
+// The 64 x HD bf16 tile is read with coalesced 16-byte loads into LDS; item (d, kt) then walks its 32 keys down a column.
 template <int HD>
-__global__ void attn_quant_vt_kernel(const QuantP p) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)p.P * p.H * p.NT * 2 * HD;
-  if (idx >= total) return;
-  const int d = (int)(idx % HD);
-  int64_t t = idx / HD;
-  const int kt = (int)(t & 1); t >>= 1;
+__global__ __launch_bounds__(256) void attn_quant_vt_kernel(const QuantP p) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile_s[F8_KVB][HD + 8];     // +8: column walks of adjacent d stay conflict-free
+  int64_t t = blockIdx.x;
   const int tile = (int)(t % p.NT); t /= p.NT;
   const int h = (int)(t % p.H);
   const int pr = (int)(t / p.H);
-  const bf16_t* src = reinterpret_cast<const bf16_t*>(p.X) + (int64_t)pr * p.ps + (int64_t)h * p.hs + d;
-  const int key0 = tile * F8_KVB + kt * 32;
-  float v[32];                                       // v[hh*16 + r]
-  float amax = 0.f;
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      const float x = key < p.L ? to_f32(src[(int64_t)key * p.rs]) : 0.f;
-      v[hh * 16 + r] = x;
-      amax = fmaxf(amax, fabsf(x));
-    }
-  const uint32_t sb = e8m0_for(amax);
-  const float inv = inv_scale_of(sb);
-  uint8_t* base = p.X8 + ((((int64_t)pr * p.H + h) * p.NT + tile) * HD + d) * 64;
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    u32x4 w;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      int word = 0;
-      word = __builtin_amdgcn_cvt_pk_fp8_f32(v[hh * 16 + c * 4 + 0] * inv, v[hh * 16 + c * 4 + 1] * inv, word, false);
-      word = __builtin_amdgcn_cvt_pk_fp8_f32(v[hh * 16 + c * 4 + 2] * inv, v[hh * 16 + c * 4 + 3] * inv, word, true);
-      w[c] = (uint32_t)word;
-    }
-    *reinterpret_cast<u32x4*>(base + hh * 32 + kt * 16) = w;
+  const bf16_t* src = reinterpret_cast<const bf16_t*>(p.X) + (int64_t)pr * p.ps + (int64_t)h * p.hs;
+  constexpr int CPRW = HD / 8;
+  for (int c = threadIdx.x; c < F8_KVB * CPRW; c += 256) {
+    const int row = c / CPRW, ch = c % CPRW, key = tile * F8_KVB + row;
+    u32x4 w = {0u, 0u, 0u, 0u};
+    if (key < p.L) w = *reinterpret_cast<const u32x4*>(src + (int64_t)key * p.rs + ch * 8);
+    *reinterpret_cast<u32x4*>(&tile_s[row][ch * 8]) = w;
   }
-  p.sX[((((int64_t)pr * p.H + h) * p.NT + tile) * HD + d) * 2 + kt] = (uint8_t)sb;
+  __syncthreads();
+  for (int item = threadIdx.x; item < 2 * HD; item += 256) {
+    const int d = item % HD, kt = item / HD;
+    float v[32];                                     // v[hh*16 + r]
+    float amax = 0.f;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = to_f32(tile_s[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh][d]);
+        v[hh * 16 + r] = x;
+        amax = fmaxf(amax, fabsf(x));
+      }
+    const uint32_t sb = e8m0_for(amax);
+    const float inv = inv_scale_of(sb);
+    uint8_t* base = p.X8 + ((((int64_t)pr * p.H + h) * p.NT + tile) * HD + d) * 64;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      u32x4 w;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        int word = 0;
+        word = __builtin_amdgcn_cvt_pk_fp8_f32(v[hh * 16 + c * 4 + 0] * inv, v[hh * 16 + c * 4 + 1] * inv, word, false);
+        word = __builtin_amdgcn_cvt_pk_fp8_f32(v[hh * 16 + c * 4 + 2] * inv, v[hh * 16 + c * 4 + 3] * inv, word, true);
+        w[c] = (uint32_t)word;
+      }
+      *reinterpret_cast<u32x4*>(base + hh * 32 + kt * 16) = w;
+    }
+    p.sX[((((int64_t)pr * p.H + h) * p.NT + tile) * HD + d) * 2 + kt] = (uint8_t)sb;
+  }
 }
 
 // ---- the attention kernel -------------------------------------------------------------------------------------------
@@ -171,14 +166,14 @@ __device__ __forceinline__ i32x8 f8_frag(const char* tile, int row, int c0) {
 }
 // LDS-DMA of one contiguous tile of ROWS x (CPR * 16) bytes into its swizzled image (256 threads)
 template <int ROWS, int CPR>
-__device__ __forceinline__ void f8_dma_tile(char* lds, const uint8_t* src) {
+__device__ __forceinline__ void f8_dma_tile(char* lds, const uint8_t* src, int64_t pitch) {
   constexpr int NCH = ROWS * CPR;
   const int tid = threadIdx.x, wave = tid >> 6;
 #pragma unroll
   for (int c0 = 0; c0 < NCH; c0 += 256) {
     const int c = c0 + tid;
     const int row = c / CPR, ch = (c % CPR) ^ f8_swz<CPR>(row);
-    const uint8_t* g = src + (int64_t)row * (CPR * 16) + ch * 16;
+    const uint8_t* g = src + (int64_t)row * pitch + ch * 16;
     const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((c0 + wave * 64) * 16));
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
@@ -199,10 +194,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const AttnF8P p) {
   const int seg = blockIdx.x / bps, qb = blockIdx.x % bps;
   const int h = blockIdx.y, pr = blockIdx.z;
   const int qprob = seg == 0 ? pr : (pr + p.shift) % p.P;
-  const uint8_t* Q8 = p.Q8 + ((int64_t)qprob * p.H + h) * p.LqP * HD;
-  const uint8_t* sQ = p.sQ + ((int64_t)qprob * p.H + h) * p.LqP * (HD / 32);
-  const uint8_t* K8 = p.K8 + ((int64_t)pr * p.H + h) * p.LkP * HD;
-  const uint8_t* sK = p.sK + ((int64_t)pr * p.H + h) * p.LkP * (HD / 32);
+  // row operands are [problem][row][head][HD]: rows of one head H * HD bytes apart (scales: H * HD / 32)
+  const int64_t rp = (int64_t)p.H * HD, sp = (int64_t)p.H * (HD / 32);
+  const uint8_t* Q8 = p.Q8 + (int64_t)qprob * p.LqP * rp + h * HD;
+  const uint8_t* sQ = p.sQ + (int64_t)qprob * p.LqP * sp + h * (HD / 32);
+  const uint8_t* K8 = p.K8 + (int64_t)pr * p.LkP * rp + h * HD;
+  const uint8_t* sK = p.sK + (int64_t)pr * p.LkP * sp + h * (HD / 32);
   const uint8_t* V8 = p.V8T + ((int64_t)pr * p.H + h) * p.NT * HD * 64;
   const uint8_t* sV = p.sV + ((int64_t)pr * p.H + h) * p.NT * HD * 2;
   const int qw0 = qb * QB + wave * QT * 32;
@@ -219,10 +216,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const AttnF8P p) {
       u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
       int s = 127;
       if (ok) {
-        const uint8_t* row = Q8 + (int64_t)q * HD + kf * 64 + hf * 32;
+        const uint8_t* row = Q8 + (int64_t)q * rp + kf * 64 + hf * 32;
         a = *reinterpret_cast<const u32x4*>(row);
         b = *reinterpret_cast<const u32x4*>(row + 16);
-        s = sQ[(int64_t)q * (HD / 32) + kf * 2 + hf];
+        s = sQ[(int64_t)q * sp + kf * 2 + hf];
       }
       qf[qt][kf] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
       qs[qt][kf] = s;
@@ -251,8 +248,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const AttnF8P p) {
 
   auto stage = [&](int t, int buf) {
     char* b = smem + buf * STAGE;
-    f8_dma_tile<F8_KVB, CPRK>(b, K8 + (int64_t)t * KT_BYTES);
-    f8_dma_tile<HD, 4>(b + KT_BYTES, V8 + (int64_t)t * VT_BYTES);
+    f8_dma_tile<F8_KVB, CPRK>(b, K8 + (int64_t)t * F8_KVB * rp, rp);
+    f8_dma_tile<HD, 4>(b + KT_BYTES, V8 + (int64_t)t * VT_BYTES, 64);
   };
   // scale bytes of a tile's fragments (tiny, L2-resident), fetched ONE TILE AHEAD so that no tile waits on them
   int ks[2][NKF], vs[NDT], ks_n[2][NKF], vs_n[NDT];
@@ -260,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const AttnF8P p) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int kf = 0; kf < NKF; ++kf) k_[kt][kf] = sK[(int64_t)(t * F8_KVB + kt * 32 + il) * (HD / 32) + kf * 2 + hf];
+      for (int kf = 0; kf < NKF; ++kf) k_[kt][kf] = sK[(int64_t)(t * F8_KVB + kt * 32 + il) * sp + kf * 2 + hf];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) v_[dt] = sV[((int64_t)t * HD + dt * 32 + il) * 2 + hf];
   };
@@ -415,7 +412,8 @@ int f8_check(const dl_attn_fwd_args* a) {
   DL_CHECK_ARG(!a->raw_logits, DL_ERR_UNSUPPORTED, "dl_attn_fwd_fp8: raw logits are not produced by the fp8 form");
   const int64_t st[] = {a->q_ps, a->q_hs, a->q_rs, a->k_ps, a->k_hs, a->k_rs, a->v_ps, a->v_hs, a->v_rs, a->o_ps, a->o_hs, a->o_rs, a->o_ss};
   for (int i = 0; i < 13; ++i)
-    DL_CHECK_ARG(st[i] % 4 == 0, DL_ERR_ALIGN, "dl_attn_fwd_fp8: stride #%d (%ld) not a multiple of 4 elements", i, (long)st[i]);
+    DL_CHECK_ARG(st[i] % 8 == 0, DL_ERR_ALIGN, "dl_attn_fwd_fp8: stride #%d (%ld) not a multiple of 8 elements", i, (long)st[i]);
+  DL_CHECK_ARG((((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V) & 15) == 0, DL_ERR_ALIGN, "dl_attn_fwd_fp8: Q/K/V must be 16-byte aligned");
   return DL_OK;
 }
 
@@ -427,18 +425,18 @@ int f8_launch(const dl_attn_fwd_args* a, char* ws, hipStream_t s) {
   // Q rows
   q.X = (const char*)a->Q; q.ps = a->q_ps; q.hs = a->q_hs; q.rs = a->q_rs; q.L = a->Lq; q.LP = L.LqP;
   q.X8 = (uint8_t*)(ws + L.q8); q.sX = (uint8_t*)(ws + L.sq);
-  int64_t n = (int64_t)q.P * q.H * q.LP * (HD / 32);
+  int64_t n = (int64_t)q.P * q.H * q.LP * (HD / 8);
   hipLaunchKernelGGL((attn_quant_rows_kernel<HD>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, q);
   // K rows
   q.X = (const char*)a->K; q.ps = a->k_ps; q.hs = a->k_hs; q.rs = a->k_rs; q.L = a->Lk; q.LP = L.LkP;
   q.X8 = (uint8_t*)(ws + L.k8); q.sX = (uint8_t*)(ws + L.sk);
-  n = (int64_t)q.P * q.H * q.LP * (HD / 32);
+  n = (int64_t)q.P * q.H * q.LP * (HD / 8);
   hipLaunchKernelGGL((attn_quant_rows_kernel<HD>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, q);
   // V transposed
   q.X = (const char*)a->V; q.ps = a->v_ps; q.hs = a->v_hs; q.rs = a->v_rs; q.L = a->Lk; q.NT = L.NT;
   q.X8 = (uint8_t*)(ws + L.v8); q.sX = (uint8_t*)(ws + L.sv);
-  n = (int64_t)q.P * q.H * L.NT * 2 * HD;
-  hipLaunchKernelGGL((attn_quant_vt_kernel<HD>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, q);
+  n = (int64_t)q.P * q.H * L.NT;
+  hipLaunchKernelGGL((attn_quant_vt_kernel<HD>), dim3((uint32_t)n), dim3(256), 0, s, q);
 
   AttnF8P p = {};
   p.Q8 = (const uint8_t*)(ws + L.q8); p.sQ = (const uint8_t*)(ws + L.sq);

@@ -21,6 +21,7 @@ class EmbeddingStore:
         self._index: Dict[Hashable, Tuple[int, int]] = {}
         self._chunks, self._rows = [], 0
         self._store = None
+        self._finalized = False
 
     def add(self, key: Hashable, emb) -> None:
         """emb: (len, feat_dim) array / tensor.  Keys are unique entities (Drug_ID / Prot_ID)."""
@@ -30,13 +31,15 @@ class EmbeddingStore:
         if t.dim() != 2 or t.shape[1] != self.feat_dim:
             raise ValueError("EmbeddingStore.add: expected (len, %d), got %s" % (self.feat_dim, tuple(t.shape)))
         self._index[key] = (self._rows, t.shape[0])
-        self._chunks.append(t.to(self.dtype))
+        # chunks appended after a finalize() join the device-resident store on the device (torch.cat needs one device)
+        self._chunks.append(t.to(device=self.device if self._finalized else t.device, dtype=self.dtype))
         self._rows += t.shape[0]
         self._store = None
 
     def finalize(self) -> "EmbeddingStore":
-        self._store = torch.cat(self._chunks, dim=0).to(self.device).contiguous()
+        self._store = torch.cat([c.to(self.device) for c in self._chunks], dim=0).contiguous()
         self._chunks = [self._store]            # keep one reference so that add() after finalize() still works
+        self._finalized = True
         return self
 
     @property
@@ -48,6 +51,13 @@ class EmbeddingStore:
         if self._store is None or self._store.shape[0] != self._rows:
             self.finalize()
         idx = [self._index[k] for k in keys]
+        if not repeat:
+            # the reference's tail_pad (utils.py:304-312) raises on a sequence longer than maxsize (shape mismatch in
+            # `out[i, :len] = a`); its repeat_pad yields an all-zero block instead (0 whole repetitions), kept as is
+            too_long = [k for k, (_, n) in zip(keys, idx) if n > max_rows]
+            if too_long:
+                raise ValueError("EmbeddingStore.batch: %d sequence(s) longer than max_rows=%d under tail padding (first key: %r)"
+                                 % (len(too_long), max_rows, too_long[0]))
         offsets = torch.tensor([o for o, _ in idx], dtype=torch.int64, device=self.device)
         lengths = torch.tensor([n for _, n in idx], dtype=torch.int32, device=self.device)
         return ops.gather_pad(self._store, offsets, lengths, max_rows, repeat)

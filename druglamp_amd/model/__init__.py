@@ -1,1 +1,1 @@
-from .model_interface import MInterface  # noqa: F401
+from .model_interface import MInterface, load_reference_checkpoint  # noqa: F401

@@ -23,3 +23,28 @@ class MInterface(object):
         args1 = {a: other_args[a] for a in class_args if a in other_args}
         args1.update(**config)
         return Model(**args1)
+
+
+def load_reference_checkpoint(model, checkpoint, strict: bool = True):
+    """Load a checkpoint written by the reference's Lightning run (trainer.py:151-156 ModelCheckpoint on the ExpModule):
+    a dict whose "state_dict" maps "exp_model.<key>" to tensors (ExpModule stores the model as self.exp_model,
+    trainer.py:43) next to metric-object states.  `checkpoint` is a path or the loaded dict; a bare state_dict (with or
+    without the prefix) is accepted too.  The lazily created SimSiam projectors are built first when the checkpoint holds
+    them (the reference needs one SSL forward before it can load such a checkpoint).  Returns load_state_dict's result;
+    the reference itself reloads with strict=False (trainer.py:134)."""
+    import torch
+    ck = torch.load(checkpoint, map_location="cpu") if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "read") else checkpoint
+    sd = ck.get("state_dict", ck) if isinstance(ck, dict) else ck
+    prefix = "exp_model."
+    if any(k.startswith(prefix) for k in sd):
+        sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    proj = [k for k in sd if ".projector." in k]
+    if proj and hasattr(model, "ssl_model"):
+        dims = {}
+        for name in ("net", "llm_net"):
+            w = sd.get("ssl_model.%s.projector.0.weight" % name)
+            if w is not None:
+                dims[name] = int(w.shape[1])
+        if len(dims) == 2:
+            model.ssl_model.build_projectors(dims["net"], dims["llm_net"], device=next(model.parameters()).device)
+    return model.load_state_dict(sd, strict=strict)

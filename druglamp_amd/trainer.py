@@ -298,6 +298,7 @@ class Trainer:
     graph_steps=True: cls-only steps run as hipGraph replays (GraphedStep); SSL / CM steps and the first step of every
     new batch shape stay eager."""
     overlap = None
+    _agreed_sets = None
 
     def __init__(self, model, cfg, device=None, compute_dtype=torch.float32, graph_steps: bool = False):
         self.model = model
@@ -315,6 +316,12 @@ class Trainer:
         # main.py:158-160: three AdamW over model.parameters() built BEFORE any SSL forward (the lazily
         # created SimSiam projectors are therefore in none of them)
         self.flat = FlatParams([p for p in model.parameters()])
+        if self.world > 1:
+            # what the reference's DDP wrapper does at wrap time (trainer.py:143-148 -> torch DDP): every replica starts
+            # from rank 0's parameters and buffers (BatchNorm running statistics, step counters), whatever each rank's
+            # own initialisation drew.  Without it replicas that were seeded differently drift silently: the all-reduce
+            # averages gradients, never weights.
+            self.sync_replicas()
         Fn.bump_param_epoch()
         warm = int(self.epochs * 0.2)
         self.opt = FusedAdamW(self.flat, cfg["SOLVER"]["LR"])
@@ -344,12 +351,33 @@ class Trainer:
         # hook-driven collectives cannot be launched from inside a graph replay: graphed steps reduce after the replay
         self.graph_steps = bool(graph_steps) and self.overlap is None
         self._graphs: Dict[tuple, GraphedStep] = {}
+        self._agreed_sets: Dict[str, frozenset] = {}
         self._eager_seen: Dict[tuple, int] = {}
         self.graph_warmup = 2            # eager (real) steps of a batch shape before its graph is captured
         if self.graph_steps:
             ops.use_seed_offset(True)    # one dropout-seed regime for eager and replayed steps
 
     # -- helpers ------------------------------------------------------------------------------------
+    def sync_replicas(self, src: int = 0):
+        """Broadcast the parameter arena and every module buffer from rank `src` (no-op at world size 1)."""
+        if self.world <= 1:
+            return
+        dist.broadcast(self.flat.arena, src=src)
+        for b in self.model.buffers():
+            dist.broadcast(b, src=src)
+        Fn.bump_param_epoch()
+
+    def replicas_in_sync(self) -> bool:
+        """True iff every rank holds bit-identical parameters (a cheap checksum all-gather; used by tests / on demand)."""
+        if self.world <= 1:
+            return True
+        a = self.flat.arena
+        chk = torch.stack((a.double().sum(), a.double().abs().sum(), (a.double() * torch.arange(1, a.numel() + 1, device=a.device,
+                                                                                                   dtype=torch.float64) % 9973).sum()))
+        allc = [torch.empty_like(chk) for _ in range(self.world)]
+        dist.all_gather(allc, chk)
+        return all(torch.equal(allc[0], c) for c in allc[1:])
+
     def _zero_grad(self):
         for p in self.flat.params:
             p.grad = None
@@ -358,14 +386,42 @@ class Trainer:
         if self.overlap is not None and last == kind:
             self.overlap.arm(kind)
 
-    def _reduce_and_pack(self) -> List[int]:
+    def _reduce_and_pack(self, kind: str = "cls") -> List[int]:
         if self.overlap is not None:
             return self.overlap.finish()
         idx = self.flat.pack_grads()
-        if self.world > 1 and idx:
+        if self.world > 1:
+            idx = self._agreed(kind, idx)
             for s, e, _ in self.flat.runs(idx, lambda i: 0):
                 dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM)
         return idx
+
+    def _agreed(self, kind: str, have: List[int]) -> List[int]:
+        """The parameter set every rank reduces for a backward pass of `kind`: the union over ranks of the parameters that
+        received a gradient, agreed on ONCE per kind (one small MAX all-reduce, cached).  A parameter of the set without
+        a local gradient contributes zeros (what DDP's find_unused_parameters does for the reference,
+        trainer.py:147); a gradient outside the cached set means the graph changed and the set is re-agreed — every
+        rank takes the same branch because the decision itself is all-reduced."""
+        n = len(self.flat.params)
+        if self._agreed_sets is None:
+            self._agreed_sets = {}
+        cached = self._agreed_sets.get(kind)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.flat.grads.device)
+        if cached is None or not set(have) <= cached:
+            flag.fill_(1)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag) != 0:
+            mask = torch.zeros(n, dtype=torch.int32)
+            mask[have] = 1
+            if cached is not None:
+                mask[sorted(cached)] = 1
+            mask = mask.to(self.flat.grads.device)
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+            cached = self._agreed_sets[kind] = frozenset(mask.cpu().nonzero().flatten().tolist())
+        missing = sorted(cached - set(have))
+        if missing:
+            torch._foreach_zero_([self.flat.grad_views[i] for i in missing])
+        return sorted(cached)
 
     def set_lrs(self, lr=None, ssl_lr=None, cm_lr=None):
         if lr is not None:
@@ -425,7 +481,7 @@ class Trainer:
             self._arm(last, "cm")
             cm_loss.backward()
             out["cm"] = cm_loss.detach()
-        idx = self._reduce_and_pack()
+        idx = self._reduce_and_pack(last)
         scale = 1.0 / self.world
         self.opt.step(idx, scale)
         if compute_ssl:
@@ -440,7 +496,8 @@ class Trainer:
         if g is None:
             g = self._graphs[sig] = GraphedStep(self, batch)     # records only; the replay below is the step
         out, idx = g.run(batch)
-        if self.world > 1 and idx:
+        if self.world > 1:
+            idx = self._agreed("cls", idx)
             for s, e, _ in self.flat.runs(idx, lambda i: 0):
                 dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM)
         self.opt.step(idx, 1.0 / self.world)
@@ -465,32 +522,100 @@ class Trainer:
 
     # -- evaluation (trainer.py:256-292; torchmetrics replaced by sklearn on the gathered predictions) -----
     @torch.no_grad()
-    def evaluate(self, batches) -> Dict[str, float]:
-        from sklearn.metrics import average_precision_score, roc_auc_score
+    def predict(self, batches):
+        """Eval-mode forward over `batches` (any batch size: the reference validates / tests at batch 1, main.py:146-153;
+        the per-sample results do not depend on the batch because BatchNorm uses its running statistics).  Returns this
+        rank's (probabilities, labels, summed BCE, sample count)."""
         self.model.eval()
-        preds, labs, losses = [], [], []
+        preds, labs = [], []
+        loss_sum = torch.zeros((), dtype=torch.float64, device=self.device)
         for batch in batches:
             feat_d, feat_p, labels, llm_d, llm_p = batch
             _, _, _, _, score = self.model(feat_d, feat_p, llm_d, llm_p)
             n, loss = binary_cross_entropy(score, labels) if self.n_class == 1 else cross_entropy_logits(score, labels)
-            preds.append(n.float())
-            labs.append(labels.float())
-            losses.append(loss.float().reshape(1))
-        p, y = torch.cat(preds), torch.cat(labs)
-        if self.world > 1:
-            ps = [torch.empty_like(p) for _ in range(self.world)]
-            ys = [torch.empty_like(y) for _ in range(self.world)]
-            dist.all_gather(ps, p)
-            dist.all_gather(ys, y)
-            p, y = torch.cat(ps), torch.cat(ys)
-        p, y = p.cpu().numpy(), y.cpu().numpy()
-        auroc = float(roc_auc_score(y, p)) if len(set(y.tolist())) > 1 else float("nan")
-        auprc = float(average_precision_score(y, p)) if y.sum() > 0 else float("nan")
-        yhat = (p >= 0.5).astype("float32")
-        tp, tn = float(((yhat == 1) & (y == 1)).sum()), float(((yhat == 0) & (y == 0)).sum())
-        fp, fn = float(((yhat == 1) & (y == 0)).sum()), float(((yhat == 0) & (y == 1)).sum())
-        prec = tp / max(tp + fp, 1.0)
-        rec = tp / max(tp + fn, 1.0)
-        return {"loss": float(torch.cat(losses).mean()), "auroc": auroc, "auprc": auprc, "ausum": auroc + auprc,
-                "acc": (tp + tn) / max(len(y), 1), "sn": rec, "sp": tn / max(tn + fp, 1.0), "pr": prec,
-                "f1": 2 * prec * rec / max(prec + rec, 1e-12)}
+            preds.append(n.float().reshape(-1))
+            labs.append(labels.float().reshape(-1))
+            loss_sum += loss.double() * labels.numel()              # per-batch means -> a sum over samples
+        p = torch.cat(preds) if preds else torch.zeros(0, device=self.device)
+        y = torch.cat(labs) if labs else torch.zeros(0, device=self.device)
+        return p, y, loss_sum, p.numel()
+
+    def evaluate(self, batches) -> Dict[str, float]:
+        """Metrics over the union of all ranks' samples (the reference's torchmetrics objects gather their states at
+        epoch end, trainer.py:262-292; its logged loss is `sync_dist=True`): ranks may hold different numbers of samples."""
+        p, y, loss_sum, n = self.predict(batches)
+        p, y, loss_sum, n = gather_predictions(p, y, loss_sum, n, self.world)
+        out = binary_metrics(p.cpu().numpy(), y.cpu().numpy())
+        out["loss"] = float(loss_sum) / max(n, 1)
+        return out
+
+    def fit(self, train_batches, val_batches, epochs: Optional[int] = None, on_epoch=None) -> Dict[str, object]:
+        """The reference's run_experiment loop (trainer.py:131-135,150-163): one pass over `train_batches()` per epoch
+        (a callable yielding (batch, meta) pairs), on_train_epoch_end, validation; the parameters with the best
+        `val_ausum` (AUROC + AUPRC: ModelCheckpoint(monitor='val_ausum', mode='max')) are kept, training stops after
+        patience = epochs / 4 epochs without improvement (EarlyStopping, min_delta 0), and the best parameters are
+        reloaded before returning (trainer.py:134) — ready for evaluate(test_batches)."""
+        epochs = int(epochs or self.epochs)
+        patience = max(int(epochs / 4), 1)
+        best = {"ausum": -float("inf"), "epoch": 0, "arena": None, "buffers": None}
+        history, bad = [], 0
+        for ep in range(1, epochs + 1):
+            for batch, meta in train_batches():
+                self.training_step(batch, meta=meta, cur_epoch=ep)
+            self.on_train_epoch_end(ep)
+            val = self.evaluate(val_batches() if callable(val_batches) else val_batches)
+            history.append(val)
+            if on_epoch is not None:
+                on_epoch(ep, val)
+            score = val["ausum"]
+            if score == score and score > best["ausum"]:
+                best.update(ausum=score, epoch=ep, arena=self.flat.arena.clone(),
+                            buffers=[b.detach().clone() for b in self.model.buffers()])
+                bad = 0
+            else:
+                bad += 1
+                if bad >= patience:
+                    break
+        if best["arena"] is not None:                                    # reload the best checkpoint (trainer.py:134)
+            with torch.no_grad():
+                self.flat.arena.copy_(best["arena"])
+                for b, src in zip(self.model.buffers(), best["buffers"]):
+                    b.copy_(src)
+            Fn.bump_param_epoch()
+        return {"best_epoch": best["epoch"], "best_val_ausum": best["ausum"], "epochs_run": len(history), "history": history}
+
+
+def gather_predictions(p: torch.Tensor, y: torch.Tensor, loss_sum: torch.Tensor, n: int, world: int):
+    """All ranks' predictions / labels / loss sums, for shards of DIFFERENT sizes: counts are gathered first, every
+    shard is padded to the largest and trimmed after the gather (equal-size all_gather would hang or mis-slice)."""
+    if world <= 1:
+        return p, y, loss_sum, n
+    dev = p.device
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=dev))
+    counts = [int(c) for c in counts]
+    m = max(max(counts), 1)
+    buf = torch.zeros((2, m), dtype=torch.float32, device=dev)
+    buf[0, :n], buf[1, :n] = p.float(), y.float()
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    ls = loss_sum.detach().double().reshape(1).clone()
+    dist.all_reduce(ls, op=dist.ReduceOp.SUM)
+    p = torch.cat([b[0, :c] for b, c in zip(bufs, counts)])
+    y = torch.cat([b[1, :c] for b, c in zip(bufs, counts)])
+    return p, y, ls[0], sum(counts)
+
+
+def binary_metrics(p, y) -> Dict[str, float]:
+    """AUROC / AUPRC (sklearn = torchmetrics' exact, threshold-free definitions), their sum (the reference's BinaryAUSum,
+    trainer.py:17-37) and the thresholded metrics at 0.5 (trainer.py:109-119)."""
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    auroc = float(roc_auc_score(y, p)) if len(set(y.tolist())) > 1 else float("nan")
+    auprc = float(average_precision_score(y, p)) if y.sum() > 0 else float("nan")
+    yhat = (p >= 0.5).astype("float32")
+    tp, tn = float(((yhat == 1) & (y == 1)).sum()), float(((yhat == 0) & (y == 0)).sum())
+    fp, fn = float(((yhat == 1) & (y == 0)).sum()), float(((yhat == 0) & (y == 1)).sum())
+    prec = tp / max(tp + fp, 1.0)
+    rec = tp / max(tp + fn, 1.0)
+    return {"auroc": auroc, "auprc": auprc, "ausum": auroc + auprc, "acc": (tp + tn) / max(len(y), 1), "sn": rec,
+            "sp": tn / max(tn + fp, 1.0), "pr": prec, "f1": 2 * prec * rec / max(prec + rec, 1e-12)}

@@ -1,0 +1,108 @@
+"""Host-side logic added in round 2, CPU only:
+  * repeat_integer_label (druglamp_amd/data.py) against the reference's own repeat_integer_label_protein outputs stored in
+    tests/golden/human_random_rows.npz (reference utils.py:392-412);
+  * binary_metrics against sklearn called directly, and the reference's BinaryAUSum definition (trainer.py:17-37);
+  * gather_predictions with UNEVEN shards, replica synchronisation and the agreed gradient set on two gloo ranks."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_protein_code_tiling_matches_reference_encoder_outputs():
+    from druglamp_amd.data import repeat_integer_label
+    g = np.load(os.path.join(GOLD, "human_random_rows.npz"))
+    offs, codes = g["prot_offsets"], g["prot_codes"]
+    for pid in range(4):
+        mine = repeat_integer_label(codes[offs[pid]:offs[pid + 1]], 9 * 256)
+        assert mine.dtype == np.float64 and np.array_equal(mine.astype(np.uint8), g["full_encodings"][pid])
+    assert codes.max() <= 25 and g["train"].shape == (1024, 3) and set(np.unique(g["train"][:, 2])) <= {0, 1}
+    # ids are numbered in order of first appearance over train, val, test
+    assert g["train"][0, 0] == 0 and g["train"][0, 1] == 0
+
+
+def test_binary_metrics_equal_sklearn_and_ausum_definition():
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    from druglamp_amd.trainer import binary_metrics
+    rs = np.random.RandomState(0)
+    y = (rs.rand(200) < 0.4).astype(np.float32)
+    p = np.clip(0.3 * y + rs.rand(200) * 0.7, 0, 1).astype(np.float32)
+    m = binary_metrics(p, y)
+    assert abs(m["auroc"] - roc_auc_score(y, p)) < 1e-12 and abs(m["auprc"] - average_precision_score(y, p)) < 1e-12
+    assert abs(m["ausum"] - (m["auroc"] + m["auprc"])) < 1e-12
+    yh = p >= 0.5
+    assert abs(m["acc"] - float((yh == (y == 1)).mean())) < 1e-12
+    one = binary_metrics(np.array([0.2, 0.3], dtype=np.float32), np.array([0, 0], dtype=np.float32))
+    assert np.isnan(one["auroc"]) and np.isnan(one["auprc"])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from druglamp_amd.trainer import FlatParams, Trainer, binary_metrics, gather_predictions
+    ok = True
+    # ---- uneven evaluation shards: rank 0 holds 5 samples, rank 1 holds 2 (and an empty-shard round) ----
+    full_p = torch.tensor([0.9, 0.1, 0.4, 0.8, 0.3, 0.7, 0.2])
+    full_y = torch.tensor([1.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0])
+    lo, hi = (0, 5) if rank == 0 else (5, 7)
+    p, y, ls, n = gather_predictions(full_p[lo:hi], full_y[lo:hi], torch.tensor(float(hi - lo) * (rank + 1.0)), hi - lo, world)
+    ok &= n == 7 and torch.equal(p, full_p) and torch.equal(y, full_y) and abs(float(ls) - (5 * 1.0 + 2 * 2.0)) < 1e-12
+    ok &= abs(binary_metrics(p.numpy(), y.numpy())["auroc"] - binary_metrics(full_p.numpy(), full_y.numpy())["auroc"]) < 1e-12
+    e = torch.zeros(0)
+    p, y, ls, n = gather_predictions(full_p if rank == 0 else e, full_y if rank == 0 else e, torch.tensor(0.0), 7 if rank == 0 else 0, world)
+    ok &= n == 7 and torch.equal(p, full_p)
+    # ---- replica synchronisation: ranks start from DIFFERENT parameters / buffers, rank 0 wins ----
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+    net[1].running_mean.fill_(float(rank + 1))
+    t = Trainer.__new__(Trainer)
+    t.model, t.world, t.rank = net, world, rank
+    t.flat = FlatParams(list(net.parameters()))
+    ok &= not t.replicas_in_sync()
+    t.sync_replicas()
+    ok &= t.replicas_in_sync() and float(net[1].running_mean[0]) == 1.0
+    # ---- agreed gradient set: rank 1 has no gradient for the last Linear on the first step, none for the first on the second ----
+    t._agreed_sets = {}
+    ps = t.flat.params
+
+    def step(skip):
+        for i, p_ in enumerate(ps):
+            p_.grad = None if i in skip else torch.full_like(p_, float(rank + 1))
+        idx = t._reduce_and_pack("cls")
+        return idx
+    idx = step({4, 5} if rank == 1 else set())
+    ok &= idx == list(range(len(ps)))
+    for i in range(len(ps)):
+        want = 3.0 if i < 4 else 1.0                  # parameters 4, 5 exist on rank 0 only: 1 + zeros
+        ok &= bool(torch.allclose(t.flat.grad_views[i], torch.full_like(ps[i], want)))
+    idx = step({0} if rank == 1 else set())           # inside the cached set: no re-agreement needed, zero-filled locally
+    ok &= idx == list(range(len(ps))) and bool(torch.allclose(t.flat.grad_views[0], torch.full_like(ps[0], 1.0)))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_uneven_eval_gather_replica_sync_and_agreed_gradient_set_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -187,3 +187,27 @@ def test_ops_reject_cpu_tensors():
         ops.gemm(x, x, M=8, N=8, K=8)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.layernorm_fwd(x, torch.ones(8), torch.zeros(8), 1e-6)
+
+
+def test_load_reference_checkpoint_strips_the_lightning_prefix(tmp_path):
+    """Reference checkpoints are Lightning files of ExpModule: {"state_dict": {"exp_model.<key>": tensor, ...}}
+    (trainer.py:43,151-156); the helper strips the prefix, builds the lazy SimSiam projectors when present and loads
+    strictly."""
+    import torch
+    from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
+    from druglamp_amd.model import MInterface, load_reference_checkpoint
+    cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP")
+    torch.manual_seed(0)
+    src = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640)
+    src.ssl_model.build_projectors(128, 385)
+    ck = {"epoch": 3, "state_dict": {"exp_model." + k: v.clone() for k, v in src.state_dict().items()}}
+    ck["state_dict"]["valid_metrics.auroc.preds"] = torch.zeros(3)          # Lightning stores metric states next to the model
+    path = tmp_path / "max_val_ausum= 1.50000.ckpt"
+    torch.save(ck, path)
+    torch.manual_seed(1)
+    dst = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640)
+    assert dst.ssl_model.net.projector is None
+    res = load_reference_checkpoint(dst, str(path))
+    assert not res.missing_keys and not res.unexpected_keys
+    a, b = src.state_dict(), dst.state_dict()
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)

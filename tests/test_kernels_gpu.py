@@ -248,6 +248,14 @@ def test_embedding_store_batches_equal_reference_collate_padding(dt):
         n = plen[k]
         reps = 2304 // n
         assert torch.equal(row[:reps * n], e.repeat(reps, 1)) and not row[reps * n:].any()
+    # add() after the store went to the device (finalize is implied by batch) keeps working ...
+    extra = torch.randn(11, 640, generator=g)
+    ps.add("late", extra)
+    out = ps.batch(["late", 1], 2304, repeat=True)
+    assert torch.equal(out[0, :11], extra.to(dt).cuda()) and torch.equal(out[1, :1022], pe[1].to(dt).cuda())
+    # ... and tail padding refuses a sequence longer than the window, like the reference's tail_pad (utils.py:304-312)
+    with pytest.raises(ValueError):
+        st.batch(["k9"], 48, repeat=False)
 
 
 def test_layernorm_bwd_shared_dy_rows_equal_expanded_dy():

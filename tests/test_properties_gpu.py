@@ -84,8 +84,10 @@ def test_layernorm_rows_are_standardised_at_full_size():
     assert (mean - x.float().mean(1)).abs().max() <= 1e-3
 
 
-def test_training_step_is_bit_reproducible():
-    """Same seeds -> identical loss and identical parameters after two steps (no atomics anywhere on the path)."""
+@pytest.mark.parametrize("B", [64, 256])
+def test_training_step_is_bit_reproducible(B):
+    """Same seeds -> identical loss and identical parameters after two steps (no atomics anywhere on the path);
+    B = 256 is the batch bench.py times."""
     from druglamp_amd import ops
     from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
     from druglamp_amd.model import MInterface
@@ -100,7 +102,7 @@ def test_training_step_is_bit_reproducible():
         model = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
         tr = Trainer(model, cfg, device=dev, compute_dtype=DT)
         tr.set_lrs(cfg["SOLVER"]["LR"], cfg["SOLVER"]["SSL_LR"], cfg["SOLVER"]["CM_LR"])
-        batch, meta = make_batch(64, dev, seed=3, with_graph=True, llm_dtype=DT)
+        batch, meta = make_batch(B, dev, seed=3, with_graph=True, llm_dtype=DT)
         losses = [tr.training_step(batch, meta=meta, cur_epoch=1) for _ in range(2)]
         torch.cuda.synchronize()
         res.append((losses, torch.cat([p.detach().flatten() for p in model.parameters()]).clone()))

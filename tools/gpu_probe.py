@@ -134,7 +134,8 @@ def attn_cases():
     for dt in (torch.float32, torch.bfloat16):
         for (P, H, Lq, Lk, hd, nseg) in [(2, 4, 256, 256, 64, 1), (2, 2, 100, 77, 64, 1), (3, 1, 256, 512, 128, 1),
                                          (2, 4, 64, 64, 128, 1), (4, 4, 128, 128, 64, 2), (2, 4, 256, 256, 64, 2),
-                                         (2, 2, 40, 40, 128, 2)]:
+                                         (2, 2, 40, 40, 128, 2),
+                                         (3, 4, 64, 512, 64, 1)]:          # north-star cross-attention tile (Ld=64, Lp=512, 4 heads of 64)
             d = H * hd
             scale = 1.0 / math.sqrt(hd)
             # layout [P][L][3d] fused qkv (like the projection GEMM writes it)
