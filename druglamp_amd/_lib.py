@@ -110,6 +110,7 @@ SIGNATURES = {
     "dl_bn_finalize": (c_i32, [c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dl_interleave_streams": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "dl_norm_adjacency": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "dl_graph_aggregate": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "dl_concat2": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "dl_gather_pad": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "dl_embed_pad": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),

@@ -864,9 +864,17 @@ class GraphAggregateFn(torch.autograd.Function):
     (two zero fills, two slice copies and an add per layer)."""
 
     @staticmethod
+    def _hip(ahat, feat):
+        return (feat.is_cuda and ahat.shape[-1] <= 128 and feat.shape[-1] == 128 and ahat.dtype == feat.dtype
+                and feat.dtype in (torch.float32, torch.bfloat16))
+
+    @staticmethod
     def forward(ctx, ahat, feat):
         Nr = ahat.shape[-1]
         ctx.save_for_backward(ahat)
+        if GraphAggregateFn._hip(ahat, feat):
+            return ops.graph_aggregate(ahat, feat, transpose=False)        # one launch per layer on the HIP path
+        # graphs with more than 128 real atoms: batched product through the BLAS library
         if Nr == feat.shape[1]:
             return torch.bmm(ahat, feat)
         out = feat.clone()
@@ -877,6 +885,8 @@ class GraphAggregateFn(torch.autograd.Function):
     def backward(ctx, dout):
         (ahat,) = ctx.saved_tensors
         Nr = ahat.shape[-1]
+        if GraphAggregateFn._hip(ahat, dout):
+            return None, ops.graph_aggregate(ahat, dout.contiguous(), transpose=True)
         if Nr == dout.shape[1]:
             return None, torch.bmm(ahat.transpose(1, 2), dout)
         dfeat = dout.clone()

@@ -507,6 +507,17 @@ def norm_adjacency(adj: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return out
 
 
+def graph_aggregate(ahat: torch.Tensor, feat: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """ahat (B, n, n), feat (B, N, C) -> (B, N, C): [A' @ feat[:, :n] ; feat[:, n:]] with A' = ahat or ahat^T (dl_graph_aggregate)."""
+    _need_gpu(ahat, feat)
+    ahat, feat = ahat.contiguous(), feat.contiguous()
+    B, N, Cc = feat.shape
+    out = torch.empty_like(feat)
+    check(_lib.lib().dl_graph_aggregate(ahat.data_ptr(), feat.data_ptr(), out.data_ptr(), B, ahat.shape[-1], N, Cc, int(bool(transpose)),
+                                        _dt(feat), _stream()), "dl_graph_aggregate")
+    return out
+
+
 def concat2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """cat((a, b), -1) for two tensors with equal leading shape."""
     _need_gpu(a, b)

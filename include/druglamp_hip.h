@@ -233,6 +233,12 @@ int dl_interleave_streams(const void* src, void* dst, int64_t R, int64_t row_byt
  * with clamped degrees^-1/2 (MolecularGCN: model/basic_model.py:137-153, 591-617 — dgl GraphConv norm='both').
  * adj (B, n, n) fp32, ahat (B, n, n) out_dtype; n <= 190. */
 int dl_norm_adjacency(const float* adj, void* ahat, int64_t B, int32_t n, int32_t out_dtype, dl_stream s);
+/* Neighbourhood aggregation of MolecularGCN on dense batched graphs (dgl GraphConv norm='both' `update_all(copy_u, sum)`,
+ * model/basic_model.py:591-617): out[b][i][:] = sum_j A'[b][i][j] * feat[b][j][:] for the n real nodes (A' = ahat, or
+ * ahat^T when transpose = 1: the gradient), out[b][i][:] = feat[b][i][:] for the virtual padding nodes n <= i < N (their
+ * only edge is the self loop).  ahat (B, n, n) from dl_norm_adjacency, feat / out (B, N, C), all `dtype`; n <= 128, C = 128. */
+int dl_graph_aggregate(const void* ahat, const void* feat, void* out, int64_t B, int32_t n, int32_t N, int32_t C,
+                       int32_t transpose, int32_t dtype, dl_stream s);
 /* cat[r] = [a[r] | b[r]] for two row-major buffers (model/DrugLAMP.py:57,66: `cat((prot_sites, guided), 2)` in front of
  * the MHLA blocks); inverse = 1 splits cat back into a and b (the gradient). */
 int dl_concat2(void* a, void* b, void* cat, int64_t R, int64_t a_row_bytes, int64_t b_row_bytes, int32_t inverse,

@@ -314,3 +314,21 @@ def test_norm_adjacency_matches_the_torch_formula():
         assert (got - want).abs().max() <= 1e-6
         got16 = ops.norm_adjacency(adj, torch.bfloat16).float()
         assert (got16 - want).abs().max() <= 4e-3
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("n", [128, 77, 5])
+def test_graph_aggregate_matches_batched_product(dt, tol, n):
+    """dl_graph_aggregate (MolecularGCN neighbourhood sum on dense batched graphs, reference basic_model.py:591-617) against
+    torch.bmm in fp64, forward (ahat) and gradient (ahat^T) forms; virtual nodes n..N-1 pass through unchanged."""
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(n)
+    B, N, C = 5, 512, 128
+    ahat = (torch.rand(B, n, n, generator=g) * (torch.rand(B, n, n, generator=g) < 0.2)).to(dt).cuda()
+    feat = torch.randn(B, N, C, generator=g).to(dt).cuda()
+    for transpose in (False, True):
+        out = ops.graph_aggregate(ahat, feat, transpose=transpose)
+        a = ahat.double().transpose(1, 2) if transpose else ahat.double()
+        ref = torch.bmm(a, feat[:, :n].double())
+        assert float((out[:, :n].double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+        assert torch.equal(out[:, n:], feat[:, n:])
