@@ -62,11 +62,15 @@ __device__ __forceinline__ float dot8_bf16(u32x4 a, u32x4 b) {
 }
 
 // =================================== forward ===================================================
-template <typename T, int HD, int QT>
-__global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnP p) {
+// KVB keys per streamed tile: 64, or 128 for long key sequences at head_dim 64 in bf16 (half the barriers per key).
+// OCC = waves per SIMD the kernel is built for: the QT = 1 form fits 128 VGPRs, so FOUR workgroups share a CU — for shapes
+// with few query rows per key (the north-star cross-attention shape: 64 queries x 512 keys per head) every workgroup is a
+// short chain of dependent HBM round trips, and what hides them is more workgroups in flight, not wider tiles.
+template <typename T, int HD, int QT, int KVB = 64, int OCC = 2>
+__global__ __launch_bounds__(ATT_THREADS, OCC) void attn_fwd_kernel(const AttnP p) {
   using TL = ATile<T, HD>;
   constexpr int KF = Mma<T>::KF, NKF = HD / KF, NDT = HD / 16, CT = KF / 16;
-  constexpr int KVB = 64, NKT = KVB / 16, NKP = KVB / KF;
+  constexpr int NKT = KVB / 16, NKP = KVB / KF;
   constexpr int QB = 4 * QT * 16;
   constexpr int BUF = 2 * KVB * TL::RB;                 // one (K tile, V tile) pair
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
@@ -196,7 +200,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(const AttnP p)
         for (int qt = 0; qt < QT; ++qt) o[d][qt] = Mma<T>::mma(va, pb[qt], o[d][qt]);
       }
     }
-    __syncthreads();
+    // (no barrier here: the one at the top of the next iteration is what separates this tile's reads from the DMA that
+    //  refills its buffer two iterations later)
   }
   // ---- epilogue ----
 #pragma unroll
@@ -727,6 +732,17 @@ int launch_fwd(const AttnP& p, hipStream_t s) {
   constexpr int QT = fwd_qt<T>();
   constexpr int QB = 4 * QT * 16;
   dim3 grid((uint32_t)(p.S * ((p.Lq + QB - 1) / QB)), (uint32_t)p.H, (uint32_t)p.P);
+  if constexpr (sizeof(T) == 2 && HD == 64) {
+    if (!p.raw && p.Lq <= 64) {                        // one 16-row query tile per wave, four workgroups per CU
+      const dim3 g1((uint32_t)(p.S * ((p.Lq + 63) / 64)), (uint32_t)p.H, (uint32_t)p.P);
+      hipLaunchKernelGGL((attn_fwd_kernel<T, HD, 1, 64, 4>), g1, dim3(ATT_THREADS), 0, s, p);
+      return DL_OK;
+    }
+    if (!p.raw && p.Lk >= 1024) {                      // long key sequences: 128-key tiles
+      hipLaunchKernelGGL((attn_fwd_kernel<T, HD, QT, 128>), grid, dim3(ATT_THREADS), 0, s, p);
+      return DL_OK;
+    }
+  }
   hipLaunchKernelGGL((attn_fwd_kernel<T, HD, QT>), grid, dim3(ATT_THREADS), 0, s, p);
   return DL_OK;
 }
