@@ -42,6 +42,65 @@ class EmbeddingStore:
         self._finalized = True
         return self
 
+    # ---- on-disk format (replaces the reference's one `.pt` file per entity, handler/dataset.py:119-122,186-195) ----
+    # One file per modality, little endian:
+    #   [0:8)    magic b"DLEMBST1"
+    #   [8:40)   uint32 dtype code (0 = float32, 1 = bfloat16), uint32 feat_dim, uint64 n_entities, uint64 total_rows, uint64 key_bytes
+    #   then     int64 row_offset[n_entities], int32 length[n_entities], the keys as one UTF-8 JSON list (key_bytes), zero padding
+    #            to a 4096-byte boundary, and the rows themselves: total_rows x feat_dim elements, entity after entity.
+    # The row block is read (or memory-mapped) as ONE tensor and goes to the device with a single copy.
+    MAGIC = b"DLEMBST1"
+
+    def save(self, path: str) -> None:
+        import json
+        import struct
+        if self._store is None or self._store.shape[0] != self._rows:
+            self.finalize()
+        keys = list(self._index.keys())
+        if not all(isinstance(k, (int, str)) for k in keys):
+            raise TypeError("EmbeddingStore.save: keys must be int or str")
+        kb = json.dumps(keys).encode("utf-8")
+        offs = np.asarray([self._index[k][0] for k in keys], dtype="<i8")
+        lens = np.asarray([self._index[k][1] for k in keys], dtype="<i4")
+        code = {torch.float32: 0, torch.bfloat16: 1}[self.dtype]
+        head = self.MAGIC + struct.pack("<IIQQQ", code, self.feat_dim, len(keys), self._rows, len(kb))
+        body = head + offs.tobytes() + lens.tobytes() + kb
+        pad = (-len(body)) % 4096
+        rows = self._store.detach().cpu().contiguous()
+        raw = rows.view(torch.int16).numpy() if self.dtype == torch.bfloat16 else rows.numpy()
+        with open(path, "wb") as f:
+            f.write(body + b"\0" * pad)
+            f.write(raw.tobytes())
+
+    @classmethod
+    def load(cls, path: str, device="cuda", mmap: bool = True) -> "EmbeddingStore":
+        import json
+        import struct
+        with open(path, "rb") as f:
+            head = f.read(40)
+            if head[:8] != cls.MAGIC:
+                raise ValueError("EmbeddingStore.load: %s is not an embedding store file" % path)
+            code, feat, n, total, klen = struct.unpack("<IIQQQ", head[8:40])
+            offs = np.frombuffer(f.read(8 * n), dtype="<i8")
+            lens = np.frombuffer(f.read(4 * n), dtype="<i4")
+            keys = json.loads(f.read(klen).decode("utf-8"))
+            start = 40 + 12 * n + klen
+            start += (-start) % 4096
+        dtype = {0: torch.float32, 1: torch.bfloat16}[code]
+        npdt = np.float32 if code == 0 else np.int16
+        arr = np.memmap(path, dtype=npdt, mode="r", offset=start, shape=(total, feat)) if mmap else \
+            np.fromfile(path, dtype=npdt, offset=start).reshape(total, feat)
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if code == 1:
+            t = t.view(torch.bfloat16)
+        st = cls(feat, dtype=dtype, device=device)
+        st._index = {k: (int(o), int(m)) for k, o, m in zip(keys, offs, lens)}
+        st._rows = int(total)
+        st._store = t.to(st.device)
+        st._chunks = [st._store]
+        st._finalized = True
+        return st
+
     @property
     def nbytes(self) -> int:
         return self._rows * self.feat_dim * torch.empty((), dtype=self.dtype).element_size()

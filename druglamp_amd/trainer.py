@@ -398,26 +398,25 @@ class Trainer:
 
     def _agreed(self, kind: str, have: List[int]) -> List[int]:
         """The parameter set every rank reduces for a backward pass of `kind`: the union over ranks of the parameters that
-        received a gradient, agreed on ONCE per kind (one small MAX all-reduce, cached).  A parameter of the set without
-        a local gradient contributes zeros (what DDP's find_unused_parameters does for the reference,
-        trainer.py:147); a gradient outside the cached set means the graph changed and the set is re-agreed — every
-        rank takes the same branch because the decision itself is all-reduced."""
+        received a gradient, agreed on ONCE per kind (one small MAX all-reduce in the first pass of that kind — the only
+        host synchronisation; later steps issue no extra collective).  A parameter of the set without a local gradient
+        contributes zeros (what DDP's find_unused_parameters does for the reference, trainer.py:147); a gradient OUTSIDE
+        the agreed set means the graph changed between steps and raises (ranks must not silently issue different
+        collectives)."""
         n = len(self.flat.params)
         if self._agreed_sets is None:
             self._agreed_sets = {}
         cached = self._agreed_sets.get(kind)
-        flag = torch.zeros(1, dtype=torch.int32, device=self.flat.grads.device)
-        if cached is None or not set(have) <= cached:
-            flag.fill_(1)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag) != 0:
+        if cached is None:
             mask = torch.zeros(n, dtype=torch.int32)
             mask[have] = 1
-            if cached is not None:
-                mask[sorted(cached)] = 1
             mask = mask.to(self.flat.grads.device)
             dist.all_reduce(mask, op=dist.ReduceOp.MAX)
             cached = self._agreed_sets[kind] = frozenset(mask.cpu().nonzero().flatten().tolist())
+        extra = set(have) - cached
+        if extra:
+            raise RuntimeError("Trainer: %d parameters outside the set agreed for '%s' backward passes received a gradient "
+                               "(first: index %d); the graph changed between steps" % (len(extra), kind, min(extra)))
         missing = sorted(cached - set(have))
         if missing:
             torch._foreach_zero_([self.flat.grad_views[i] for i in missing])

@@ -106,3 +106,31 @@ def test_uneven_eval_gather_replica_sync_and_agreed_gradient_set_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_embedding_store_file_roundtrip(tmp_path):
+    """The packed on-disk format of the pre-extracted LLM embeddings (one file per modality instead of the reference's one
+    .pt per entity): save -> load gives the same index and bit-identical rows, for both dtypes and int / str keys."""
+    from druglamp_amd.embedding_store import EmbeddingStore
+    g = torch.Generator().manual_seed(0)
+    for dt, keys in ((torch.bfloat16, [7, 3, 11]), (torch.float32, ["P1", "Q9Y", "x"])):
+        st = EmbeddingStore(16, dtype=dt, device="cpu")
+        embs = [torch.randn(n, 16, generator=g) for n in (5, 1, 9)]
+        for k, e in zip(keys, embs):
+            st.add(k, e)
+        path = str(tmp_path / ("store_%s.bin" % str(dt).split(".")[1]))
+        st.save(path)
+        for mm in (True, False):
+            ld = EmbeddingStore.load(path, device="cpu", mmap=mm)
+            assert ld.dtype == dt and ld.feat_dim == 16 and ld._index == st._index and ld._rows == 15
+            assert torch.equal(ld._store, st._store)
+        ld.add("late", torch.randn(2, 16, generator=g))            # a loaded store can still grow
+        ld.finalize()
+        assert ld._rows == 17 and torch.equal(ld._store[:15], st._store)
+    with open(str(tmp_path / "junk.bin"), "wb") as f:
+        f.write(b"not a store" * 10)
+    try:
+        EmbeddingStore.load(str(tmp_path / "junk.bin"), device="cpu")
+        assert False
+    except ValueError:
+        pass
