@@ -5,6 +5,11 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python3 "$ROOT/bench.py" 2>/dev/null | tail -1 > "$OUT/bench_line.json"
+# strong-scaling operating points of one GPU (per-GPU batch = 256 / N for N = 2, 4, 8): hipGraph-replayed steps
+for b in 128 64 32; do python3 "$ROOT/bench.py" --batch $b --steps 100 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_line_batch$b.json"; done
+# step kinds of configs C3 / C4 (SSL + CM heads active: epoch 5 of DrugLAMP2C2P; SSL epoch of DrugLAMP)
+python3 "$ROOT/bench.py" --model DrugLAMP2C2P --epoch 5 --steps 50 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_line_2c2p_epoch5.json"
+python3 "$ROOT/bench.py" --model DrugLAMP --epoch 5 --steps 50 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_line_druglamp_epoch5.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 > "$OUT/under_rocprof.log" 2>&1
 grep '"metric"' "$OUT/under_rocprof.log" | tail -1 > "$OUT/bench_line_under_rocprof.json"
 T=$(find "$OUT/trace" -name '*kernel_trace.csv' | head -1); S=$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)
