@@ -5,51 +5,52 @@
 //   out[b][i][:] = sum_j A'[b][i][j] * feat[b][j][:]   for the first n nodes (A' = ahat or ahat^T: forward / gradient)
 //   out[b][i][:] = feat[b][i][:]                       for nodes n <= i < N (virtual padding nodes: self loop only)
 //
-// One workgroup per molecule: ahat (n <= 128 real atoms, <= 32 KB in bf16) and the n x C feature block sit in LDS; each of
-// the four waves owns 32 output rows and walks the C columns in 16-wide MFMA tiles.  Fragments are gathered element by
-// element from LDS (the problem is 4 MFLOP per molecule — launch-bound, not worth a transposing tile layout); rows of
-// virtual nodes are copied with 16-byte accesses.
-#include "common.cuh"
+// One workgroup per molecule: ahat (n <= 128 real atoms) and the n x C feature block sit in LDS as swizzled 128-wide tile
+// images; each of the four waves owns 32 output rows and all C columns (8 accumulator tiles), fragments come from the
+// LDS transposing read (features, and the adjacency in the gradient form) or two 8-byte reads (adjacency, forward form).
+// Rows of virtual nodes are copied with 16-byte accesses.  (The first version gathered fragments element by element:
+// 48 us per launch at any batch size, 0.3 ms per step; this one is bound by the launch and the 64 KB tile fill.)
+#include "tiles.cuh"
 
 namespace {
+using namespace dltile;
 
-template <typename T> struct GFrag;
-template <> struct GFrag<bf16_t> {
-  static constexpr int KF = 32, SL = 8;
-  __device__ static __forceinline__ u32x4 pack(const float (&v)[8]) {
-    return u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-  }
-};
-template <> struct GFrag<float> {
-  static constexpr int KF = 16, SL = 4;
-  __device__ static __forceinline__ u32x4 pack(const float (&v)[8]) {
-    return __builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]});
-  }
-};
-
+// Both operands live in LDS as ATile<T, 128> images (128-element rows, 16-byte chunks XOR-swizzled — the layout of the
+// attention kernels), zero outside the n x n / n x C blocks:
+//   Fs[k][c]  = feat[b][k][c]      read as the FIRST MFMA operand F^T[c][k] through the transposing fragment read
+//   As[r][q]  = ahat[b][r][q]      second operand A'^T[k][i]: row i, slots k (two 8-byte reads, CTILE slot map) for the
+//                                  forward form, the transposing read for the gradient form (A' = ahat^T)
+// so that D[c][i] = sum_k F^T[c][k] A'[i][k] leaves every lane with 4 consecutive columns c of one output row i.
 template <typename T, int C>
 __global__ __launch_bounds__(256) void graph_aggregate_kernel(const T* __restrict__ ahat, const T* __restrict__ feat, T* __restrict__ out,
                                                                int n, int N, int transpose) {
-  constexpr int NP = 128;                                  // padded node count of the LDS tiles
-  constexpr int PA = NP + 4 / (int)sizeof(T);               // scalar accesses only: a 65 / 129-dword pitch keeps column walks conflict-free
-  constexpr int PF = C + 16 / (int)sizeof(T);               // rows are written with 16-byte stores: pitch a multiple of 16 bytes
+  static_assert(C == 128, "tile images are 128 elements wide");
+  using TL = ATile<T, 128>;
+  constexpr int NP = 128, EPC = TL::EPC, KF = Mma<T>::KF;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* As = reinterpret_cast<T*>(smem_raw);                  // [NP][PA], zero outside n x n
-  T* Fs = As + NP * PA;                                    // [NP][PF], zero rows >= n
+  char* As = smem_raw;                                      // [NP] rows of TL::RB bytes
+  char* Fs = smem_raw + NP * TL::RB;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 15, g = lane >> 4;
   const T* A = ahat + (int64_t)b * n * n;
   const T* F = feat + (int64_t)b * N * C;
   T* O = out + (int64_t)b * N * C;
-  for (int e = tid; e < NP * NP; e += 256) {
-    const int i = e / NP, j = e % NP;
-    As[i * PA + j] = (i < n && j < n) ? A[(int64_t)i * n + j] : from_f32<T>(0.f);
-  }
-  constexpr int EPC = 16 / (int)sizeof(T);
-  for (int e = tid; e < NP * (C / EPC); e += 256) {
-    const int j = e / (C / EPC), c = (e % (C / EPC)) * EPC;
-    u32x4 w = {0u, 0u, 0u, 0u};
-    if (j < n) w = *reinterpret_cast<const u32x4*>(F + (int64_t)j * C + c);
-    *reinterpret_cast<u32x4*>(Fs + j * PF + c) = w;
+  const bool avec = (n % EPC) == 0 && ((uintptr_t)A & 15) == 0;
+  for (int c = tid; c < NP * TL::CPR; c += 256) {           // 16-byte chunks
+    const int row = c / TL::CPR, ch = c % TL::CPR, col = ch * EPC;
+    u32x4 wa = {0u, 0u, 0u, 0u}, wf = {0u, 0u, 0u, 0u};
+    if (row < n) {
+      wf = *reinterpret_cast<const u32x4*>(F + (int64_t)row * C + col);
+      if (avec) {
+        if (col < n) wa = *reinterpret_cast<const u32x4*>(A + (int64_t)row * n + col);
+      } else {
+        T tmp[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) tmp[e] = (col + e < n) ? A[(int64_t)row * n + col + e] : from_f32<T>(0.f);
+        wa = *reinterpret_cast<const u32x4*>(tmp);
+      }
+    }
+    lds_write16(As, row * TL::RB + ((ch ^ TL::swz(row)) << 4), wa);
+    lds_write16(Fs, row * TL::RB + ((ch ^ TL::swz(row)) << 4), wf);
   }
   // virtual padding nodes: identity
   for (int64_t e = tid; e < (int64_t)(N - n) * (C / EPC); e += 256) {
@@ -57,29 +58,36 @@ __global__ __launch_bounds__(256) void graph_aggregate_kernel(const T* __restric
     *reinterpret_cast<u32x4*>(O + off) = *reinterpret_cast<const u32x4*>(F + off);
   }
   __syncthreads();
-  constexpr int KF = GFrag<T>::KF, SL = GFrag<T>::SL;
   const int nk = (n + KF - 1) / KF;
 #pragma unroll 1
-  for (int it = 0; it < 2; ++it) {                         // two 16-row tiles per wave
+  for (int it = 0; it < 2; ++it) {                          // two 16-row output tiles per wave
     const int i0 = wave * 32 + it * 16;
     if (i0 >= n) break;
-#pragma unroll 1
-    for (int c0 = 0; c0 < C; c0 += 16) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int kf = 0; kf < nk; ++kf) {
-        const int k0 = kf * KF + g * SL;                   // CONTIG slot map: slot s of group g <-> k0 + s
-        float av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[C / 16];
 #pragma unroll
-        for (int s = 0; s < SL; ++s) {
-          av[s] = to_f32(transpose ? As[(k0 + s) * PA + i0 + il] : As[(i0 + il) * PA + k0 + s]);
-          bv[s] = to_f32(Fs[(k0 + s) * PF + c0 + il]);
-        }
-        // D[i][c] = sum_k A'[i][k] feat[k][c]: first operand rows = c (feat^T), second operand columns = i  ->  D^T[c][i];
-        // written the other way round so that a lane ends up with 4 CONSECUTIVE columns c of one row i:
-        acc = Mma<T>::mma(GFrag<T>::pack(bv), GFrag<T>::pack(av), acc);       // lane (il, g): acc[r] = out[i0 + il][c0 + 4g + r]
+    for (int ct = 0; ct < C / 16; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kf = 0; kf < nk; ++kf) {
+      const int kb = kf * KF;
+      u32x4 af;
+      if (transpose) {
+        af = frag_tr<T, 128>(As, kb, i0, il, g);            // A'[i][k] = ahat[k][i]
+      } else if constexpr (sizeof(T) == 2) {
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(As + TL::off(i0 + il, kb + 4 * g));
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(As + TL::off(i0 + il, kb + 16 + 4 * g));
+        af = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      } else {
+        af = lds_read16(As, TL::off(i0 + il, kb + 4 * g));  // f32: CTILE and CONTIG slot maps coincide
       }
-      const int i = i0 + il;
-      if (i < n) store4<T>(O + (int64_t)i * C + c0 + 4 * g, acc);
+#pragma unroll
+      for (int ct = 0; ct < C / 16; ++ct) {
+        const u32x4 ff = frag_tr<T, 128>(Fs, kb, ct * 16, il, g);
+        acc[ct] = Mma<T>::mma(ff, af, acc[ct]);             // lane (il, g): acc[r] = out[i0 + il][ct*16 + 4g + r]
+      }
+    }
+    const int i = i0 + il;
+    if (i < n) {
+#pragma unroll
+      for (int ct = 0; ct < C / 16; ++ct) store4<T>(O + (int64_t)i * C + ct * 16 + 4 * g, acc[ct]);
     }
   }
 }
@@ -96,12 +104,12 @@ extern "C" int dl_graph_aggregate(const void* ahat, const void* feat, void* out,
   DL_CHECK_ARG((((uintptr_t)feat | (uintptr_t)out) & 15) == 0, DL_ERR_ALIGN, "dl_graph_aggregate: feat / out must be 16-byte aligned");
   DL_CHECK_ARG(B <= 0x7fffffff, DL_ERR_SHAPE, "dl_graph_aggregate: batch too large");
   if (dtype == DL_BF16) {
-    const size_t lds = (size_t)128 * (128 + 2) * 2 + (size_t)128 * (128 + 8) * 2;
+    const size_t lds = (size_t)2 * 128 * 128 * 2;
     (void)hipFuncSetAttribute((const void*)graph_aggregate_kernel<bf16_t, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((graph_aggregate_kernel<bf16_t, 128>), dim3((uint32_t)B), dim3(256), lds, s, (const bf16_t*)ahat,
                        (const bf16_t*)feat, (bf16_t*)out, (int)n, (int)N, (int)transpose);
   } else {
-    const size_t lds = (size_t)128 * (128 + 1) * 4 + (size_t)128 * (128 + 4) * 4;
+    const size_t lds = (size_t)2 * 128 * 128 * 4;
     (void)hipFuncSetAttribute((const void*)graph_aggregate_kernel<float, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((graph_aggregate_kernel<float, 128>), dim3((uint32_t)B), dim3(256), lds, s, (const float*)ahat,
                        (const float*)feat, (float*)out, (int)n, (int)N, (int)transpose);
