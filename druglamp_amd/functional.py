@@ -91,11 +91,10 @@ def _refresh_all_images() -> None:
         if tab is None or tab[0] != sig:
             items, bmap = [], []
             for e, ps in lst:
-                total = sum(p.shape[0] for p in ps)
                 row0 = 0
                 for p_ in ps:
-                    r, c = p_.shape
-                    ld = e.image.shape[1]                      # [rows][cols] image, or [cols][rows] when transposed
+                    r, c = p_.shape if p_.dim() == 2 else (1, p_.shape[0])     # a 1-D parameter is one row of the image
+                    ld = e.image.shape[1] if e.image.dim() == 2 else c       # [rows][cols] image, or [cols][rows] when transposed
                     items.append((p_.data_ptr(), e.image.data_ptr(), ld, r, c, row0, 1 if e.transpose else 0))
                     ntile = ((r + 63) // 64) * ((c + 63) // 64)
                     bmap.extend((len(items) - 1, t) for t in range(ntile))
@@ -127,7 +126,9 @@ def lowp(params: Sequence[torch.Tensor], dtype: torch.dtype, transpose: bool = F
         if e.epoch != _param_epoch or e.versions != tuple(p._version for p in params):
             _refresh_all_images()
         return e.image
-    planned = all(p.dim() == 2 and p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda for p in params)
+    planned = all(p.dim() == 2 and p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda for p in params) or \
+        (not transpose and pad is None and len({p.shape for p in params}) == 1 and
+         all(p.dim() == 1 and p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda for p in params))
     if len(_lowp_cache) > 4096:
         _lowp_cache.clear()
         _lowp_tables.clear()
@@ -442,10 +443,11 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
                      v_strides=(Lk * 2 * E, hd, 2 * E), o_strides=(Lq * E, hd, E), o_ss=0, do_strides=(Lq * E, hd, E),
                      do_ss=0, dq=dqp, dq_strides=(Lq * E, hd, E), dk=dkv, dk_strides=(Lk * 2 * E, hd, 2 * E),
                      dv=dkv[:, E:], dv_strides=(Lk * 2 * E, hd, 2 * E))
-        dwq, dbq = _wgrad(dqp, q2, E, E, Lq * B, E, E, want_bias=has_inb)
-        dwkv, dbkv = _wgrad(dkv, k2, 2 * E, E, Lk * B, 2 * E, E, want_bias=has_inb)
-        din_w = torch.cat((dwq, dwkv), dim=0)
-        din_b = torch.cat((dbq, dbkv)) if has_inb else None
+        # in_proj gradient = [dWq ; dWkv] (guided_cross_attention_model.py:146-161): both products write their rows of it
+        din_w = torch.empty((3 * E, E), dtype=torch.float32, device=g.device)
+        din_b = torch.empty(3 * E, dtype=torch.float32, device=g.device) if has_inb else None
+        _wgrad(dqp, q2, E, E, Lq * B, E, E, want_bias=has_inb, out_w=din_w[:E], out_b=None if din_b is None else din_b[:E])
+        _wgrad(dkv, k2, 2 * E, E, Lk * B, 2 * E, E, want_bias=has_inb, out_w=din_w[E:], out_b=None if din_b is None else din_b[E:])
         dquery = ops.gemm(dqp, w[:E], M=Lq * B, N=E, K=E, w_kslow=True, ldw=E).view(B, Lq, E).transpose(0, 1)
         dkey = ops.gemm(dkv, w[E:], M=Lk * B, N=E, K=2 * E, w_kslow=True, ldw=E).view(B, Lk, E).transpose(0, 1)
         return dquery, dkey, din_w, din_b, dwo, dbo, None, None
@@ -564,11 +566,12 @@ def attention_maps(x, blk, H: int, paired: bool):
 # ------------------------------------------------------------------------------------------------
 # loss Functions (fp32)
 # ------------------------------------------------------------------------------------------------
-def _wgrad(g, x, M, N, K, ldx, ldw, want_bias=True):
-    """dW[M][N] = g^T x over the K rows (fp32) and, from the same pass over g, db[M] = column sums of g."""
-    db = torch.empty(M, dtype=torch.float32, device=g.device) if want_bias else None
+def _wgrad(g, x, M, N, K, ldx, ldw, want_bias=True, out_w=None, out_b=None):
+    """dW[M][N] = g^T x over the K rows (fp32) and, from the same pass over g, db[M] = column sums of g.
+    out_w / out_b: write into these (slices of a concatenated gradient) instead of fresh tensors."""
+    db = (out_b if out_b is not None else torch.empty(M, dtype=torch.float32, device=g.device)) if want_bias else None
     dw = ops.gemm(g, x, M=M, N=N, K=K, x_kslow=True, w_kslow=True, ldx=ldx, ldw=ldw, out_dtype=torch.float32,
-                  split_k=0, x_colsum=db)
+                  split_k=0, x_colsum=db, out=out_w)
     return dw, db
 
 
@@ -771,18 +774,21 @@ def _padded_weight(w: torch.Tensor, Np: int, Kp: int, dtype: torch.dtype) -> tor
 
 
 class DenseFn(torch.autograd.Function):
-    """x: [..., Kp] (Kp >= weight.shape[1], extra columns MUST be zero).  Output [..., Np] with
-    Np = ceil8(weight.shape[0]); padded output columns are exactly zero."""
+    """x: [..., Kp] (Kp >= in_features, extra columns MUST be zero).  Output [..., Np] with Np = ceil8(out_features);
+    padded output columns are exactly zero.  weight is [out][in] (nn.Linear), or [in][out] with weight_t=True (the
+    GraphConv weights, basic_model.py:560) — the parameter itself is handed over either way, so its compute-dtype
+    image is cached and refreshed with all others."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act):
+    def forward(ctx, x, weight, bias, residual, act, weight_t=False):
         cdt = x.dtype
-        N, K = weight.shape
+        N, K = (weight.shape[1], weight.shape[0]) if weight_t else weight.shape
         Kp = x.shape[-1]
         Np = (N + 7) // 8 * 8
         x2 = x.reshape(-1, Kp).contiguous()
         M = x2.shape[0]
-        w = _padded_weight(weight, Np, Kp, cdt)
+        # [Np][Kp] image of the [out][in] matrix (for a [in][out] parameter: its transpose, padded before transposing)
+        w = lowp((weight,), cdt, transpose=True, pad=(Kp, Np)) if weight_t else _padded_weight(weight, Np, Kp, cdt)
         b = None
         if bias is not None:
             if N == Np and bias.dtype == torch.float32:
@@ -799,13 +805,13 @@ class DenseFn(torch.autograd.Function):
                 raise NotImplementedError("dense: relu with a residual (the mask could not be read off the output)")
             pre = y                                    # relu'(pre) = [y > 0]
         ctx.save_for_backward(x2, w, pre)
-        ctx.cfg = (x.shape, M, N, K, Np, Kp, bias is not None, residual is not None, act)
+        ctx.cfg = (x.shape, M, N, K, Np, Kp, bias is not None, residual is not None, act, weight_t)
         return y.reshape(*x.shape[:-1], Np)
 
     @staticmethod
     def backward(ctx, dy):
         x2, w, pre = ctx.saved_tensors
-        xshape, M, N, K, Np, Kp, has_bias, has_res, act = ctx.cfg
+        xshape, M, N, K, Np, Kp, has_bias, has_res, act, weight_t = ctx.cfg
         g = dy.reshape(M, Np).contiguous()
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         if act == "relu":
@@ -817,16 +823,16 @@ class DenseFn(torch.autograd.Function):
         want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw, db = _wgrad(g, x2, Np, Kp, M, Np, Kp, want_bias=want_b)
-            dw = dw[:N, :K]
+            dw = dw[:N, :K].t() if weight_t else dw[:N, :K]
             db = db[:N] if want_b else None
         else:
             db = ops.colsum(g)[:N] if want_b else None
-        return dx, dw, db, dres, None
+        return dx, dw, db, dres, None, None
 
 
-def dense(x, weight, bias=None, residual=None, act=False):
+def dense(x, weight, bias=None, residual=None, act=False, weight_t=False):
     """act: False, True (erf GELU, pre-activation saved) or "relu" (fused in the GEMM epilogue)."""
-    return DenseFn.apply(x, weight, bias, residual, act)
+    return DenseFn.apply(x, weight, bias, residual, act, weight_t)
 
 
 class Concat2Fn(torch.autograd.Function):
@@ -996,6 +1002,37 @@ class BatchNormRowsFn(torch.autograd.Function):
         return dx, sums[C:], sums[:C], None, None, None, None, None
 
 
+# nn.BatchNorm1d's num_batches_tracked counters: one `+= 1` launch per BatchNorm layer (nine per DrugLAMP forward) or, inside
+# a `deferred_bn_ticks()` block (the model forwards), ONE multi-tensor add when the block ends.
+_tick_list = None
+
+
+class deferred_bn_ticks:
+    def __enter__(self):
+        global _tick_list
+        self.outer = _tick_list
+        if _tick_list is None:
+            _tick_list = []
+        return self
+
+    def __exit__(self, *exc):
+        global _tick_list
+        if self.outer is None:
+            ticks, _tick_list = _tick_list, None
+            if ticks and exc[0] is None:
+                with torch.no_grad():
+                    torch._foreach_add_(ticks, 1)
+        return False
+
+
+def bn_tick(counter: torch.Tensor) -> None:
+    if _tick_list is not None:
+        _tick_list.append(counter)
+    else:
+        with torch.no_grad():
+            counter += 1
+
+
 def batch_norm_rows(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor) -> torch.Tensor:
     """nn.BatchNorm1d semantics (incl. running statistics, momentum, unbiased running variance)."""
     C = x2d.shape[1]
@@ -1004,8 +1041,7 @@ def batch_norm_rows(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor) -> torch.Tensor
     y, mean, var = BatchNormRowsFn.apply(x2d, w, b, bn.running_mean, bn.running_var, bn.training, bn.eps,
                                          bn.momentum if bn.training else None)
     if bn.training:
-        with torch.no_grad():
-            bn.num_batches_tracked += 1        # running mean / var were updated by dl_bn_finalize
+        bn_tick(bn.num_batches_tracked)        # running mean / var were updated by dl_bn_finalize
     return y
 
 

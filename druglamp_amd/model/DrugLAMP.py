@@ -13,6 +13,10 @@ class DrugLAMP(DrugLAMPBase):
         super().__init__(n_drug_feature, n_prot_feature, n_hidden, **cfg)
 
     def forward(self, vd, vp, xd, xp, mode="train"):
+        with Fn.deferred_bn_ticks():             # the nine BatchNorm step counters advance in one launch at the end
+            return self._forward(vd, vp, xd, xp, mode)
+
+    def _forward(self, vd, vp, xd, xp, mode):
         vd = self.drug_extractor(vd)
         # one pass over each LLM tensor: fill bit + (site-pooled) fill-bit-augmented features, already padded
         # to the GEMM alignment (641 -> 648, 385 -> 392 columns)

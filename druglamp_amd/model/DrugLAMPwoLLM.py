@@ -9,6 +9,10 @@ class DrugLAMPwoLLM(DrugLAMPBase):
         super().__init__(n_drug_feature, n_prot_feature, n_hidden, **cfg)
 
     def forward(self, vd, vp, xd, xp, mode="train"):
+        with Fn.deferred_bn_ticks():             # the nine BatchNorm step counters advance in one launch at the end
+            return self._forward(vd, vp, xd, xp, mode)
+
+    def _forward(self, vd, vp, xd, xp, mode):
         vd = self.drug_extractor(vd)
         fill_p, _ = ops.fill_pool(xp, self.site_len, self.compute_dtype)
         ssl = {"vp": vp, "xp": None, "fill_bit_p": fill_p, "vd": vd, "xd": None, "p_mode": "vp"}

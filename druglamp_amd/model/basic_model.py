@@ -65,7 +65,9 @@ class _GraphConvDense(nn.Module):
         only edge is their self loop (degree 1): for them the normalised aggregation is the identity, so only
         the real-atom block goes through the batched product."""
         agg = Fn.GraphAggregateFn.apply(ahat, feat)
-        return Fn.dense(agg, self.weight.t(), self.bias, act="relu")        # feature transform + ReLU on the HIP GEMM path
+        # feature transform + ReLU on the HIP GEMM path; the (in, out) parameter itself is handed over (weight_t): a
+        # `.t()` view would be a new tensor object per call and miss the weight-image cache every step
+        return Fn.dense(agg, self.weight, self.bias, act="relu", weight_t=True)
 
 
 class _GCNLayerDense(nn.Module):
@@ -166,9 +168,8 @@ class ProteinCNN(nn.Module):
         outs = ProteinCNNFn.apply(x, self.training, self.bn1.eps, fused_pool, momenta, True, *params)
         z = outs[0]
         if self.training:
-            with torch.no_grad():
-                for bn in (self.bn1, self.bn2, self.bn3):
-                    bn.num_batches_tracked += 1    # running mean / var were updated inside (dl_bn_finalize)
+            for bn in (self.bn1, self.bn2, self.bn3):
+                Fn.bn_tick(bn.num_batches_tracked)    # running mean / var were updated inside (dl_bn_finalize)
         if fused_pool:
             return z
         z = z.transpose(1, 2).contiguous().view(B, L, C)                            # (B, C, L) reinterpreted, like the reference

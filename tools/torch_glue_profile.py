@@ -11,7 +11,8 @@ dev = torch.device("cuda", 0)
 cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP")
 model = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
 trainer = Trainer(model, cfg, device=dev, compute_dtype=torch.bfloat16)
-batch, meta = make_batch(256, dev, seed=100, with_graph=True, llm_dtype=torch.bfloat16)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+batch, meta = make_batch(B, dev, seed=100, with_graph=True, llm_dtype=torch.bfloat16)
 for _ in range(3):
     trainer.training_step(batch, meta=meta, cur_epoch=1)
 torch.cuda.synchronize()
@@ -39,5 +40,5 @@ for ev in prof.events():
     agg[key][1] += 1
 tot = sum(v[0] for v in agg.values())
 print("torch-op device time %.2f ms" % (tot / 1e3))
-for k, (us, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+for k, (us, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:90]:
     print("%8.1f us %3d  %-18s %-70s %s" % (us, n, k[0], k[1], k[2]))
