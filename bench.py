@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay cls steps as a hipGraph (auto: per-GPU batch <= 128)")
     ap.add_argument("--no-weak", action="store_true", help="skip the extra weak-scaling measurement at N > 1")
+    ap.add_argument("--seq-len", type=int, default=2304, help="PROTEIN.SEQ_LEN (9216 = 1024 sites: BASELINE config 5, long proteins)")
+    ap.add_argument("--attention", default="native", choices=["native", "fp8"],
+                    help="fp8: PMMA attention forward on MXFP8 MFMA (dl_attn_fwd_fp8; BASELINE config 5)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model", default="DrugLAMP")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,7 +133,9 @@ def main():
     cfg = load_yaml_into(get_cfg_defaults(), args.model)
     if args.global_batch_cm:
         cfg["RS"]["GLOBAL_BATCH"] = True
+    cfg["PROTEIN"]["SEQ_LEN"] = args.seq_len
     model = MInterface(args.model, cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
+    model.pmma.attention_precision = args.attention
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     trainer = Trainer(model, cfg, device=dev, compute_dtype=cdt, graph_steps=use_graph)
     trainer.set_lrs(cfg["SOLVER"]["LR"], cfg["SOLVER"]["SSL_LR"], cfg["SOLVER"]["CM_LR"])
@@ -146,7 +151,8 @@ def main():
 
     def measure(per_gpu_batch, steps, warmup, with_events):
         """W untimed + K timed steps at one per-GPU batch; returns (seconds, max over ranks; family statistics)."""
-        batch, meta = make_batch(per_gpu_batch, dev, seed=100 + rank, with_graph=True, llm_dtype=cdt)
+        batch, meta = make_batch(per_gpu_batch, dev, seed=100 + rank, with_graph=True, llm_dtype=cdt, seq_len=args.seq_len,
+                                 max_prot_len=1022 if args.seq_len <= 2304 else args.seq_len // 2 - 2)
         for _ in range(max(warmup, trainer.graph_warmup + 1 if graphed else 0)):
             trainer.training_step(batch, meta=meta, cur_epoch=ep)
         batch = trainer.static_batch(batch)       # inputs stay resident: the graph's own input tensors (no per-step copy)
@@ -204,15 +210,19 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s training step (%s; fwd+bwd+grad all-reduce+AdamW), BindingDB-shaped synthetic pairs "
-                                   "(512 drug nodes/tokens, 2304 protein tokens, pre-extracted 384-d/640-d LLM embeddings), "
-                                   "global batch %d = %d per GPU x %d%s%s" % (
-                                       args.model, "+".join(kinds) + " step, epoch %d" % ep, args.batch * world, args.batch, world,
+                                   "(512 drug nodes/tokens, %d protein tokens = %d sites, pre-extracted 384-d/640-d LLM embeddings), "
+                                   "global batch %d = %d per GPU x %d%s%s%s" % (
+                                       args.model, "+".join(kinds) + " step, epoch %d" % ep, args.seq_len, args.seq_len // 9,
+                                       args.batch * world, args.batch, world,
                                        ", cls step replayed as a hipGraph" if graphed else "",
-                                       ", CM latents all-gathered (RS.GLOBAL_BATCH)" if args.global_batch_cm else ""),
+                                       ", CM latents all-gathered (RS.GLOBAL_BATCH)" if args.global_batch_cm else "",
+                                       ", PMMA attention forward in MXFP8" if args.attention == "fp8" else ""),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "step_kind": "+".join(kinds), "epoch": ep, "hip_graph": bool(graphed)},
-            "hot_path_tflops_per_gpu": round(value * HOT_FLOPS_PER_PAIR_STEP / world / 1e12, 2),
-            "hot_path_frac_of_peak": round(value * HOT_FLOPS_PER_PAIR_STEP / world / 1e12 / peak, 4),
+                       "step_kind": "+".join(kinds), "epoch": ep, "hip_graph": bool(graphed), "protein_seq_len": args.seq_len,
+                       "attention": args.attention},
+            # (the per-pair flop count of BASELINE.md section 3 is for 256 sites; not applicable to other lengths)
+            "hot_path_tflops_per_gpu": round(value * HOT_FLOPS_PER_PAIR_STEP / world / 1e12, 2) if args.seq_len == 2304 else None,
+            "hot_path_frac_of_peak": round(value * HOT_FLOPS_PER_PAIR_STEP / world / 1e12 / peak, 4) if args.seq_len == 2304 else None,
         }
         if timing and fam_stats["gemm"][0] > 0:
             n, ms, fl, by, n_all, fl_all, by_all = fam_stats["gemm"]
@@ -222,7 +232,8 @@ def main():
             traffic, traffic_source = None, None
             for pmc_name in ("r2_pmc_summary.json", "r1_pmc_summary.json"):
                 pmc = os.path.join(ROOT, "profiles", pmc_name)
-                if os.path.exists(pmc) and args.batch == 256 and args.dtype == "bf16" and args.model == "DrugLAMP" and kinds == ["cls"]:
+                if os.path.exists(pmc) and args.batch == 256 and args.dtype == "bf16" and args.model == "DrugLAMP" and kinds == ["cls"] \
+                        and args.seq_len == 2304 and args.attention == "native":
                     # HBM bytes per dl_gemm launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
                     # workload (tools/pmc_summary.py; x2 gfx950 read correction), committed under profiles/ — a
                     # recorded counter measurement of the same command, NOT re-measured by this run
