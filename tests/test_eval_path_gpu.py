@@ -82,18 +82,22 @@ def test_fit_keeps_best_val_ausum_and_stops_on_patience():
     assert torch.equal(tr.flat.arena, snaps[2]) and not torch.equal(snaps[4], snaps[2])     # best parameters reloaded
 
 
-def test_config2_bf16_eval_scores_at_batch_256_vs_oracle_slice():
-    """The bench's configuration (DrugLAMP, bf16, batch 256, dense graph input): sigmoid scores of 16 samples taken from
-    the batch-256 forward against the fp32 oracle run on those 16 samples alone (eval mode: per-sample independent)."""
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 3e-2), (torch.float32, 1e-4)])
+def test_config2_eval_scores_at_batch_256_vs_oracle_slice(dtype, tol):
+    """The bench's configuration (DrugLAMP, batch 256): scores of 16 samples taken from the batch-256 forward against the
+    fp32 oracle run on those 16 samples alone (eval mode: per-sample independent) — bf16 at the bf16 tolerance, fp32 at the
+    north-star tolerance 1e-4 (the large-tile / many-tile kernel forms only occur at this size)."""
     from druglamp_amd.synthetic import make_batch
-    m, cfg = _model("DrugLAMP", torch.bfloat16)
-    (vd, vp, y, xd, xp), _ = make_batch(256, DEV, seed=21, with_graph=False, llm_dtype=torch.bfloat16)
+    m, cfg = _model("DrugLAMP", dtype)
+    (vd, vp, y, xd, xp), _ = make_batch(256, DEV, seed=21, with_graph=False, llm_dtype=dtype)
     m.eval()
     with torch.no_grad():
         score = m(vd, vp, xd, xp)[4].float().cpu()
     sl = slice(100, 116)
     ref = _oracle_scores(m, "DrugLAMP", vd[sl], vp[sl], xd[sl], xp[sl])
-    assert float((score[sl] - ref).abs().max()) <= 3e-2 * max(1.0, float(ref.abs().max()))
+    assert float((score[sl] - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    if dtype == torch.float32:
+        return
     with torch.no_grad():
         alone = m(vd[sl], vp[sl], xd[sl], xp[sl])[4].float().cpu()
     assert float((alone - score[sl]).abs().max()) <= 2e-2          # batch-size independence of the eval path (bf16 tiles differ)
