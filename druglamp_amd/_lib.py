@@ -41,6 +41,7 @@ class GemmArgs(C.Structure):
         ("x_colsum", c_vp),
         ("dropout_seed_offset", c_vp),
         ("algo", c_i32),
+        ("tile_tickets", c_vp),
     ]
 
 

@@ -42,6 +42,7 @@ struct GemmP {
   char* pre_out; int64_t ldp;
   const char* dact_pre; int64_t lddp;
   uint32_t drop_thr16; float drop_inv_keep; uint64_t seed; const uint64_t* seed_off;
+  int* tickets;   // gemm_big_kernel: dynamic tile hand-out (dl_gemm_args.tile_tickets) or nullptr
   int accumulate;
   float* slabs;   // split mode: [splits][M][N] f32
   float* cs_slabs; // split mode, optional: [splits][M] partial column sums of the K-slow X operand
@@ -805,6 +806,7 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   p.drop_thr16 = a->dropout_p > 0.f ? dl_dropout_thr16(a->dropout_p) : 0u;
   p.drop_inv_keep = a->dropout_p > 0.f ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
   p.seed = a->dropout_seed; p.seed_off = a->dropout_seed_offset;
+  p.tickets = a->tile_tickets;
   p.accumulate = a->accumulate;
   p.slabs = (float*)a->workspace;
   p.cs_slabs = a->x_colsum ? (float*)a->workspace + (size_t)sp * a->M * a->N : nullptr;

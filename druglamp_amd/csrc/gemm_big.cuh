@@ -85,7 +85,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN >= 8 ? NWM * NWN / 4 : 2
   constexpr int SR = (STAGE >= 4096 * NWM * NWN) ? 16 : 8;     // rows per epilogue staging pass
   static_assert(STAGE >= SR * 256 * NWM * NWN, "epilogue slices must fit one stage buffer");
   static_assert(D >= 1 && D <= 3 && PER * D < 64, "prefetch distance");
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
+  // (+16 bytes: the ticket word of the dynamic tile hand-out lives in the SAME shared object — a second __shared__
+  //  variable makes the compiler drain vmcnt before every fragment read of the LDS-DMA pipeline)
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE + 16];
+  volatile uint32_t* ticket_s = reinterpret_cast<volatile uint32_t*>(smem + NSTAGE * STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int il = lane & 15, g = lane >> 4;
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN >= 8 ? NWM * NWN / 4 : 2
 
   const uint32_t ntiles = (uint32_t)p.mt * p.nt;
   const uint32_t G = gridDim.x;
+  const bool dyn = p.tickets != nullptr;
   auto locate = [&](uint32_t it, int& m0, int& n0) {
     const uint32_t round0 = (it / G) * G;
     const uint32_t span = min(G, ntiles - round0);
@@ -196,6 +200,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN >= 8 ? NWM * NWN / 4 : 2
       }
       ++gs;
     };
+    // dynamic hand-out: the ticket of the NEXT tile is drawn while this tile's main loop runs (its latency hides behind
+    // the k-steps; every k-step has a workgroup barrier, so the word is visible to all waves long before it is read)
+    if (dyn && tid == 0) *ticket_s = G + (uint32_t)__hip_atomic_fetch_add(p.tickets, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (DL_DBG(p) & 2) {                   // timing study: no operand feed after the prologue (results are garbage)
       for (int kt = 0; kt < nk; ++kt) kstep(std::false_type{}, kt);
     } else {
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN >= 8 ? NWM * NWN / 4 : 2
 
     // ---- tile end: request the next tile's first stages, then the epilogue --------------------
     const int cm0 = m0, cn0 = n0;
-    const uint32_t itn = it + G;
+    const uint32_t itn = dyn ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*ticket_s) : it + G;
     const bool have_next = itn < ntiles;
     if (have_next) {
       locate(itn, m0, n0);
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN >= 8 ? NWM * NWN / 4 : 2
       for (int s = 0; s < D; ++s)
         if (s < nk) issue(s, (gs + s) % NSTAGE);   // every buffer but the one consumed last is free
     }
-    wg_barrier();                                   // all waves are done reading the last stage buffer
+    wg_barrier();                                   // all waves are done reading the last stage buffer (and the ticket word)
     char* st = smem + ((gs + NSTAGE - 1) % NSTAGE) * STAGE + wave * (SR * 256);
     // pieces of this lane: item = (i, hp, h) -> row m_of(item), columns n_lane .. n_lane + 7
     constexpr int HPI = 16 / SR, HH = SR / 8, NITEM = XF * HPI * HH, PF = 4;
@@ -267,6 +274,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN >= 8 ? NWM * NWN / 4 : 2
     }
     if (!have_next) break;
     it = itn;
+  }
+  // the last workgroup to leave returns the two ticket words to zero for the next launch on the stream
+  if (dyn && tid == 0) {
+    const int gone = __hip_atomic_fetch_add(p.tickets + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone == (int)G - 1) {
+      __hip_atomic_store(p.tickets, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.tickets + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

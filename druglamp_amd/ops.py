@@ -104,12 +104,35 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_kslow=Fa
     a.x_colsum = _ptr(x_colsum)
     a.dropout_seed_offset = _seed_offset_ptr(x.device) if dropout_p > 0 else None
     a.algo = algo
+    a.tile_tickets = _tickets_ptr(x.device)
     nbytes = L.dl_gemm_workspace_bytes(C.byref(a))
     if nbytes:
         ws = _ws.get(nbytes, x.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     check(L.dl_gemm(C.byref(a), _stream()), "dl_gemm")
     return out
+
+
+# Dynamic tile hand-out of the persistent large-tile GEMM (dl_gemm_args.tile_tickets): on while gradient buckets are being
+# all-reduced DURING backward (trainer.GradOverlap), when RCCL channel workgroups occupy some CUs for a while — a CU that
+# starts late then simply takes fewer tiles.  Two int32 per device, zero between launches (the kernel restores them).
+_tickets = {}
+_tickets_on = False
+
+
+def dynamic_tiles(on: bool) -> None:
+    global _tickets_on
+    _tickets_on = bool(on)
+
+
+def _tickets_ptr(device):
+    if not _tickets_on:
+        return None
+    key = (device.type, device.index)
+    t = _tickets.get(key)
+    if t is None:
+        t = _tickets[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return t.data_ptr()
 
 
 def colsum(x2d: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate=False) -> torch.Tensor:

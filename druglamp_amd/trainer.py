@@ -339,15 +339,20 @@ class Trainer:
         # the reference wipes the cls (and ssl) gradients with the next zero_grad before any optimiser steps
         # (header); a backward pass whose gradients nobody consumes is skipped unless asked for
         self.run_dead_backward = os.environ.get("DL_DEAD_BACKWARD", "0") == "1"
-        # "1": bucketed all-reduce from inside backward (GradOverlap); "force": also at world 1 (RCCL sanity runs);
-        # default "0": one reduction after backward.  Off by default because the large-tile GEMMs are persistent with
-        # ONE workgroup per CU (all of its registers and 128 KB of LDS): every CU an RCCL channel workgroup sits on
-        # cannot take its GEMM workgroup until the collective's kernel retires, and with the static tile lists that
-        # GEMM then runs a second round — the 56 MB all-reduce (2-3 % of the step) is not worth that until the tile
-        # lists are handed out dynamically.
-        ov = os.environ.get("DL_GRAD_OVERLAP", "0")
+        # Gradient all-reduce at world > 1.  Default ("1"): bucketed all-reduce from inside backward (GradOverlap) for
+        # eagerly run steps; the persistent large-tile GEMMs then hand their tiles out dynamically (ops.dynamic_tiles):
+        # a CU that an RCCL channel workgroup occupies for a while takes fewer tiles instead of forcing a second round —
+        # the reason overlap was off by default in round 1.  "0": one reduction after backward.  "force": overlap also at
+        # world size 1 (RCCL sanity runs).  hipGraph-replayed steps (graph_steps) always reduce after the replay: hooks
+        # cannot launch collectives from inside a replay, and at the small per-GPU batches where graphs are used the
+        # 5 ms saved on launches outweigh the <= 0.6 ms all-reduce they leave exposed.  UNMEASURED on RCCL with N > 1
+        # (no multi-GPU box was available; two ranks sharing one GPU over gloo: tests/test_grad_overlap_gpu.py).
+        ov = os.environ.get("DL_GRAD_OVERLAP", "1")
         grouped = dist.is_available() and dist.is_initialized()
-        self.overlap = GradOverlap(self.flat) if (self.world > 1 and ov not in ("0", "")) or (ov == "force" and grouped) else None
+        want_overlap = ((self.world > 1 and ov not in ("0", "")) or (ov == "force" and grouped)) and not graph_steps
+        self.overlap = GradOverlap(self.flat) if want_overlap else None
+        if self.overlap is not None:
+            ops.dynamic_tiles(True)      # persistent GEMMs hand their tiles out dynamically while collectives share the CUs
         # hook-driven collectives cannot be launched from inside a graph replay: graphed steps reduce after the replay
         self.graph_steps = bool(graph_steps) and self.overlap is None
         self._graphs: Dict[tuple, GraphedStep] = {}

@@ -85,6 +85,12 @@ typedef struct {
                                         the kernel runs — lets a hipGraph-captured step draw fresh masks per replay */
   int32_t algo;                      /* DL_GEMM_ALGO_AUTO, or DL_GEMM_ALGO_TILE128: never take the 256-wide persistent
                                         kernels (gemm_big.cuh) — outputs are bit-identical either way (tested) */
+  int32_t* tile_tickets;             /* NULL, or a DEVICE array of 2 int32 that is ZERO on entry (and is zero again when the
+                                        launch has finished): the one-workgroup-per-CU persistent kernel then takes its
+                                        tiles beyond the first from an atomic ticket counter instead of a static stride, so
+                                        a CU that starts late — e.g. because an RCCL channel workgroup of an overlapped
+                                        gradient all-reduce was sitting on it — costs its share of tiles, not a second
+                                        round.  Outputs are bit-identical with and without (tested). */
 } dl_gemm_args;
 enum { DL_GEMM_ALGO_AUTO = 0, DL_GEMM_ALGO_TILE128 = 1 };
 

@@ -332,3 +332,43 @@ def test_graph_aggregate_matches_batched_product(dt, tol, n):
         ref = torch.bmm(a, feat[:, :n].double())
         assert float((out[:, :n].double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
         assert torch.equal(out[:, n:], feat[:, n:])
+
+
+@pytest.mark.parametrize("M,N,K", [(49152, 512, 256), (49000, 520, 192), (65536, 1024, 256)])
+def test_dynamic_tile_tickets_leave_the_large_tile_gemm_bitwise_unchanged(M, N, K):
+    """dl_gemm_args.tile_tickets: the persistent one-workgroup-per-CU kernel draws its later tiles from an atomic counter
+    (used while an overlapped all-reduce shares the CUs).  Every output tile is still computed by exactly one workgroup in
+    the same k order: outputs are bit-identical, for each specialised epilogue, over repeated launches (the two ticket
+    words must be back at zero after every launch)."""
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(13)
+    dt = torch.bfloat16
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dt).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.1).to(dt).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to(dt).cuda()
+    pre_in = torch.randn(M, N, generator=g).to(dt).cuda()
+    cases = {"plain": dict(), "gelu+pre+drop": dict(bias=b, act=1, pre_out=True, dropout_p=0.1, seed=5),
+             "dgelu+drop": dict(dact_pre=pre_in, dropout_p=0.1, seed=5), "res": dict(bias=b, residual=res)}
+    try:
+        for name, kw in cases.items():
+            got = {}
+            for dyn in (False, True, True, True):
+                ops.dynamic_tiles(dyn)
+                k2 = dict(kw)
+                pre = None
+                if k2.get("pre_out"):
+                    pre = torch.zeros(M, N, device="cuda", dtype=dt)
+                    k2["pre_out"] = pre
+                out = torch.full((M, N), 7.0, device="cuda", dtype=dt)
+                ops.gemm(x, w, M=M, N=N, K=K, out=out, **k2)
+                torch.cuda.synchronize()
+                if dyn:
+                    assert ops._tickets[("cuda", 0)].tolist() == [0, 0], name
+                    assert torch.equal(out, got[False][0]), name
+                    if pre is not None:
+                        assert torch.equal(pre, got[False][1]), name
+                else:
+                    got[False] = (out, pre)
+    finally:
+        ops.dynamic_tiles(False)
