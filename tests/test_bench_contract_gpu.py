@@ -1,0 +1,47 @@
+"""bench.py's output contract (one JSON line on stdout with the keys the driver reads), on a short run: default workload
+(eager, batch 256) incl. the roofline and cpu_baseline objects, and a graph-replayed small-batch run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=900,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contract_keys():
+    d = _run("--steps", "4", "--warmup", "2", "--cpu-steps", "1")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert d["config"]["global_batch"] == 256 and d["config"]["per_gpu_batch"] == 256 and "workload" in d["config"]
+    assert "model" not in d["config"] and d["config"]["hip_graph"] is False
+    assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "timing_source"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3 and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == "pairs/s"
+
+
+def test_small_batch_line_replays_a_graph_and_says_so():
+    d = _run("--batch", "32", "--steps", "6", "--warmup", "4", "--no-cpu-baseline")
+    assert d["config"]["hip_graph"] is True and d["scaling"] == "weak" and d["config"]["per_gpu_batch"] == 32
+    assert "EAGER" in d["roofline"]["timing_source"] and "cpu_baseline" not in d
