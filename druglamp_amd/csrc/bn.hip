@@ -156,6 +156,116 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restric
   }
   store4<T>(dy + r * C + c, o);
 }
+
+// ---- wide forms of the two apply passes (bf16, C in {64, 128, 256}) -------------------------------------------------
+// A thread keeps ONE 8-column chunk (16 bytes) for the whole launch, so the per-column parameters are loaded and folded
+// once (z = y * a + b with a = rstd * gamma, b = beta - mean * a); it walks rows with a grid stride, BN_WIDE_U rows in
+// flight per iteration.  The one-quad-per-thread forms above spend more instructions on index arithmetic and the halo
+// test (a 32-bit modulo per 8 bytes) than on the data: 3.2 / 4.0 TB/s; these: see tools/ln_bench.py.
+constexpr int BN_WIDE_U = 4;
+__device__ __forceinline__ void unpack8(u32x4 w, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo(w[i]); f[2 * i + 1] = bf16hi(w[i]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  return u32x4{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void bn_apply_fwd_wide_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ z,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                int R, int win, int halo, int valid) {
+  constexpr int TPR = C / 8, RPB = 256 / TPR;              // threads per row, rows per block and pass
+  const int c = (threadIdx.x % TPR) * 8, rsub = threadIdx.x / TPR;
+  float a[8], b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = rstd[c + e] * gamma[c + e]; b[e] = beta[c + e] - mean[c + e] * a[e]; }
+  const int stride = gridDim.x * RPB;
+  for (int r0 = blockIdx.x * RPB + rsub; r0 < R; r0 += stride * BN_WIDE_U) {
+    u32x4 w[BN_WIDE_U];
+    bool ok[BN_WIDE_U];
+#pragma unroll
+    for (int u = 0; u < BN_WIDE_U; ++u) {
+      const int r = r0 + u * stride;
+      ok[u] = r < R && row_valid(r, win, halo, valid);
+      w[u] = u32x4{0u, 0u, 0u, 0u};
+      if (ok[u]) w[u] = *reinterpret_cast<const u32x4*>(y + (int64_t)r * C + c);
+    }
+#pragma unroll
+    for (int u = 0; u < BN_WIDE_U; ++u) {
+      const int r = r0 + u * stride;
+      if (r >= R) break;
+      u32x4 o = {0u, 0u, 0u, 0u};                         // halo rows are written as zeros (the next conv's padding)
+      if (ok[u]) {
+        float f[8];
+        unpack8(w[u], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], a[e], b[e]);
+        o = pack8(f);
+      }
+      *reinterpret_cast<u32x4*>(z + (int64_t)r * C + c) = o;
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void bn_bwd_apply_wide_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                                float inv_n, int relu_mask, bf16_t* __restrict__ dy, int R, int win,
+                                                                int halo, int valid) {
+  constexpr int TPR = C / 8, RPB = 256 / TPR;
+  const int c = (threadIdx.x % TPR) * 8, rsub = threadIdx.x / TPR;
+  // dy = g*rs*(d - s0/n - yhat*s1/n), yhat = (y - mu)*rs   ->   dy = k0*d + k1*y + k2 per column
+  float mu[8], rs[8], gr[8], m0[8], m1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = mean[c + e]; rs[e] = rstd[c + e]; gr[e] = gamma[c + e] * rs[e];
+    m0[e] = sums[c + e] * inv_n; m1[e] = sums[C + c + e] * inv_n;
+  }
+  const int stride = gridDim.x * RPB;
+  for (int r0 = blockIdx.x * RPB + rsub; r0 < R; r0 += stride * BN_WIDE_U) {
+    u32x4 wd[BN_WIDE_U], wy[BN_WIDE_U];
+    bool ok[BN_WIDE_U];
+#pragma unroll
+    for (int u = 0; u < BN_WIDE_U; ++u) {
+      const int r = r0 + u * stride;
+      ok[u] = r < R && row_valid(r, win, halo, valid);
+      wd[u] = u32x4{0u, 0u, 0u, 0u}; wy[u] = wd[u];
+      if (ok[u]) {
+        wd[u] = *reinterpret_cast<const u32x4*>(dz + (int64_t)r * C + c);
+        wy[u] = *reinterpret_cast<const u32x4*>(y + (int64_t)r * C + c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BN_WIDE_U; ++u) {
+      const int r = r0 + u * stride;
+      if (r >= R) break;
+      u32x4 o = {0u, 0u, 0u, 0u};
+      if (ok[u]) {
+        float d[8], yv[8];
+        unpack8(wd[u], d);
+        unpack8(wy[u], yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float yh = (yv[e] - mu[e]) * rs[e];                  // same operation order as bn_bwd_apply_kernel
+          float v = gr[e] * (d[e] - m0[e] - yh * m1[e]);
+          if (relu_mask) v = yv[e] > 0.f ? v : 0.f;
+          d[e] = v;
+        }
+        o = pack8(d);
+      }
+      *reinterpret_cast<u32x4*>(dy + (int64_t)r * C + c) = o;
+    }
+  }
+}
+
+static inline uint32_t bn_wide_blocks(int64_t R, int C) {
+  const int rpb = 256 / (C / 8);
+  int64_t b = (R + (int64_t)rpb * BN_WIDE_U - 1) / ((int64_t)rpb * BN_WIDE_U);
+  return (uint32_t)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
 }  // namespace
 
 extern "C" size_t dl_bn_workspace_bytes(int64_t R, int64_t C) {
@@ -212,7 +322,13 @@ extern "C" int dl_bn_apply_fwd(const void* y, void* z, const float* mean, const 
                "dl_bn_apply_fwd: bad args");
   const int64_t n = R * (C / 4);
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
-  if (dtype == DL_BF16)
+  const bool wide = dtype == DL_BF16 && (C == 64 || C == 128 || C == 256) && (((uintptr_t)y | (uintptr_t)z) & 15) == 0;
+  if (wide) {
+    const uint32_t wb = bn_wide_blocks(R, (int)C);
+    if (C == 64) hipLaunchKernelGGL((bn_apply_fwd_wide_kernel<64>), dim3(wb), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean, rstd, gamma, beta, (int)R, (int)win, (int)halo, (int)valid);
+    else if (C == 128) hipLaunchKernelGGL((bn_apply_fwd_wide_kernel<128>), dim3(wb), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean, rstd, gamma, beta, (int)R, (int)win, (int)halo, (int)valid);
+    else hipLaunchKernelGGL((bn_apply_fwd_wide_kernel<256>), dim3(wb), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean, rstd, gamma, beta, (int)R, (int)win, (int)halo, (int)valid);
+  } else if (dtype == DL_BF16)
     hipLaunchKernelGGL((bn_apply_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean,
                        rstd, gamma, beta, R, (int)C, win, halo, valid);
   else
@@ -231,7 +347,13 @@ extern "C" int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean,
                "dl_bn_bwd_apply: bad args");
   const int64_t n = R * (C / 4);
   const uint32_t blocks = (uint32_t)((n + 255) / 256);
-  if (dtype == DL_BF16)
+  const bool wide = dtype == DL_BF16 && (C == 64 || C == 128 || C == 256) && (((uintptr_t)y | (uintptr_t)dz | (uintptr_t)dy) & 15) == 0;
+  if (wide) {
+    const uint32_t wb = bn_wide_blocks(R, (int)C);
+    if (C == 64) hipLaunchKernelGGL((bn_bwd_apply_wide_kernel<64>), dim3(wb), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, (int)R, (int)win, (int)halo, (int)valid);
+    else if (C == 128) hipLaunchKernelGGL((bn_bwd_apply_wide_kernel<128>), dim3(wb), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, (int)R, (int)win, (int)halo, (int)valid);
+    else hipLaunchKernelGGL((bn_bwd_apply_wide_kernel<256>), dim3(wb), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, (int)R, (int)win, (int)halo, (int)valid);
+  } else if (dtype == DL_BF16)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y,
                        mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, R, (int)C, win, halo, valid);
   else
