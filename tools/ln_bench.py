@@ -31,3 +31,35 @@ tba = t(lambda: ops.bn_bwd_apply(dz, y, mean, rstd, gm, s2, 1.0 / (256 * 2304), 
 by = R * C * 2
 print("BN %d x %d: stats %.1f us (%.2f TB/s)  apply %.1f us (%.2f TB/s)  bwd_reduce %.1f us (%.2f TB/s)  bwd_apply %.1f us (%.2f TB/s)" % (
     R, C, ts, by / ts / 1e6, ta, 2 * by / ta / 1e6, tr, 2 * by / tr / 1e6, tba, 3 * by / tba / 1e6))
+# ---- other elementwise passes of the step --------------------------------------------------------------------------
+M, D = 65536, 512
+x = torch.randn(M, D, device=dev).to(dt); pre = torch.randn(M, 4 * D, device=dev).to(dt); dyb = torch.randn(M, 4 * D, device=dev).to(dt)
+td = t(lambda: ops.dropout_apply(x, 0.1, 5))
+print("dropout_apply %d x %d: %.1f us (%.2f TB/s)" % (M, D, td, 2 * M * D * 2 / td / 1e6))
+tg = t(lambda: ops.gelu_bwd(dyb[:, :1024].contiguous(), pre[:, :1024].contiguous()))
+print("gelu_bwd (+2 copies) %d x 1024: %.1f us" % (M, tg))
+a = torch.randn(2, M, 256, device=dev).to(dt)
+ti = t(lambda: ops.interleave_streams(a)); ti2 = t(lambda: ops.interleave_streams(a.reshape(M, 512).contiguous().reshape(1, M, 512)[0], inverse=True))
+print("interleave_streams 2 x %d x 256: %.1f us (%.2f TB/s), inverse %.1f us" % (M, ti, 2 * a.numel() * 2 / ti / 1e6, ti2))
+p1 = torch.randn(M, 128, device=dev).to(dt); p2 = torch.randn(M, 128, device=dev).to(dt)
+tc = t(lambda: ops.concat2(p1, p2))
+print("concat2 %d x (128 | 128): %.1f us (%.2f TB/s)" % (M, tc, 2 * (p1.numel() + p2.numel()) * 2 / tc / 1e6))
+v = torch.randn(256, 256, 256, device=dev).to(dt); lg = torch.randn(256, 256, 8, device=dev).to(dt)
+out, gate = ops.token_gate_fwd(v, lg, 8, True)
+tgf = t(lambda: ops.token_gate_fwd(v, lg, 8, True)); tgb = t(lambda: ops.token_gate_bwd(out, v, gate, 8, True))
+print("token_gate fwd %.1f us (%.2f TB/s)  bwd %.1f us (%.2f TB/s)" % (tgf, 2 * v.numel() * 2 / tgf / 1e6, tgb, 3 * v.numel() * 2 / tgb / 1e6))
+xf = torch.randn(14_000_000, device=dev); gf = torch.randn_like(xf); m1 = torch.zeros_like(xf); m2 = torch.zeros_like(xf)
+tad = t(lambda: ops.adamw_step(xf, gf, m1, m2, lr=1e-4, step=3))
+print("adamw 14M params: %.1f us (%.2f TB/s)" % (tad, 28 * xf.numel() / tad / 1e6))
+xc = torch.randn(M, 512, device=dev)
+tcast = t(lambda: ops.cast(xc, dt))
+print("cast f32->bf16 %d x 512: %.1f us (%.2f TB/s)" % (M, tcast, 6 * xc.numel() / tcast / 1e6))
+z = torch.randn(256, 2312, 128, device=dev).to(dt)
+tsp = t(lambda: ops.cnn_sitepool_fwd(z, 2304, 4, 9)); pooled = ops.cnn_sitepool_fwd(z, 2304, 4, 9); tsb = t(lambda: ops.cnn_sitepool_bwd(pooled, 2304, 4, 9))
+print("cnn_sitepool fwd %.1f us (%.2f TB/s)  bwd %.1f us (%.2f TB/s)" % (tsp, z.numel() * 2 / tsp / 1e6, tsb, z.numel() * 2 / tsb / 1e6))
+xp = torch.randn(256, 2304, 640, device=dev).to(dt)
+tfp = t(lambda: ops.fill_pool(xp, 9, dt))
+print("fill_pool 256 x 2304 x 640: %.1f us (%.2f TB/s)" % (tfp, xp.numel() * 2 / tfp / 1e6))
+pe = torch.randn(256, 256, device=dev).to(dt); xr = torch.randn(M, 256, device=dev).to(dt)
+tar = t(lambda: ops.add_rowmod_dropout(xr, pe, 0.1, 3)); trs = t(lambda: ops.rowmod_sum(xr, 256))
+print("add_rowmod_dropout %.1f us (%.2f TB/s)  rowmod_sum %.1f us (%.2f TB/s)" % (tar, 2 * xr.numel() * 2 / tar / 1e6, trs, xr.numel() * 2 / trs / 1e6))
