@@ -470,7 +470,9 @@ __global__ __launch_bounds__(ATT_THREADS, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k
 #pragma unroll
       for (int kf = 0; kf < NKF; ++kf) dof[qt][kf] = frag_global<T>(dOb + (int64_t)q * p.do_rs, ok, kf, g);
       lse2[qt] = ok ? p.LSE[statbase + q] * LOG2E : INFINITY;
-      if constexpr (RES && sizeof(T) == 2) {
+      if constexpr (sizeof(T) == 2) {
+        // Delta = sum_d dO * O from the dO fragments this kernel holds anyway (written out for the dK/dV kernel that
+        // follows on the stream): no separate Delta launch in the bf16 pipelines
         const T* Ob = reinterpret_cast<const T*>(p.O) + (int64_t)seg * p.o_ss + (int64_t)pa * p.o_ps + (int64_t)h * p.o_hs;
         float part = 0.f;
 #pragma unroll
@@ -763,7 +765,7 @@ int launch_bwd(const AttnP& p, hipStream_t s) {
       return DL_OK;
     }
   }
-  {
+  if constexpr (sizeof(T) != 2) {                       // fp32 pipelines: Delta by its own pass (bf16: inside the dQ kernel)
     const int64_t rows = (int64_t)p.S * p.P * p.H * p.Lq;
     hipLaunchKernelGGL((attn_delta_kernel<T, HD>), dim3((uint32_t)((rows + 15) / 16)), dim3(256), 0, s, p);
   }
