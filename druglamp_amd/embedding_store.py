@@ -90,13 +90,17 @@ class EmbeddingStore:
         npdt = np.float32 if code == 0 else np.int16
         arr = np.memmap(path, dtype=npdt, mode="r", offset=start, shape=(total, feat)) if mmap else \
             np.fromfile(path, dtype=npdt, offset=start).reshape(total, feat)
-        t = torch.from_numpy(np.ascontiguousarray(arr))
-        if code == 1:
-            t = t.view(torch.bfloat16)
         st = cls(feat, dtype=dtype, device=device)
         st._index = {k: (int(o), int(m)) for k, o, m in zip(keys, offs, lens)}
         st._rows = int(total)
-        st._store = t.to(st.device)
+        # the row block goes to the device in slices of <= 256 MB: a memory-mapped file of hundreds of GB never has to be
+        # resident in host memory as a whole
+        dst = torch.empty((total, feat), dtype=dtype, device=st.device)
+        rows_per = max(1, (256 << 20) // max(1, feat * arr.dtype.itemsize))
+        for r0 in range(0, int(total), rows_per):
+            piece = torch.from_numpy(np.ascontiguousarray(arr[r0:r0 + rows_per]))
+            dst[r0:r0 + rows_per].copy_(piece.view(torch.bfloat16) if code == 1 else piece)
+        st._store = dst
         st._chunks = [st._store]
         st._finalized = True
         return st
