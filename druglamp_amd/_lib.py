@@ -21,6 +21,20 @@ DL_F32, DL_BF16 = 0, 1
 c_i64, c_i32, c_f32, c_u64, c_vp, c_sz = C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_void_p, C.c_size_t
 
 
+class ReduceItem(C.Structure):
+    """dl_reduce_item: a pending second-stage reduction (include/druglamp_hip.h)."""
+    _fields_ = [
+        ("kind", c_i32), ("out_dtype", c_i32),
+        ("src", c_vp), ("out", c_vp),
+        ("mn", c_i64), ("ldc", c_i64),
+        ("N", c_i32), ("splits", c_i32), ("accumulate", c_i32), ("M", c_i32),
+        ("cs_slabs", c_vp), ("cs_out", c_vp),
+    ]
+
+
+REDUCE_BATCH_MAX = 24
+
+
 class GemmArgs(C.Structure):
     _fields_ = [
         ("X", c_vp), ("ldx", c_i64), ("x_kslow", c_i32),
@@ -42,6 +56,7 @@ class GemmArgs(C.Structure):
         ("dropout_seed_offset", c_vp),
         ("algo", c_i32),
         ("tile_tickets", c_vp),
+        ("deferred", C.POINTER(ReduceItem)),
     ]
 
 
@@ -85,6 +100,7 @@ SIGNATURES = {
     "dl_version": (c_i32, []),
     "dl_gemm_workspace_bytes": (c_sz, [C.POINTER(GemmArgs)]),
     "dl_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "dl_reduce_batch": (c_i32, [C.POINTER(ReduceItem), c_i32, c_vp]),
     "dl_colsum": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "dl_colsum_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "dl_bn_workspace_bytes": (c_sz, [c_i64, c_i64]),
@@ -96,7 +112,7 @@ SIGNATURES = {
     "dl_layernorm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "dl_layernorm_bwd_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "dl_layernorm_bwd": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
-                                 c_i32, c_i64, c_i64, c_i32, c_vp, c_sz, c_vp]),
+                                 c_i32, c_i64, c_i64, c_i32, c_vp, c_sz, C.POINTER(ReduceItem), c_vp]),
     "dl_attn_fwd": (c_i32, [C.POINTER(AttnFwdArgs), c_vp]),
     "dl_attn_bwd": (c_i32, [C.POINTER(AttnBwdArgs), c_vp]),
     "dl_attn_fwd_fp8_workspace_bytes": (c_sz, [C.POINTER(AttnFwdArgs)]),

@@ -584,6 +584,44 @@ bool big_eligible(const dl_gemm_args* a, const GemmP& p, int sp) {
   return tiles >= 192;
 }
 int big_cfg() { return dl_study_env("DL_GEMM_BIGCFG", 0); }
+// Few-tile ("latency") form of the same kernel: a 128x128 tile per 4-wave workgroup with a DEEP stage ring.  When the
+// whole output is at most a round or two of tiles (strong-scaling batches: M = 8192 ... 32768 rows) every workgroup walks
+// its k-steps alone on its CU, and gemm_kernel's two-buffer ring pays one full memory round trip per k-step; three
+// steps in flight divide that by three.  Returns the variant (0 = not eligible).
+int lat_cfg() { return dl_study_env("DL_GEMM_LATCFG", 1); }
+int lat_eligible(const dl_gemm_args* a, const GemmP& p, int sp) {
+  const int cfg = lat_cfg();
+  if (cfg == 0 || a->algo == DL_GEMM_ALGO_TILE128) return 0;
+  if (sp > 1 || a->in_dtype != DL_BF16 || a->out_dtype != DL_BF16 || a->x_kslow || a->w_kslow) return 0;
+  if (pick_epi(p, false) == 1) return 0;
+  // measured (tools/latency_gemm_bench.py, M = 8192 / 16384 / 32768): 10-25 % faster than the two-buffer ring when the
+  // tiles fit ONE round of one-workgroup-per-CU and there are >= 8 k-steps; with two rounds, or at K = 256, the
+  // two-workgroups-per-CU ring of gemm_kernel wins
+  if (a->K % 64 != 0 || a->K < dl_study_env("DL_GEMM_LATMINK", 512) || a->N < 128) return 0;
+  const int64_t tiles = ((a->M + 127) / 128) * ((a->N + 127) / 128);
+  if (tiles > dl_study_env("DL_GEMM_LATMAX", 256)) return 0;
+  return cfg;
+}
+void launch_lat(const GemmP& p, hipStream_t s, int cfg) {
+  const uint32_t ntiles = (uint32_t)p.mt * p.nt;
+#define DL_LAT_SW(XF_, RB_, NS_, WGS_)                                                                              \
+  {                                                                                                                  \
+    const uint32_t nblocks = ntiles < (WGS_) ? ntiles : (WGS_);                                                      \
+    switch (pick_epi(p, false)) {                                                                                    \
+      case 0: hipLaunchKernelGGL((gemm_big_kernel<XF_, 2, 2, RB_, NS_, 0>), dim3(nblocks), dim3(256), 0, s, p); break; \
+      case 2: hipLaunchKernelGGL((gemm_big_kernel<XF_, 2, 2, RB_, NS_, 2>), dim3(nblocks), dim3(256), 0, s, p); break; \
+      case 3: hipLaunchKernelGGL((gemm_big_kernel<XF_, 2, 2, RB_, NS_, 3>), dim3(nblocks), dim3(256), 0, s, p); break; \
+      case 4: hipLaunchKernelGGL((gemm_big_kernel<XF_, 2, 2, RB_, NS_, 4>), dim3(nblocks), dim3(256), 0, s, p); break; \
+      default: hipLaunchKernelGGL((gemm_big_kernel<XF_, 2, 2, RB_, NS_, 5>), dim3(nblocks), dim3(256), 0, s, p); break; \
+    }                                                                                                                \
+  }
+#ifdef DL_STUDY
+  if (cfg == 2) { DL_LAT_SW(4, 128, 3, 256u); return; }       // 96 KB ring, one workgroup per CU
+  if (cfg == 3) { DL_LAT_SW(4, 64, 4, 512u); return; }        // 64-byte rows: 64 KB ring, two workgroups per CU
+#endif
+  DL_LAT_SW(4, 128, 4, 256u);                                 // 128 KB ring, one workgroup per CU, three steps in flight
+#undef DL_LAT_SW
+}
 void launch_big(const GemmP& p, hipStream_t s) {
   const uint32_t ntiles = (uint32_t)p.mt * p.nt;
   const int cfg = big_cfg();
@@ -822,6 +860,9 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   } else if (big_eligible(a, p, sp)) {
     p.mt = (int)((a->M + 255) / 256); p.nt = (int)((a->N + (big_cfg() == 1 ? 127 : 255)) / (big_cfg() == 1 ? 128 : 256));
     launch_big(p, s);
+  } else if (const int lat = lat_eligible(a, p, sp)) {
+    p.mt = (int)((a->M + 127) / 128); p.nt = (int)((a->N + 127) / 128);
+    launch_lat(p, s, lat);
   } else if (a->in_dtype == DL_BF16) {
     if (slab_path) rc = dispatch_layout<bf16_t, float, true>(a, p, s, tw);
     else if (a->out_dtype == DL_F32) rc = dispatch_layout<bf16_t, float, false>(a, p, s, tw);
@@ -840,6 +881,14 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   }
   if (slab_path) {
     const int64_t mn = a->M * a->N;
+    if (a->deferred) {
+      dl_reduce_item& it = *a->deferred;
+      it.kind = DL_REDUCE_SPLITK; it.out_dtype = a->out_dtype;
+      it.src = (const float*)a->workspace; it.out = a->C; it.mn = mn; it.ldc = a->ldc; it.N = (int32_t)a->N;
+      it.splits = sp; it.accumulate = a->accumulate; it.M = a->x_colsum ? (int32_t)a->M : 0;
+      it.cs_slabs = p.cs_slabs; it.cs_out = a->x_colsum;
+      return DL_OK;
+    }
     const int threads = 256;
     const int64_t blocks = (mn / 4 + threads - 1) / threads;
     const int64_t cs_blocks = a->x_colsum ? (a->M + threads - 1) / threads : 0;   // column sums ride along
@@ -852,6 +901,8 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
                          (const float*)a->workspace, (bf16_t*)a->C, mn, a->ldc, (int)a->N, sp,
                          a->accumulate, (const float*)p.cs_slabs, a->x_colsum, (int)a->M, (uint32_t)blocks);
     DL_CHECK_LAUNCH("dl_gemm(split reduce)");
+  } else if (a->deferred) {
+    a->deferred->kind = DL_REDUCE_NONE;
   }
   return DL_OK;
 }

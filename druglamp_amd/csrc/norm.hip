@@ -209,8 +209,9 @@ extern "C" int dl_layernorm_bwd(const void* dy, int64_t lddy, int64_t dy_share, 
                                 const float* mean, const float* rstd, const float* gamma,
                                 const void* dres, int64_t lddres, void* dx, int64_t lddx, float* dgamma,
                                 float* dbeta, int32_t accumulate, int64_t M, int64_t D, int32_t dtype,
-                                void* workspace, size_t workspace_bytes, dl_stream stream) {
+                                void* workspace, size_t workspace_bytes, dl_reduce_item* deferred, dl_stream stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (deferred) deferred->kind = DL_REDUCE_NONE;
   DL_CHECK_ARG(dy && x && mean && rstd && gamma && dx, DL_ERR_ARG, "dl_layernorm_bwd: null pointer");
   DL_CHECK_ARG(dy_share >= 1, DL_ERR_ARG, "dl_layernorm_bwd: dy_share=%ld must be >= 1", (long)dy_share);
   DL_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, DL_ERR_SHAPE,
@@ -227,6 +228,13 @@ extern "C" int dl_layernorm_bwd(const void* dy, int64_t lddy, int64_t dy_share, 
   else { if (nvg <= 1) LN_BWD(float, 1); else if (nvg <= 2) LN_BWD(float, 2); else if (nvg <= 4) LN_BWD(float, 4); else LN_BWD(float, 8); }
 #undef LN_BWD
   DL_CHECK_LAUNCH("dl_layernorm_bwd");
+  if (dgamma && dbeta == dgamma + D && deferred) {
+    dl_reduce_item& it = *deferred;
+    it.kind = DL_REDUCE_PARTIALS; it.out_dtype = DL_F32; it.src = (const float*)workspace; it.out = dgamma;
+    it.mn = 2 * D; it.ldc = 0; it.N = (int32_t)(2 * D); it.splits = nb; it.accumulate = accumulate; it.M = 0;
+    it.cs_slabs = nullptr; it.cs_out = nullptr;
+    return DL_OK;
+  }
   if (dgamma && dbeta == dgamma + D) {
     // adjacent outputs ([2][D]): the partials' [2][D] rows reduce in one launch
     hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((2 * D + DL_REDUCE_COLS - 1) / DL_REDUCE_COLS)), dim3(1024), 0, s,

@@ -14,6 +14,7 @@ Reference semantics restated here (see oracle/druglamp_oracle.py for the plain-t
 """
 from __future__ import annotations
 
+import functools
 import math
 import weakref
 from typing import List, Optional, Sequence
@@ -26,6 +27,16 @@ from . import ops
 # compute-dtype copies of fp32 master parameters, cached per optimiser epoch
 # ------------------------------------------------------------------------------------------------
 _param_epoch = 0
+def _deferring(fn):
+    """Backward passes whose split-K / LayerNorm second-stage reductions leave in one dl_reduce_batch launch at the end
+    (ops.deferred_reductions): legal because these passes never read the gradients they produce, they only return them."""
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with ops.deferred_reductions():
+            return fn(*a, **k)
+    return wrapped
+
+
 _lowp_cache = {}            # key -> _LowpEntry
 _lowp_tables = {}           # (device, dtype) -> (signature, items_dev, block_map_dev, n_blocks)
 _derived_cache = {}         # conv-weight layouts etc.: recomputed per optimiser epoch (small)
@@ -230,6 +241,7 @@ class TransformerBlockFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_deferring
     def backward(ctx, dout):
         paired, H, p_eff, S, B, L, d, seeds = ctx.cfg
         sv = ctx.saved_tensors
@@ -429,6 +441,7 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
         return y.view(B, Lq, E).transpose(0, 1), raw
 
     @staticmethod
+    @_deferring
     def backward(ctx, dy, _draw):
         q2, k2, w, qp, kv, o, lse, ow = ctx.saved_tensors
         Lq, Lk, B, E, H, scale, has_inb, has_outb = ctx.cfg
@@ -477,6 +490,7 @@ class TokenGateFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_deferring
     def backward(ctx, dout):
         v2, lw1, lw2, pre, hid, gate = ctx.saved_tensors
         B, L, D, H, dd, add_residual = ctx.cfg

@@ -5,6 +5,7 @@ on a HIP device and the shared library must be present.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 from typing import Optional
@@ -106,11 +107,59 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_kslow=Fa
     a.algo = algo
     a.tile_tickets = _tickets_ptr(x.device)
     nbytes = L.dl_gemm_workspace_bytes(C.byref(a))
+    item = None
     if nbytes:
-        ws = _ws.get(nbytes, x.device)
+        if _pending is not None and not accumulate:
+            # inside deferred_reductions(): the slabs get a buffer of their own (it has to outlive the batched launch) and
+            # the reduction is queued instead of launched
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            item = _lib.ReduceItem()
+            a.deferred = C.pointer(item)
+        else:
+            if _pending:
+                flush_reductions()          # an accumulating reduction must see every earlier write to its output
+            ws = _ws.get(nbytes, x.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     check(L.dl_gemm(C.byref(a), _stream()), "dl_gemm")
+    if item is not None and item.kind != 0:
+        _pending.append((item, ws, out, x_colsum))
     return out
+
+
+# Deferred second-stage reductions (dl_reduce_item / dl_reduce_batch): inside `with deferred_reductions():` every split-K
+# GEMM (and LayerNorm backward) only writes its partial results; the reductions leave together, DL_REDUCE_BATCH_MAX per
+# launch, when the block ends.  NOTHING inside the block may read an output of those calls — the backward passes that use
+# it only hand the gradients back to autograd.
+_pending = None
+
+
+@contextlib.contextmanager
+def deferred_reductions():
+    global _pending
+    if _pending is not None:            # nested: the outermost block flushes
+        yield
+        return
+    _pending = []
+    try:
+        yield
+    finally:
+        try:
+            flush_reductions()
+        finally:
+            _pending = None
+
+
+def flush_reductions() -> None:
+    """Launch what is queued (keeps the deferred mode, if any, active)."""
+    if not _pending:
+        return
+    L = _lib.lib()
+    todo = list(_pending)
+    del _pending[:]
+    for i in range(0, len(todo), _lib.REDUCE_BATCH_MAX):
+        part = todo[i:i + _lib.REDUCE_BATCH_MAX]
+        arr = (_lib.ReduceItem * len(part))(*[t[0] for t in part])
+        check(L.dl_reduce_batch(arr, len(part), _stream()), "dl_reduce_batch")
 
 
 # Dynamic tile hand-out of the persistent large-tile GEMM (dl_gemm_args.tile_tickets): on while gradient buckets are being
@@ -171,11 +220,19 @@ def layernorm_bwd(dy2d, x2d, mean, rstd, gamma, dres=None, need_param_grads=True
     if need_param_grads:
         gb = torch.empty((2, D), dtype=torch.float32, device=x2d.device)   # adjacent: one final-reduction launch
         dgamma, dbeta = gb[0], gb[1]
-    ws = _ws.get(L.dl_layernorm_bwd_workspace_bytes(M, D), x2d.device)
+    nbytes = L.dl_layernorm_bwd_workspace_bytes(M, D)
+    item = None
+    if _pending is not None and need_param_grads:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x2d.device)     # the partials outlive this call (deferred_reductions)
+        item = _lib.ReduceItem()
+    else:
+        ws = _ws.get(nbytes, x2d.device)
     check(L.dl_layernorm_bwd(dy2d.data_ptr(), dy2d.stride(0), int(dy_share), x2d.data_ptr(), x2d.stride(0), mean.data_ptr(),
                              rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), 0 if dres is None else dres.stride(0),
                              dx.data_ptr(), dx.stride(0), _ptr(dgamma), _ptr(dbeta), 0, M, D, _dt(x2d),
-                             ws.data_ptr(), ws.numel(), _stream()), "dl_layernorm_bwd")
+                             ws.data_ptr(), ws.numel(), None if item is None else C.pointer(item), _stream()), "dl_layernorm_bwd")
+    if item is not None and item.kind != 0:
+        _pending.append((item, ws, gb, None))
     return dx, dgamma, dbeta
 
 

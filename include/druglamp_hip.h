@@ -61,6 +61,31 @@ int dl_version(void);
  * split_k > 1: the contraction is cut into split_k slabs reduced by a second kernel; only the
  * plain epilogue (optionally accumulate) is allowed and out_dtype must be DL_F32.
  * ------------------------------------------------------------------------------------------ */
+/* A pending second-stage reduction (see dl_reduce_batch): what dl_gemm's split-K path or dl_layernorm_bwd would have
+ * launched right away, handed back to the caller instead so that several of them leave in ONE launch.  At the
+ * strong-scaling batches (32-64 pairs per GPU) a step is bound by its launch count, and a third of those launches
+ * were these reductions. */
+typedef struct dl_reduce_item {
+  int32_t kind;          /* DL_REDUCE_NONE (nothing pending), DL_REDUCE_SPLITK, DL_REDUCE_PARTIALS */
+  int32_t out_dtype;     /* SPLITK: DL_F32 or DL_BF16 output */
+  const float* src;      /* SPLITK: slabs [splits][M*N]; PARTIALS: partial [chunks][stride] */
+  void* out;             /* SPLITK: C (row pitch ldc); PARTIALS: float [ncols] */
+  int64_t mn;            /* SPLITK: M*N; PARTIALS: stride */
+  int64_t ldc;
+  int32_t N;             /* SPLITK: N; PARTIALS: ncols */
+  int32_t splits;        /* SPLITK: slabs; PARTIALS: chunks */
+  int32_t accumulate;
+  int32_t M;             /* SPLITK: rows of the column sums that ride along (x_colsum), else 0 */
+  const float* cs_slabs; /* SPLITK: [splits][M] or NULL */
+  float* cs_out;
+} dl_reduce_item;
+enum { DL_REDUCE_NONE = 0, DL_REDUCE_SPLITK = 1, DL_REDUCE_PARTIALS = 2 };
+enum { DL_REDUCE_BATCH_MAX = 24 };
+/* Runs n <= DL_REDUCE_BATCH_MAX pending reductions in one launch; every item's result is bit-identical to what the
+ * immediate path produces (same per-element summation order).  The buffers an item points to (the GEMM's workspace,
+ * the LayerNorm partials) must stay untouched until this launch has run. */
+int dl_reduce_batch(const dl_reduce_item* items, int32_t n, dl_stream s);
+
 typedef struct {
   const void* X; int64_t ldx; int32_t x_kslow;
   const void* W; int64_t ldw; int32_t w_kslow;
@@ -91,6 +116,9 @@ typedef struct {
                                         a CU that starts late — e.g. because an RCCL channel workgroup of an overlapped
                                         gradient all-reduce was sitting on it — costs its share of tiles, not a second
                                         round.  Outputs are bit-identical with and without (tested). */
+  dl_reduce_item* deferred;          /* NULL, or HOST pointer: a split-K call writes its slabs, describes the pending
+                                        reduction here and does NOT launch it (kind = DL_REDUCE_NONE when the call took no
+                                        split); the caller owns the workspace until dl_reduce_batch has run */
 } dl_gemm_args;
 enum { DL_GEMM_ALGO_AUTO = 0, DL_GEMM_ALGO_TILE128 = 1 };
 
@@ -150,7 +178,9 @@ int dl_layernorm_bwd(const void* dy, int64_t lddy, int64_t dy_share, const void*
                      const float* rstd, const float* gamma, const void* dres, int64_t lddres,
                      void* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate,
                      int64_t M, int64_t D, int32_t dtype, void* workspace, size_t workspace_bytes,
-                     dl_stream s);
+                     dl_reduce_item* deferred, dl_stream s);
+/* deferred (HOST pointer or NULL): with dbeta == dgamma + D the final [2][D] column reduction is described there instead
+ * of launched (dl_reduce_batch runs it; the workspace must stay untouched until then); kind = DL_REDUCE_NONE otherwise. */
 
 /* ------------------------------------------------------------------------------------------
  * Fused attention: O = softmax(scale * Q K^T) V, no mask, no dropout

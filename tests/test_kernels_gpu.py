@@ -54,9 +54,10 @@ def test_fill_pool_matches_reference_formulation(dtype, odt, site_len, S, F):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(49152, 512, 256), (49000, 520, 192)])
+@pytest.mark.parametrize("M,N,K", [(49152, 512, 256), (49000, 520, 192), (8192, 512, 2048), (8100, 264, 1024), (16384, 256, 512)])
 def test_large_tile_gemm_is_bitwise_equal_to_the_128_tile_path(M, N, K):
-    """The 256x256 persistent kernel (gemm_big.cuh) and gemm_kernel accumulate every output element in the same
+    """The 256x256 persistent kernel (gemm_big.cuh), its few-tile 128x128 deep-ring form (the last three shapes: at most
+    256 tiles, K >= 512 — the strong-scaling batches) and gemm_kernel accumulate every output element in the same
     k order and share epilogue math and dropout counters: outputs must be identical bit for bit, for every
     specialised epilogue, including ragged M / N edges."""
     from druglamp_amd import ops
@@ -372,3 +373,45 @@ def test_dynamic_tile_tickets_leave_the_large_tile_gemm_bitwise_unchanged(M, N, 
                     got[False] = (out, pre)
     finally:
         ops.dynamic_tiles(False)
+
+
+@pytest.mark.gpu
+def test_deferred_reductions_are_bitwise_equal_to_immediate_ones():
+    """dl_reduce_batch (split-K slabs of several weight-gradient GEMMs incl. their bias column sums, and LayerNorm
+    dgamma / dbeta partials, all in ONE launch) against the launches dl_gemm / dl_layernorm_bwd make on their own."""
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(21)
+    dt = torch.bfloat16
+    K = 8192
+    shapes = [(1024, 256), (256, 1024), (1536, 512), (128, 128), (768, 256), (8, 1024)]
+    ops_in = [((torch.randn(K, M, generator=g) * 0.5).to(dt).cuda(), (torch.randn(K, N, generator=g) * 0.5).to(dt).cuda()) for M, N in shapes]
+    x = torch.randn(K, 512, generator=g).to(dt).cuda()
+    dy = torch.randn(K, 512, generator=g).to(dt).cuda()
+    gamma = torch.randn(512, generator=g).cuda()
+    _, mean, rstd = ops.layernorm_fwd(x, gamma, torch.zeros(512, device="cuda"), 1e-6)
+
+    def run():
+        outs = []
+        for (M, N), (a, b) in zip(shapes, ops_in):
+            db = torch.empty(M, dtype=torch.float32, device="cuda")
+            dw = ops.gemm(a, b, M=M, N=N, K=K, x_kslow=True, w_kslow=True, ldx=M, ldw=N, out_dtype=torch.float32, split_k=0, x_colsum=db)
+            outs += [dw, db]
+        dx, dg, dbt = ops.layernorm_bwd(dy, x, mean, rstd, gamma)
+        return outs + [dx, dg, dbt]
+
+    ref = [t.clone() for t in run()]
+    with ops.deferred_reductions():
+        got = run()
+        assert len(ops._pending) == len(shapes) + 1          # every reduction is queued, none has run
+    torch.cuda.synchronize()
+    for r, o in zip(ref, got):
+        assert torch.equal(r, o)
+    # accumulate=True is never deferred, and flushes what is queued before it runs
+    with ops.deferred_reductions():
+        a, b = ops_in[0]
+        dw = ops.gemm(a, b, M=1024, N=256, K=K, x_kslow=True, w_kslow=True, ldx=1024, ldw=256, out_dtype=torch.float32, split_k=0)
+        ops.gemm(a, b, M=1024, N=256, K=K, x_kslow=True, w_kslow=True, ldx=1024, ldw=256, out_dtype=torch.float32, split_k=0,
+                 out=dw, accumulate=True)
+        assert not ops._pending
+    torch.cuda.synchronize()
+    assert torch.equal(dw, ref[0] * 2)
