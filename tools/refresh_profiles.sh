@@ -20,5 +20,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o
 F=$(find "$OUT/pmc_f" -name '*counter_collection.csv' | head -1); W=$(find "$OUT/pmc_w" -name '*counter_collection.csv' | head -1)
 python3 "$ROOT/tools/pmc_summary.py" "$F" "$W" "$OUT/pmc_summary.json" > "$OUT/pmc_summary.txt" 2>&1
 python3 "$ROOT/tools/gemm_shapes.py" > "$OUT/gemm_shapes.txt" 2>&1
+python3 "$ROOT/tools/gemm_shapes.py" --batch 32 > "$OUT/gemm_shapes_batch32.txt" 2>&1
+python3 "$ROOT/tools/cpu_baseline_sweep.py" > "$OUT/cpu_baseline_sweep.jsonl" 2>/dev/null
 rm -rf "$OUT/trace" "$OUT/pmc_f" "$OUT/pmc_w"
 ls -la "$OUT"; head -c 600 "$OUT/bench_line.json"; echo; head -12 "$OUT/bench_timed_window_summary.txt"
