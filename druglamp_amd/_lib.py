@@ -100,6 +100,7 @@ SIGNATURES = {
     "dl_version": (c_i32, []),
     "dl_gemm_workspace_bytes": (c_sz, [C.POINTER(GemmArgs)]),
     "dl_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "dl_gemm_pair": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp]),
     "dl_reduce_batch": (c_i32, [C.POINTER(ReduceItem), c_i32, c_vp]),
     "dl_colsum": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "dl_colsum_workspace_bytes": (c_sz, [c_i64, c_i64]),

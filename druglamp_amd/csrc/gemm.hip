@@ -47,6 +47,10 @@ struct GemmP {
   float* slabs;   // split mode: [splits][M][N] f32
   float* cs_slabs; // split mode, optional: [splits][M] partial column sums of the K-slow X operand
   int dbg;
+  // paired launch (gemm_kernel only): byte offsets from problem 0's pointers to problem 1's, and the seed difference
+  int nprob = 1;
+  int64_t dX = 0, dW = 0, dC = 0, dBias = 0, dRes = 0, dPre = 0, dDact = 0;
+  uint64_t dSeed = 0;
 };
 
 // ---- global -> registers (4 chunks of 16 B per thread per operand) ------------------------
@@ -168,7 +172,8 @@ __device__ __forceinline__ u32x4 read_frag(const char* lds, int rb, int kf, int 
 // EPI: 0 bias only | 1 general (all runtime flags) | 2 bias+pre_out+GELU(+dropout) | 3 bias(+dropout)+residual |
 //      4 gelu'(dact_pre)(+dropout) | 5 bias+ReLU.   EPI != 1 need N % 8 == 0 and take 16-byte accesses only.
 template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA, int EPI, int TW, bool CS = false>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p0) {
+  GemmP p = p0;            // (local copy: a paired launch re-points the epilogue fields per tile, see below)
   constexpr bool SIMPLE = (EPI == 0);
   constexpr int BM = 32 * TW, BN = 32 * TW;
   constexpr bool XD = DMA, WD = DMA;                 // operands staged by LDS-DMA (both layouts)
@@ -189,12 +194,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   // list with stride gridDim.x.  Within one round the XCD-aware remap keeps neighbouring logical tiles
   // (same X row panel) on one XCD / L2.  The first operand tiles of the NEXT output tile are requested
   // before the epilogue of the current one, so their HBM latency and the epilogue's stores overlap.
-  const uint32_t ntiles = (uint32_t)p.mt * p.nt * p.splits;
+  // Paired launch (dl_gemm_pair, nprob = 2): two problems of identical shape whose pointers differ by the byte deltas
+  // d* — the two streams of a paired block.  Problem 1's tiles follow problem 0's in the tile list; operand pointers are
+  // chosen when a tile is located, the epilogue's when it runs.
+  const uint32_t per_prob = (uint32_t)p.mt * p.nt * p.splits;
+  const uint32_t ntiles = per_prob * (uint32_t)p0.nprob;
   const uint32_t G = gridDim.x;
+  const char* Xb = p0.X;
+  const char* Wb = p0.W;
+  int prob = 0;
   auto locate = [&](uint32_t it, int& split, int& m0, int& n0, int& kbeg, int& kend) {
     const uint32_t round0 = (it / G) * G;
     const uint32_t span = min(G, ntiles - round0);
-    const uint32_t t = round0 + xcd_remap(it - round0, span);
+    uint32_t t = round0 + xcd_remap(it - round0, span);
+    prob = (t >= per_prob) ? 1 : 0;
+    t -= prob ? per_prob : 0u;
+    Xb = p0.X + (prob ? p0.dX : 0);
+    Wb = p0.W + (prob ? p0.dW : 0);
     split = t / (p.mt * p.nt);
     const int tile = t % (p.mt * p.nt);
     m0 = (tile / p.nt) * BM; n0 = (tile % p.nt) * BN;
@@ -207,8 +223,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   if ((DL_DBG(p) & 4) && (blockIdx.x >= gridDim.x / 2)) { for (int z = 0; z < (DL_DBG(p) >> 4); ++z) __builtin_amdgcn_s_sleep(127); }
   int split, m0, n0, kbeg, kend;
   locate(it, split, m0, n0, kbeg, kend);
-  if constexpr (!XD) load_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg, kend, rx);
-  if constexpr (!WD) load_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg, kend, rw);
+  if constexpr (!XD) load_tile<T, XS, TW>(Xb, p.ldx, m0, p.M, kbeg, kend, rx);
+  if constexpr (!WD) load_tile<T, WS, TW>(Wb, p.ldw, n0, p.N, kbeg, kend, rw);
   for (;;) {
   f32x4 acc[TW][TW];
 #pragma unroll
@@ -225,9 +241,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   const bool do_cs = CS && n0 == 0 && wn == 0;
 
   const int nk = (kend - kbeg + BKE - 1) / BKE;
-  if constexpr (XD) dma_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg, smem);
+  if constexpr (XD) dma_tile<T, XS, TW>(Xb, p.ldx, m0, p.M, kbeg, smem);
   else store_tile<T, XS, TW>(smem, rx);
-  if constexpr (WD) dma_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg, smem + TB);
+  if constexpr (WD) dma_tile<T, WS, TW>(Wb, p.ldw, n0, p.N, kbeg, smem + TB);
   else store_tile<T, WS, TW>(smem + TB, rw);
   __syncthreads();
   auto kloop = [&](auto with_cs) {
@@ -237,10 +253,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
       char* nxt = smem + ((kt + 1) & 1) * 2 * TB;
       const bool more = (kt + 1 < nk);
       if (more && !(DL_DBG(p) & 2)) {
-        if constexpr (XD) dma_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, nxt);
-        else load_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, kend, rx);
-        if constexpr (WD) dma_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, nxt + TB);
-        else load_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, kend, rw);
+        if constexpr (XD) dma_tile<T, XS, TW>(Xb, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, nxt);
+        else load_tile<T, XS, TW>(Xb, p.ldx, m0, p.M, kbeg + (kt + 1) * BKE, kend, rx);
+        if constexpr (WD) dma_tile<T, WS, TW>(Wb, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, nxt + TB);
+        else load_tile<T, WS, TW>(Wb, p.ldw, n0, p.N, kbeg + (kt + 1) * BKE, kend, rw);
       }
 #pragma unroll
       for (int kf = 0; kf < NFRAG; ++kf) {
@@ -272,12 +288,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p) {
   }
   // request the next output tile's first operand tiles now (registers only)
   const int cm0 = m0, cn0 = n0, csplit = split;
+  if (p0.nprob > 1) {                    // this tile's epilogue pointers (wave-uniform)
+    const int64_t f = prob;
+    p.C = p0.C + f * p0.dC;
+    p.bias = p0.bias ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p0.bias) + f * p0.dBias) : nullptr;
+    p.res = p0.res ? p0.res + f * p0.dRes : nullptr;
+    p.pre_out = p0.pre_out ? p0.pre_out + f * p0.dPre : nullptr;
+    p.dact_pre = p0.dact_pre ? p0.dact_pre + f * p0.dDact : nullptr;
+    p.seed = p0.seed + (uint64_t)f * p0.dSeed;
+  }
   const uint32_t itn = it + G;
   const bool have_next = itn < ntiles;
   if (have_next) {
     locate(itn, split, m0, n0, kbeg, kend);
-    if constexpr (!XD) load_tile<T, XS, TW>(p.X, p.ldx, m0, p.M, kbeg, kend, rx);
-    if constexpr (!WD) load_tile<T, WS, TW>(p.W, p.ldw, n0, p.N, kbeg, kend, rw);
+    if constexpr (!XD) load_tile<T, XS, TW>(Xb, p.ldx, m0, p.M, kbeg, kend, rx);
+    if constexpr (!WD) load_tile<T, WS, TW>(Wb, p.ldw, n0, p.N, kbeg, kend, rw);
   }
 
   if constexpr (CS) {
@@ -769,9 +794,40 @@ extern "C" size_t dl_gemm_workspace_bytes(const dl_gemm_args* a) {
   return 0;
 }
 
-extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
+namespace {
+constexpr int DL_PAIR_FALLBACK = 1;       // gemm_run: the pair is not on the gemm_kernel path, nothing was launched
+// b: nullptr, or a second problem of identical shape / layout / epilogue (checked by dl_gemm_pair) that shares the launch.
+int gemm_run(const dl_gemm_args* a, const dl_gemm_args* b, dl_stream stream);
+}  // namespace
+extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) { return gemm_run(a, nullptr, stream); }
+
+extern "C" int dl_gemm_pair(const dl_gemm_args* a, const dl_gemm_args* b, dl_stream stream) {
+  DL_CHECK_ARG(a && b, DL_ERR_ARG, "dl_gemm_pair: null argument block");
+  auto same_presence = [](const void* x, const void* y) { return (x == nullptr) == (y == nullptr); };
+  const bool twin =
+      a->M == b->M && a->N == b->N && a->K == b->K && a->ldx == b->ldx && a->ldw == b->ldw && a->ldc == b->ldc &&
+      a->x_kslow == b->x_kslow && a->w_kslow == b->w_kslow && a->in_dtype == b->in_dtype && a->out_dtype == b->out_dtype &&
+      a->ldr == b->ldr && a->res_row_mod == b->res_row_mod && a->res_before_dropout == b->res_before_dropout &&
+      a->act == b->act && a->ldp == b->ldp && a->lddp == b->lddp && a->dropout_p == b->dropout_p &&
+      a->accumulate == b->accumulate && a->split_k == b->split_k && a->algo == b->algo &&
+      a->dropout_seed_offset == b->dropout_seed_offset && a->tile_tickets == b->tile_tickets &&
+      same_presence(a->bias, b->bias) && same_presence(a->residual, b->residual) && same_presence(a->pre_out, b->pre_out) &&
+      same_presence(a->dact_pre, b->dact_pre) && !a->x_colsum && !b->x_colsum && !a->deferred && !b->deferred &&
+      (((uintptr_t)b->X | (uintptr_t)b->W | (uintptr_t)b->C | (uintptr_t)b->bias | (uintptr_t)b->residual |
+        (uintptr_t)b->pre_out | (uintptr_t)b->dact_pre) & 15) == 0;
+  if (twin) {
+    const int rc = gemm_run(a, b, stream);
+    if (rc != DL_PAIR_FALLBACK) return rc;
+  }
+  const int rc = gemm_run(a, nullptr, stream);
+  return rc != DL_OK ? rc : gemm_run(b, nullptr, stream);
+}
+
+namespace {
+int gemm_run(const dl_gemm_args* a, const dl_gemm_args* b, dl_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   DL_CHECK_ARG(a && a->X && a->W && a->C, DL_ERR_ARG, "dl_gemm: null operand");
+  if (b) DL_CHECK_ARG(b->X && b->W && b->C, DL_ERR_ARG, "dl_gemm_pair: null operand");
   DL_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, DL_ERR_SHAPE, "dl_gemm: bad shape M=%ld N=%ld K=%ld",
                (long)a->M, (long)a->N, (long)a->K);
   DL_CHECK_ARG(a->M < (1ll << 30) && a->N < (1ll << 30) && a->K < (1ll << 30), DL_ERR_SHAPE,
@@ -850,6 +906,20 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   p.cs_slabs = a->x_colsum ? (float*)a->workspace + (size_t)sp * a->M * a->N : nullptr;
   p.dbg = dl_study_env("DL_GEMM_DBG", 0);     // 0 in the product build (kernels compile the study branches out)
 
+  if (b) {
+    // a pair shares a launch only on the gemm_kernel path without split-K; anything else runs as two launches
+    // (the few-tile deep-ring form beats a shared launch of the two-buffer kernel where it applies: 2 x 12.6 us against
+    //  27.6 us for two 8192x256x1024 products, tools/pair_bench.py)
+    if (slab_path || big_eligible(a, p, sp) || lat_eligible(a, p, sp)) return DL_PAIR_FALLBACK;
+    p.nprob = 2;
+    p.dX = (const char*)b->X - (const char*)a->X; p.dW = (const char*)b->W - (const char*)a->W;
+    p.dC = (char*)b->C - (char*)a->C;
+    p.dBias = a->bias ? (const char*)b->bias - (const char*)a->bias : 0;
+    p.dRes = a->residual ? (const char*)b->residual - (const char*)a->residual : 0;
+    p.dPre = a->pre_out ? (char*)b->pre_out - (char*)a->pre_out : 0;
+    p.dDact = a->dact_pre ? (const char*)b->dact_pre - (const char*)a->dact_pre : 0;
+    p.dSeed = b->dropout_seed - a->dropout_seed;
+  }
   dl_prof_before(0, s);
   int rc = DL_OK;
   if (big_tt) {
@@ -860,7 +930,7 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   } else if (big_eligible(a, p, sp)) {
     p.mt = (int)((a->M + 255) / 256); p.nt = (int)((a->N + (big_cfg() == 1 ? 127 : 255)) / (big_cfg() == 1 ? 128 : 256));
     launch_big(p, s);
-  } else if (const int lat = lat_eligible(a, p, sp)) {
+  } else if (const int lat = b ? 0 : lat_eligible(a, p, sp)) {
     p.mt = (int)((a->M + 127) / 128); p.nt = (int)((a->N + 127) / 128);
     launch_lat(p, s, lat);
   } else if (a->in_dtype == DL_BF16) {
@@ -875,8 +945,8 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   DL_CHECK_LAUNCH("dl_gemm");
   {
     // the timing bracket covers the MFMA kernel only (the split-K slab reduction is a separate, HBM-bound launch)
-    const double flops = 2.0 * (double)a->M * (double)a->N * (double)a->K;
-    const double bytes = ((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * oes;
+    const double flops = 2.0 * (double)a->M * (double)a->N * (double)a->K * (b ? 2 : 1);
+    const double bytes = (((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * oes) * (b ? 2 : 1);
     dl_prof_after(0, s, flops, bytes);
   }
   if (slab_path) {
@@ -906,6 +976,7 @@ extern "C" int dl_gemm(const dl_gemm_args* a, dl_stream stream) {
   }
   return DL_OK;
 }
+}  // namespace
 
 // ---- column sums ------------------------------------------------------------------------------
 namespace {

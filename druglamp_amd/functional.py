@@ -15,6 +15,7 @@ Reference semantics restated here (see oracle/druglamp_oracle.py for the plain-t
 from __future__ import annotations
 
 import functools
+import os
 import math
 import weakref
 from typing import List, Optional, Sequence
@@ -185,6 +186,19 @@ class _Stream:
         self.w1T, self.w2T = lowp((w1,), cdt, True), lowp((w2,), cdt, True)
 
 
+PAIR_GEMMS = os.environ.get("DL_PAIR_GEMMS", "1") != "0"     # A/B switch for tools: 0 = one launch per stream
+
+
+def _gemm_s(xs, ws, **kw):
+    """One GEMM per stream (every keyword is a per-stream list or one value for all): a single ops.gemm for one stream,
+    ops.gemm_pair — one launch when the shape is on the 128-tile path — for the two streams of a paired block."""
+    if len(xs) == 2 and PAIR_GEMMS:
+        return list(ops.gemm_pair(xs, ws, **kw))
+    if len(xs) == 2:
+        return [ops.gemm(xs[i], ws[i], **{k: (v[i] if isinstance(v, (tuple, list)) else v) for k, v in kw.items()}) for i in range(2)]
+    return [ops.gemm(xs[0], ws[0], **{k: (v[0] if isinstance(v, (tuple, list)) else v) for k, v in kw.items()})]
+
+
 class TransformerBlockFn(torch.autograd.Function):
     """x: [S, B, L, d] (S = 2 stacked streams when paired, else 1).  Returns the same shape."""
 
@@ -208,7 +222,9 @@ class TransformerBlockFn(torch.autograd.Function):
             y, mean, rstd = ops.layernorm_fwd(xs[s], st.ln1w.detach(), st.ln1b.detach(), eps)
             xn.append(y)
             stats1.append((mean, rstd))
-            ops.gemm(y, st.qkv_w, M=M, N=3 * d, K=d, bias=st.qkv_b, out=qkv[s])
+        # the same layer of both streams leaves as one launch where the shapes allow it (_gemm_s -> dl_gemm_pair)
+        _gemm_s(xn, [st.qkv_w for st in streams], M=M, N=3 * d, K=d, bias=[st.qkv_b for st in streams],
+                out=[qkv[s] for s in range(S)])
         a = torch.empty((S, M, nseg * d), dtype=cdt, device=x.device)
         qs = (L * 3 * d, hd, 3 * d)
         os_ = (L * nseg * d, hd, nseg * d)
@@ -218,22 +234,21 @@ class TransformerBlockFn(torch.autograd.Function):
                            fp8=bool(attn_fp8) and cdt == torch.bfloat16)
         out = torch.empty_like(x)
         saved: List[torch.Tensor] = [x, qkv, a, lse]
-        seeds = []
+        seeds = [((ops.next_seed(), ops.next_seed()) if p_eff > 0 else (0, 0)) for _ in range(S)]
+        if paired:
+            f = _gemm_s([a[s] for s in range(S)], [st.fc_w for st in streams], M=M, N=d, K=2 * d, bias=[st.fc_b for st in streams])
+        else:
+            f = [a[s] for s in range(S)]
+        x1 = _gemm_s(f, [st.out_w for st in streams], M=M, N=d, K=d, bias=[st.out_b for st in streams], residual=xs)
+        ln2 = [ops.layernorm_fwd(x1[s], st.ln2w.detach(), st.ln2b.detach(), eps) for s, st in enumerate(streams)]
+        hn = [t[0] for t in ln2]
+        pre = [torch.empty((M, 4 * d), dtype=cdt, device=x.device) for _ in range(S)]
+        act = _gemm_s(hn, [st.w1 for st in streams], M=M, N=4 * d, K=d, bias=[st.b1 for st in streams], act=1, pre_out=pre,
+                      dropout_p=p_eff, seed=[sd[0] for sd in seeds])
+        _gemm_s(act, [st.w2 for st in streams], M=M, N=d, K=4 * d, bias=[st.b2 for st in streams], dropout_p=p_eff,
+                seed=[sd[1] for sd in seeds], residual=x1, out=[out[s].reshape(M, d) for s in range(S)])
         for s, st in enumerate(streams):
-            if paired:
-                f = ops.gemm(a[s], st.fc_w, M=M, N=d, K=2 * d, bias=st.fc_b)
-            else:
-                f = a[s]
-            x1 = ops.gemm(f, st.out_w, M=M, N=d, K=d, bias=st.out_b, residual=xs[s])
-            hn, mean2, rstd2 = ops.layernorm_fwd(x1, st.ln2w.detach(), st.ln2b.detach(), eps)
-            pre = torch.empty((M, 4 * d), dtype=cdt, device=x.device)
-            s1 = ops.next_seed() if p_eff > 0 else 0
-            s2 = ops.next_seed() if p_eff > 0 else 0
-            act = ops.gemm(hn, st.w1, M=M, N=4 * d, K=d, bias=st.b1, act=1, pre_out=pre, dropout_p=p_eff, seed=s1)
-            ops.gemm(act, st.w2, M=M, N=d, K=4 * d, bias=st.b2, dropout_p=p_eff, seed=s2, residual=x1,
-                     out=out[s].reshape(M, d))
-            seeds.append((s1, s2))
-            saved += [xn[s], stats1[s][0], stats1[s][1], f if paired else a[s], x1, hn, mean2, rstd2, pre, act,
+            saved += [xn[s], stats1[s][0], stats1[s][1], f[s], x1[s], hn[s], ln2[s][1], ln2[s][2], pre[s], act[s],
                       st.qkv_wT, st.out_wT, st.w1T, st.w2T, st.fc_wT if paired else st.out_wT,
                       st.ln1w.detach(), st.ln2w.detach()]
         ctx.save_for_backward(*saved)
@@ -253,29 +268,30 @@ class TransformerBlockFn(torch.autograd.Function):
         cdt = x.dtype
         dout = dout.contiguous()
         da = torch.empty_like(a)
-        dx1_all = []
+        SV = [sv[4 + s * per: 4 + (s + 1) * per] for s in range(S)]
+        col = lambda i: [SV[s][i] for s in range(S)]                                  # noqa: E731
+        (xn_, _m1, _r1, f_, x1_, hn_, mean2_, rstd2_, pre_, act_, qkvw_, outw_, w1_, w2_, fcw_, _l1, ln2w_) = [col(i) for i in range(per)]
+        dys = [dout[s].reshape(M, d) for s in range(S)]
+        g2 = [ops.dropout_apply(dys[s], p_eff, seeds[s][1]) if p_eff > 0 else dys[s] for s in range(S)]
+        wg2 = [_wgrad(g2[s], act_[s], d, 4 * d, M, d, 4 * d) for s in range(S)]
+        g1 = _gemm_s(g2, w2_, M=M, N=4 * d, K=d, dact_pre=pre_, dropout_p=p_eff, seed=[seeds[s][0] for s in range(S)])
+        wg1 = [_wgrad(g1[s], hn_[s], 4 * d, d, M, 4 * d, d) for s in range(S)]
+        dhn = _gemm_s(g1, w1_, M=M, N=d, K=4 * d)
+        lnb = [ops.layernorm_bwd(dhn[s], x1_[s], mean2_[s], rstd2_[s], ln2w_[s], dres=dys[s]) for s in range(S)]
+        dx1_all = [t[0] for t in lnb]
+        wgo = [_wgrad(dx1_all[s], f_[s], d, d, M, d, d) for s in range(S)]
         grads_tail = []     # per stream: param grads produced after attention (fc/out/ln2/mlp)
-        for s in range(S):
-            (xn, mean1, rstd1, f, x1, hn, mean2, rstd2, pre, act, qkv_w, out_w, w1, w2, fc_w, ln1w, ln2w) = \
-                sv[4 + s * per: 4 + (s + 1) * per]
-            dy = dout[s].reshape(M, d)
-            s1, s2 = seeds[s]
-            g2 = ops.dropout_apply(dy, p_eff, s2) if p_eff > 0 else dy
-            dw2, db2 = _wgrad(g2, act, d, 4 * d, M, d, 4 * d)
-            g1 = ops.gemm(g2, w2, M=M, N=4 * d, K=d, dact_pre=pre, dropout_p=p_eff, seed=s1)
-            dw1, db1 = _wgrad(g1, hn, 4 * d, d, M, 4 * d, d)
-            dhn = ops.gemm(g1, w1, M=M, N=d, K=4 * d)
-            dx1, dg2, dbt2 = ops.layernorm_bwd(dhn, x1, mean2, rstd2, ln2w, dres=dy)
-            dwo, dbo = _wgrad(dx1, f, d, d, M, d, d)
-            if paired:
-                df = ops.gemm(dx1, out_w, M=M, N=d, K=d)
-                dwf, dbf = _wgrad(df, a[s], d, 2 * d, M, d, 2 * d)
-                ops.gemm(df, fc_w, M=M, N=2 * d, K=d, out=da[s])
-                grads_tail.append((dwf, dbf, dwo, dbo, dg2, dbt2, dw1, db1, dw2, db2))
-            else:
-                ops.gemm(dx1, out_w, M=M, N=d, K=d, out=da[s])
-                grads_tail.append((dwo, dbo, dg2, dbt2, dw1, db1, dw2, db2))
-            dx1_all.append(dx1)
+        if paired:
+            df = _gemm_s(dx1_all, outw_, M=M, N=d, K=d)
+            wgf = [_wgrad(df[s], a[s], d, 2 * d, M, d, 2 * d) for s in range(S)]
+            _gemm_s(df, fcw_, M=M, N=2 * d, K=d, out=[da[s] for s in range(S)])
+            for s in range(S):
+                grads_tail.append((wgf[s][0], wgf[s][1], wgo[s][0], wgo[s][1], lnb[s][1], lnb[s][2], wg1[s][0], wg1[s][1],
+                                   wg2[s][0], wg2[s][1]))
+        else:
+            _gemm_s(dx1_all, outw_, M=M, N=d, K=d, out=[da[s] for s in range(S)])
+            for s in range(S):
+                grads_tail.append((wgo[s][0], wgo[s][1], lnb[s][1], lnb[s][2], wg1[s][0], wg1[s][1], wg2[s][0], wg2[s][1]))
         # attention backward: dqkv [S, M, 3d]
         dqkv = torch.empty_like(qkv)
         qs = (L * 3 * d, hd, 3 * d)
@@ -286,13 +302,11 @@ class TransformerBlockFn(torch.autograd.Function):
                      dq=dqkv, dq_strides=qs, dk=dqkv[..., d:], dk_strides=qs, dv=dqkv[..., 2 * d:], dv_strides=qs)
         dx = torch.empty_like(x)
         out_grads: List[Optional[torch.Tensor]] = []
+        wgq = [_wgrad(dqkv[s], xn_[s], 3 * d, d, M, 3 * d, d) for s in range(S)]
+        dxn = _gemm_s([dqkv[s] for s in range(S)], qkvw_, M=M, N=d, K=3 * d)
         for s in range(S):
-            (xn, mean1, rstd1, f, x1, hn, mean2, rstd2, pre, act, qkv_w, out_w, w1, w2, fc_w, ln1w, ln2w) = \
-                sv[4 + s * per: 4 + (s + 1) * per]
-            g = dqkv[s]
-            dwqkv, dbqkv = _wgrad(g, xn, 3 * d, d, M, 3 * d, d)
-            dxn = ops.gemm(g, qkv_w, M=M, N=d, K=3 * d)
-            _, dg1, dbt1 = ops.layernorm_bwd(dxn, x[s].reshape(M, d), mean1, rstd1, ln1w, dres=dx1_all[s],
+            dwqkv, dbqkv = wgq[s]
+            _, dg1, dbt1 = ops.layernorm_bwd(dxn[s], x[s].reshape(M, d), SV[s][1], SV[s][2], SV[s][15], dres=dx1_all[s],
                                              out=dx[s].reshape(M, d))
             out_grads += [dg1, dbt1, dwqkv[0:d], dbqkv[0:d], dwqkv[d:2 * d], dbqkv[d:2 * d], dwqkv[2 * d:],
                           dbqkv[2 * d:]]

@@ -70,13 +70,12 @@ _ws2 = _Workspace()  # second buffer so that two scratch users can be live insid
 # ------------------------------------------------------------------------------------------------
 # raw ops
 # ------------------------------------------------------------------------------------------------
-def gemm(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_kslow=False, w_kslow=False,
-         ldx: Optional[int] = None, ldw: Optional[int] = None, bias=None, residual=None, res_row_mod=0,
-         res_before_dropout=False, act=0, pre_out=None, dact_pre=None, dropout_p=0.0, seed=0, out=None,
-         out_dtype=None, accumulate=False, split_k=-1, x_colsum=None, algo=0) -> torch.Tensor:
-    """C[M,N] = epilogue(sum_k X[m,k] W[n,k]); see include/druglamp_hip.h (dl_gemm)."""
+def _gemm_args(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_kslow=False, w_kslow=False,
+               ldx: Optional[int] = None, ldw: Optional[int] = None, bias=None, residual=None, res_row_mod=0,
+               res_before_dropout=False, act=0, pre_out=None, dact_pre=None, dropout_p=0.0, seed=0, out=None,
+               out_dtype=None, accumulate=False, split_k=-1, x_colsum=None, algo=0):
+    """The dl_gemm_args block of one product (and its output tensor)."""
     _need_gpu(x, w)
-    L = _lib.lib()
     out_dtype = out_dtype or x.dtype
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=x.device)
@@ -106,6 +105,14 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_kslow=Fa
     a.dropout_seed_offset = _seed_offset_ptr(x.device) if dropout_p > 0 else None
     a.algo = algo
     a.tile_tickets = _tickets_ptr(x.device)
+    return a, out
+
+
+def gemm(x: torch.Tensor, w: torch.Tensor, **kw) -> torch.Tensor:
+    """C[M,N] = epilogue(sum_k X[m,k] W[n,k]); see include/druglamp_hip.h (dl_gemm).  Keywords: _gemm_args."""
+    L = _lib.lib()
+    a, out = _gemm_args(x, w, **kw)
+    accumulate, x_colsum = kw.get("accumulate", False), kw.get("x_colsum")
     nbytes = L.dl_gemm_workspace_bytes(C.byref(a))
     item = None
     if nbytes:
@@ -124,6 +131,19 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_kslow=Fa
     if item is not None and item.kind != 0:
         _pending.append((item, ws, out, x_colsum))
     return out
+
+
+def gemm_pair(xs, ws, **kw):
+    """Two products of one shape / layout / epilogue — the two streams of a paired block — through dl_gemm_pair: ONE launch
+    when both are on the 128-tile path without split-K, two otherwise; bit-identical to two gemm() calls.  xs, ws: the two
+    operand pairs; every other keyword of gemm() is either one value for both or a 2-tuple / 2-list (one per problem)."""
+    L = _lib.lib()
+    per = [{k: (v[i] if isinstance(v, (tuple, list)) else v) for k, v in kw.items()} for i in range(2)]
+    (a0, o0), (a1, o1) = _gemm_args(xs[0], ws[0], **per[0]), _gemm_args(xs[1], ws[1], **per[1])
+    if L.dl_gemm_workspace_bytes(C.byref(a0)) or L.dl_gemm_workspace_bytes(C.byref(a1)):
+        return gemm(xs[0], ws[0], **per[0]), gemm(xs[1], ws[1], **per[1])      # split-K shapes: the plain path (own workspaces)
+    check(L.dl_gemm_pair(C.byref(a0), C.byref(a1), _stream()), "dl_gemm_pair")
+    return o0, o1
 
 
 # Deferred second-stage reductions (dl_reduce_item / dl_reduce_batch): inside `with deferred_reductions():` every split-K

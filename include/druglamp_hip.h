@@ -124,6 +124,13 @@ enum { DL_GEMM_ALGO_AUTO = 0, DL_GEMM_ALGO_TILE128 = 1 };
 
 size_t dl_gemm_workspace_bytes(const dl_gemm_args* a);
 int dl_gemm(const dl_gemm_args* a, dl_stream s);
+/* Two products of identical shape, layout and epilogue (the two streams of a paired PMMA block, reference
+ * model/PMMA/block.py:33-62: the same layer applied to the drug stream and to the protein stream with separate
+ * weights) in ONE launch when both are on the 128-tile path without split-K: at the strong-scaling batches each of them
+ * fills half the CUs and the step is bound by its launch count.  Otherwise (large-tile / split-K shapes, x_colsum,
+ * deferred reductions, different flags) the two run one after the other exactly as two dl_gemm calls.  Results are
+ * bit-identical to two dl_gemm calls either way (tested). */
+int dl_gemm_pair(const dl_gemm_args* a, const dl_gemm_args* b, dl_stream s);
 
 /* column sums: out[n] (+)= sum_m X[m,n] — bias gradients of every Linear above. */
 int dl_colsum(const void* X, int64_t ldx, int64_t M, int64_t N, int32_t dtype, float* out,

@@ -415,3 +415,44 @@ def test_deferred_reductions_are_bitwise_equal_to_immediate_ones():
         assert not ops._pending
     torch.cuda.synchronize()
     assert torch.equal(dw, ref[0] * 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(8192, 256, 256), (8100, 264, 192), (4096, 1024, 256), (49152, 512, 256)])
+def test_gemm_pair_is_bitwise_equal_to_two_calls(M, N, K):
+    """dl_gemm_pair: the two streams' products in one launch (128-tile path; the last shape takes the large tile and
+    therefore two launches) against two dl_gemm calls, for every epilogue incl. per-problem dropout seeds."""
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(13)
+    dt = torch.bfloat16
+    mk = lambda *sh, sc=1.0: [(torch.randn(*sh, generator=g) * sc).to(dt).cuda() for _ in range(2)]      # noqa: E731
+    xs, ws = mk(M, K, sc=0.5), mk(N, K, sc=0.1)
+    bs = [torch.randn(N, generator=g).cuda() for _ in range(2)]
+    res, pre_in = mk(M, N), mk(M, N)
+    cases = {
+        "plain": dict(), "bias": dict(bias=bs), "relu": dict(bias=bs, act=2),
+        "gelu+pre+drop": dict(bias=bs, act=1, pre_out=True, dropout_p=0.1, seed=[5, 9]),
+        "dgelu+drop": dict(dact_pre=pre_in, dropout_p=0.1, seed=[5, 9]),
+        "res+drop": dict(bias=bs, residual=res, dropout_p=0.1, seed=[7, 11]),
+    }
+    for name, kw in cases.items():
+        outs = {}
+        for mode in ("pair", "two"):
+            k2 = dict(kw)
+            pres = None
+            if k2.get("pre_out"):
+                pres = [torch.zeros(M, N, device="cuda", dtype=dt) for _ in range(2)]
+                k2["pre_out"] = pres
+            out = [torch.full((M, N), 7.0, device="cuda", dtype=dt) for _ in range(2)]
+            if mode == "pair":
+                ops.gemm_pair(xs, ws, M=M, N=N, K=K, out=out, **k2)
+            else:
+                for i in range(2):
+                    ops.gemm(xs[i], ws[i], M=M, N=N, K=K, out=out[i], **{k: (v[i] if isinstance(v, list) else v) for k, v in k2.items()})
+            torch.cuda.synchronize()
+            outs[mode] = (out, pres)
+        for i in range(2):
+            assert torch.equal(outs["pair"][0][i], outs["two"][0][i]), (name, i)
+            if outs["pair"][1] is not None:
+                assert torch.equal(outs["pair"][1][i], outs["two"][1][i]), (name, i)
+    assert not torch.equal(outs["pair"][0][0], outs["pair"][0][1])
