@@ -31,6 +31,9 @@ _param_epoch = 0
 def _deferring(fn):
     """Backward passes whose split-K / LayerNorm second-stage reductions leave in one dl_reduce_batch launch at the end
     (ops.deferred_reductions): legal because these passes never read the gradients they produce, they only return them."""
+    if os.environ.get("DL_DEFER_REDUCTIONS", "1") == "0":      # A/B switch for tools
+        return fn
+
     @functools.wraps(fn)
     def wrapped(*a, **k):
         with ops.deferred_reductions():
