@@ -553,6 +553,9 @@ class Trainer:
         out["loss"] = float(loss_sum) / max(n, 1)
         return out
 
+    def _epoch_losses(self, sums, steps) -> Dict[str, float]:
+        return _epoch_loss_means(sums, steps, self.world, self.device)
+
     def fit(self, train_batches, val_batches, epochs: Optional[int] = None, on_epoch=None) -> Dict[str, object]:
         """The reference's run_experiment loop (trainer.py:131-135,150-163): one pass over `train_batches()` per epoch
         (a callable yielding (batch, meta) pairs), on_train_epoch_end, validation; the parameters with the best
@@ -564,10 +567,16 @@ class Trainer:
         best = {"ausum": -float("inf"), "epoch": 0, "arena": None, "buffers": None}
         history, bad = [], 0
         for ep in range(1, epochs + 1):
+            sums: Dict[str, torch.Tensor] = {}
+            steps = 0
             for batch, meta in train_batches():
-                self.training_step(batch, meta=meta, cur_epoch=ep)
+                out = self.training_step(batch, meta=meta, cur_epoch=ep)
+                for k, v in out.items():                 # device-side running sums: no host synchronisation per step
+                    sums[k] = sums[k] + v.detach().float() if k in sums else v.detach().float().clone()
+                steps += 1
             self.on_train_epoch_end(ep)
             val = self.evaluate(val_batches() if callable(val_batches) else val_batches)
+            val.update(self._epoch_losses(sums, steps))
             history.append(val)
             if on_epoch is not None:
                 on_epoch(ep, val)
@@ -587,6 +596,25 @@ class Trainer:
                     b.copy_(src)
             Fn.bump_param_epoch()
         return {"best_epoch": best["epoch"], "best_val_ausum": best["ausum"], "epochs_run": len(history), "history": history}
+
+
+def _epoch_loss_means(sums: Dict[str, torch.Tensor], steps: int, world: int, device) -> Dict[str, float]:
+    """Epoch means of the step losses over steps AND ranks — what the reference logs with `on_epoch=True, sync_dist=True`
+    (trainer.py:201,208,222,231): train_loss (cls), ssl_loss, cm_loss (weighted, as added to the total) and all_loss (their
+    sum on the steps that had them).  One all-reduce of a 4-vector of sums + a step count per epoch."""
+    keys = ("cls", "ssl", "cm")
+    vec = torch.zeros(len(keys) + 1, dtype=torch.float64, device=device)
+    for i, k in enumerate(keys):
+        if k in sums:
+            vec[i] = sums[k].double()
+    vec[len(keys)] = float(steps)
+    if world > 1:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    v = vec.tolist()
+    n = max(v[len(keys)], 1.0)
+    out = {"train_loss": v[0] / n, "ssl_loss": v[1] / n, "cm_loss": v[2] / n}
+    out["all_loss"] = out["train_loss"] + out["ssl_loss"] + out["cm_loss"]
+    return out
 
 
 def gather_predictions(p: torch.Tensor, y: torch.Tensor, loss_sum: torch.Tensor, n: int, world: int):

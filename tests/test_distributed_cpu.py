@@ -139,3 +139,31 @@ def test_overlapped_gradient_allreduce_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _loss_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from druglamp_amd.trainer import _epoch_loss_means
+    # rank 0 ran 2 steps, rank 1 ran 3 (uneven shards): the epoch mean is over all 5 steps of both ranks
+    sums = {"cls": torch.tensor(4.0 if rank == 0 else 9.0), "ssl": torch.tensor(1.0 if rank == 0 else 1.5)}
+    out = _epoch_loss_means(sums, 2 if rank == 0 else 3, world, "cpu")
+    ok = abs(out["train_loss"] - 13.0 / 5) < 1e-12 and abs(out["ssl_loss"] - 0.5) < 1e-12 and out["cm_loss"] == 0.0
+    ok &= abs(out["all_loss"] - (13.0 / 5 + 0.5)) < 1e-12
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_epoch_loss_means_world2():
+    """The epoch-level loss means of Trainer.fit (the reference's sync_dist=True logging) over two ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loss_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -134,3 +134,13 @@ def test_embedding_store_file_roundtrip(tmp_path):
         assert False
     except ValueError:
         pass
+
+
+def test_epoch_loss_means_average_over_steps():
+    """train_loss / ssl_loss / cm_loss / all_loss as the reference's epoch-level logging reports them (trainer.py:201-231)."""
+    import torch
+    from druglamp_amd.trainer import _epoch_loss_means
+    sums = {"cls": torch.tensor(6.0), "cm": torch.tensor(1.5)}
+    out = _epoch_loss_means(sums, 3, 1, "cpu")
+    assert out == {"train_loss": 2.0, "ssl_loss": 0.0, "cm_loss": 0.5, "all_loss": 2.5}
+    assert _epoch_loss_means({}, 0, 1, "cpu")["all_loss"] == 0.0

@@ -80,6 +80,9 @@ def test_fit_keeps_best_val_ausum_and_stops_on_patience():
     res = tr.fit(lambda: [(train, meta)], lambda: [val], on_epoch=lambda ep, v: snaps.__setitem__(ep, tr.flat.arena.clone()))
     assert res["best_epoch"] == 2 and res["epochs_run"] == 4 and res["best_val_ausum"] == 1.5
     assert torch.equal(tr.flat.arena, snaps[2]) and not torch.equal(snaps[4], snaps[2])     # best parameters reloaded
+    # epoch means of the step losses ride along (the reference logs them with on_epoch=True, sync_dist=True)
+    h = res["history"][0]
+    assert 0.0 < h["train_loss"] < 10.0 and h["all_loss"] == h["train_loss"] + h["ssl_loss"] + h["cm_loss"]
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 3e-2), (torch.float32, 1e-4)])
