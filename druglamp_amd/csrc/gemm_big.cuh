@@ -72,8 +72,11 @@ __device__ __forceinline__ void wave_sync() {
 
 // XF / WF: MFMA 16x16 tiles per wave along m / n (WF is fixed at 4: 64 columns per wave, see the epilogue);
 // NWM x NWN waves; ROWB: bytes of contraction per operand row per k-step (128 or 64); NSTAGE LDS buffers.
+// (second launch-bound argument: workgroups per CU the register allocation is sized for — one when the stage ring alone
+//  takes more than half of the 160 KB LDS, else two, i.e. two waves per SIMD either way for the 8-wave forms)
 template <int XF, int NWM, int NWN, int ROWB, int NSTAGE, int EPI>
-__global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN >= 8 ? NWM * NWN / 4 : 2)) void gemm_big_kernel(const GemmP p) {
+__global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN >= 8 ? NWM * NWN / 4 : ((16 * XF * NWM + 64 * NWN) * ROWB * NSTAGE > 81920 ? 1 : 2)))
+void gemm_big_kernel(const GemmP p) {
   typedef bf16_t T;
   constexpr int WF = 4;
   constexpr int NT = 64 * NWM * NWN, BM = 16 * XF * NWM, BN = 16 * WF * NWN;
