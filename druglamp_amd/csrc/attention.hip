@@ -558,6 +558,146 @@ __global__ __launch_bounds__(ATT_THREADS, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k
   }
 }
 
+// =================================== backward: dQ, LDS-DMA ring ================================
+// head_dim 128 in bf16 (PMMA self attention, PGCA): the register-staged form above holds 378 registers, i.e. ONE wave per
+// SIMD, and half of that wave's cycles are waits on the staged K/V tiles that nobody covers (SQ counters).
+// Here the K/V tiles arrive by LDS-DMA into a two-stage ring (no staging registers, one barrier per tile) and the scores of
+// a 64-key tile are formed in two 32-key halves (half the score accumulators), which fits 256 registers: two workgroups
+// per CU.  Same arithmetic in the same order per output element as attn_bwd_dq_kernel.
+__device__ __forceinline__ void att_dma16(const char* gsrc, uint32_t lds_off) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_off) : "memory");
+}
+__device__ __forceinline__ void att_wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void att_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <typename T, int HD, int QT>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_ring_kernel(const AttnP p) {
+  using TL = ATile<T, HD>;
+  constexpr int KF = Mma<T>::KF, NKF = HD / KF, NDT = HD / 16, CT = KF / 16;
+  constexpr int KVB = 64, NKP = KVB / KF;
+  constexpr int QB = 4 * QT * 16;
+  constexpr int TILE = KVB * TL::RB, STAGE = 2 * TILE;
+  constexpr int NCH = KVB * TL::CPR / ATT_THREADS;          // DMA instructions per thread per tensor per tile
+  static_assert(sizeof(T) == 2 && KVB * TL::CPR % ATT_THREADS == 0, "bf16 tiles, whole DMA instructions");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const uint32_t smem_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 15, g = lane >> 4;
+  const int qb = blockIdx.x, h = blockIdx.y, pq = blockIdx.z;
+  const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)pq * p.q_ps + (int64_t)h * p.q_hs;
+  const int qw0 = qb * QB + wave * QT * 16;
+  const float c = p.scale * LOG2E;
+
+  u32x4 qf[QT][NKF];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = qw0 + qt * 16 + il;
+#pragma unroll
+    for (int kf = 0; kf < NKF; ++kf) qf[qt][kf] = frag_global<T>(Qb + (int64_t)q * p.q_rs, q < p.Lq, kf, g);
+  }
+  f32x4 dq[NDT][QT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) dq[d][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int seg = 0; seg < p.S; ++seg) {
+    const int pa = seg == 0 ? pq : (pq + p.P - p.shift) % p.P;
+    const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)pa * p.k_ps + (int64_t)h * p.k_hs;
+    const T* Vb = reinterpret_cast<const T*>(p.V) + (int64_t)pa * p.v_ps + (int64_t)h * p.v_hs;
+    const T* dOb = reinterpret_cast<const T*>(p.dO) + (int64_t)seg * p.do_ss + (int64_t)pa * p.do_ps + (int64_t)h * p.do_hs;
+    const int64_t statbase = (((int64_t)seg * p.P + pa) * p.H + h) * p.Lq;
+    const int nt = (p.Lk + KVB - 1) / KVB;
+    auto issue = [&](int t, int buf) {
+      const char* zero = reinterpret_cast<const char*>(attn_zero_page);
+      const uint32_t sb = smem_lds + (uint32_t)buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int cc = tid + i * ATT_THREADS;
+        const int row = cc / TL::CPR, ch = (cc % TL::CPR) ^ TL::swz(row);
+        const int key = t * KVB + row;
+        const char* ks = key < p.Lk ? reinterpret_cast<const char*>(Kb + (int64_t)key * p.k_rs + ch * TL::EPC) : zero;
+        const char* vs = key < p.Lk ? reinterpret_cast<const char*>(Vb + (int64_t)key * p.v_rs + ch * TL::EPC) : zero;
+        const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((wave * 64 + i * ATT_THREADS) * 16));
+        att_dma16(ks, sb + off);
+        att_dma16(vs, sb + TILE + off);
+      }
+    };
+    if (seg > 0) att_barrier();                        // every wave is done with the previous segment's last tiles
+    issue(0, 0);
+    u32x4 dof[QT][NKF];
+    float lse2[QT], delta[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int q = qw0 + qt * 16 + il;
+      const bool ok = q < p.Lq;
+#pragma unroll
+      for (int kf = 0; kf < NKF; ++kf) dof[qt][kf] = frag_global<T>(dOb + (int64_t)q * p.do_rs, ok, kf, g);
+      lse2[qt] = ok ? p.LSE[statbase + q] * LOG2E : INFINITY;
+      const T* Ob = reinterpret_cast<const T*>(p.O) + (int64_t)seg * p.o_ss + (int64_t)pa * p.o_ps + (int64_t)h * p.o_hs;
+      float part = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < NKF; ++kf) part += dot8_bf16(dof[qt][kf], frag_global<T>(Ob + (int64_t)q * p.o_rs, ok, kf, g));
+      delta[qt] = group4_sum(part);
+      if (ok && g == 0) p.Delta[statbase + q] = delta[qt];
+    }
+    for (int t = 0; t < nt; ++t) {
+      att_wait_all();                                   // own pieces of tile t have landed
+      att_barrier();                                    // everyone's have, and everyone is done with tile t - 1
+      if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+      const char* Kt = smem + (t & 1) * STAGE;
+      const char* Vt = Kt + TILE;
+#pragma unroll
+      for (int kp = 0; kp < NKP; ++kp) {
+        f32x4 s[QT][CT], dp[QT][CT];
+#pragma unroll
+        for (int ci = 0; ci < CT; ++ci) {
+          const int kt = kp * CT + ci;
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) { s[qt][ci] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qt][ci] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+          for (int kf = 0; kf < NKF; ++kf) {
+            const u32x4 ka = frag_kc<T, HD>(Kt, kt * 16, kf, il, g);
+            const u32x4 va = frag_kc<T, HD>(Vt, kt * 16, kf, il, g);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+              s[qt][ci] = Mma<T>::mma(ka, qf[qt][kf], s[qt][ci]);
+              dp[qt][ci] = Mma<T>::mma(va, dof[qt][kf], dp[qt][ci]);
+            }
+          }
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+          for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pv = fast_exp2(s[qt][ci][r] * c - lse2[qt]);
+              s[qt][ci][r] = pv * (dp[qt][ci][r] - delta[qt]);
+            }
+        u32x4 db[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) db[qt] = frag_from_acc<T>(&s[qt][0]);
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+          const u32x4 kta = frag_tr<T, HD>(Kt, kp * KF, d * 16, il, g);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) dq[d][qt] = Mma<T>::mma(kta, db[qt], dq[d][qt]);
+        }
+      }
+    }
+  }
+  T* dQb = reinterpret_cast<T*>(p.dQ) + (int64_t)pq * p.dq_ps + (int64_t)h * p.dq_hs;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = qw0 + qt * 16 + il;
+    if (q < p.Lq) {
+#pragma unroll
+      for (int d = 0; d < NDT; ++d)
+        store4<T>(dQb + (int64_t)q * p.dq_rs + d * 16 + 4 * g, dq[d][qt] * p.scale);
+    }
+  }
+}
+
 // =================================== backward: dK, dV ==========================================
 // work item: (attention problem pa, head, kv block of 4 waves x KT x 16 keys)
 // RES (bf16, Lq <= 256): Q, dO, LSE and Delta of one segment are LDS-resident (LDS-DMA, one barrier per segment).
@@ -705,6 +845,145 @@ __global__ __launch_bounds__(ATT_THREADS, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_
   }
 }
 
+// =================================== backward: dK, dV, LDS-DMA ring ============================
+// Same idea as attn_bwd_dq_ring_kernel for the key side: the 64-row Q / dO blocks arrive by LDS-DMA into a two-stage ring
+// (their LSE / Delta rows through registers one block ahead), and the scores of a block are formed in two 32-row halves.
+template <typename T, int HD, int KT>
+__global__ __launch_bounds__(ATT_THREADS, 1) void attn_bwd_dkv_ring_kernel(const AttnP p) {
+  using TL = ATile<T, HD>;
+  constexpr int KF = Mma<T>::KF, NKF = HD / KF, NDT = HD / 16, CT = KF / 16;
+  constexpr int QSB = 64, NQP = QSB / KF;
+  constexpr int KVB = 4 * KT * 16;
+  constexpr int TILE = QSB * TL::RB, STAGE = 2 * TILE;
+  constexpr int NCH = QSB * TL::CPR / ATT_THREADS;
+  static_assert(sizeof(T) == 2 && QSB * TL::CPR % ATT_THREADS == 0, "bf16 tiles, whole DMA instructions");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 2 * 2 * QSB * sizeof(float)];
+  const uint32_t smem_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+  float* stat_s = reinterpret_cast<float*>(smem + 2 * STAGE);        // [stage][lse | delta][QSB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 15, g = lane >> 4;
+  const int kb = blockIdx.x, h = blockIdx.y, pa = blockIdx.z;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)pa * p.k_ps + (int64_t)h * p.k_hs;
+  const T* Vb = reinterpret_cast<const T*>(p.V) + (int64_t)pa * p.v_ps + (int64_t)h * p.v_hs;
+  const int kw0 = kb * KVB + wave * KT * 16;
+  const float c = p.scale * LOG2E;
+
+  u32x4 kfr[KT][NKF], vfr[KT][NKF];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int key = kw0 + kt * 16 + il;
+    const bool ok = key < p.Lk;
+#pragma unroll
+    for (int kf = 0; kf < NKF; ++kf) {
+      kfr[kt][kf] = frag_global<T>(Kb + (int64_t)key * p.k_rs, ok, kf, g);
+      vfr[kt][kf] = frag_global<T>(Vb + (int64_t)key * p.v_rs, ok, kf, g);
+    }
+  }
+  f32x4 dk[NDT][KT], dv[NDT][KT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) { dk[d][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nqb = (p.Lq + QSB - 1) / QSB;
+  for (int seg = 0; seg < p.S; ++seg) {
+    const int qprob = seg == 0 ? pa : (pa + p.shift) % p.P;
+    const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)qprob * p.q_ps + (int64_t)h * p.q_hs;
+    const T* dOb = reinterpret_cast<const T*>(p.dO) + (int64_t)seg * p.do_ss + (int64_t)pa * p.do_ps + (int64_t)h * p.do_hs;
+    const int64_t statbase = (((int64_t)seg * p.P + pa) * p.H + h) * p.Lq;
+    // block qb -> stage qb & 1: Q / dO rows by DMA, LSE / Delta rows by the first 64 threads
+    auto issue = [&](int qb, int buf) {
+      const char* zero = reinterpret_cast<const char*>(attn_zero_page);
+      const uint32_t sb = smem_lds + (uint32_t)buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int cc = tid + i * ATT_THREADS;
+        const int row = cc / TL::CPR, ch = (cc % TL::CPR) ^ TL::swz(row);
+        const int q = qb * QSB + row;
+        const char* qs_ = q < p.Lq ? reinterpret_cast<const char*>(Qb + (int64_t)q * p.q_rs + ch * TL::EPC) : zero;
+        const char* ds_ = q < p.Lq ? reinterpret_cast<const char*>(dOb + (int64_t)q * p.do_rs + ch * TL::EPC) : zero;
+        const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((wave * 64 + i * ATT_THREADS) * 16));
+        att_dma16(qs_, sb + off);
+        att_dma16(ds_, sb + TILE + off);
+      }
+      if (tid < QSB) {
+        const int q = qb * QSB + tid;
+        stat_s[(buf * 2 + 0) * QSB + tid] = q < p.Lq ? p.LSE[statbase + q] * LOG2E : INFINITY;
+        stat_s[(buf * 2 + 1) * QSB + tid] = q < p.Lq ? p.Delta[statbase + q] : 0.f;
+      }
+    };
+    if (seg > 0) att_barrier();                        // every wave is done with the previous segment's last blocks
+    issue(0, 0);
+    for (int qb = 0; qb < nqb; ++qb) {
+      att_wait_all();
+      att_barrier();
+      if (qb + 1 < nqb) issue(qb + 1, (qb + 1) & 1);
+      const char* Qt = smem + (qb & 1) * STAGE;
+      const char* dOt = Qt + TILE;
+      const float* lse_t = stat_s + ((qb & 1) * 2 + 0) * QSB;
+      const float* del_t = stat_s + ((qb & 1) * 2 + 1) * QSB;
+#pragma unroll
+      for (int qp = 0; qp < NQP; ++qp) {
+        f32x4 s[KT][CT], dp[KT][CT];
+#pragma unroll
+        for (int ci = 0; ci < CT; ++ci) {
+          const int qt = qp * CT + ci;
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) { s[kt][ci] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt][ci] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+          for (int kf = 0; kf < NKF; ++kf) {
+            const u32x4 qa = frag_kc<T, HD>(Qt, qt * 16, kf, il, g);
+            const u32x4 da = frag_kc<T, HD>(dOt, qt * 16, kf, il, g);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+              s[kt][ci] = Mma<T>::mma(qa, kfr[kt][kf], s[kt][ci]);
+              dp[kt][ci] = Mma<T>::mma(da, vfr[kt][kf], dp[kt][ci]);
+            }
+          }
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_t + qt * 16 + 4 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_t + qt * 16 + 4 * g);
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pv = fast_exp2(s[kt][ci][r] * c - l4[r]);
+              s[kt][ci][r] = pv;
+              dp[kt][ci][r] = pv * (dp[kt][ci][r] - d4[r]);
+            }
+        }
+        u32x4 pb[KT], sb[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          pb[kt] = frag_from_acc<T>(&s[kt][0]);
+          sb[kt] = frag_from_acc<T>(&dp[kt][0]);
+        }
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+          const u32x4 dota = frag_tr<T, HD>(dOt, qp * KF, d * 16, il, g);
+          const u32x4 qta = frag_tr<T, HD>(Qt, qp * KF, d * 16, il, g);
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) {
+            dv[d][kt] = Mma<T>::mma(dota, pb[kt], dv[d][kt]);
+            dk[d][kt] = Mma<T>::mma(qta, sb[kt], dk[d][kt]);
+          }
+        }
+      }
+    }
+  }
+  T* dKb = reinterpret_cast<T*>(p.dK) + (int64_t)pa * p.dk_ps + (int64_t)h * p.dk_hs;
+  T* dVb = reinterpret_cast<T*>(p.dV) + (int64_t)pa * p.dv_ps + (int64_t)h * p.dv_hs;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int key = kw0 + kt * 16 + il;
+    if (key < p.Lk) {
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) {
+        store4<T>(dKb + (int64_t)key * p.dk_rs + d * 16 + 4 * g, dk[d][kt] * p.scale);
+        store4<T>(dVb + (int64_t)key * p.dv_rs + d * 16 + 4 * g, dv[d][kt]);
+      }
+    }
+  }
+}
+
 template <typename T> constexpr int fwd_qt() { return sizeof(T) == 2 ? 2 : 1; }
 
 int check_common(const char* who, int dtype, int head_dim, int nseg, int P, int H, int Lq, int Lk,
@@ -768,6 +1047,13 @@ int launch_bwd(const AttnP& p, hipStream_t s) {
   if constexpr (sizeof(T) != 2) {                       // fp32 pipelines: Delta by its own pass (bf16: inside the dQ kernel)
     const int64_t rows = (int64_t)p.S * p.P * p.H * p.Lq;
     hipLaunchKernelGGL((attn_delta_kernel<T, HD>), dim3((uint32_t)((rows + 15) / 16)), dim3(256), 0, s, p);
+  }
+  if constexpr (sizeof(T) == 2 && HD == 128) {
+    if (dl_study_env("DL_ATTN_BWD_RING", 3) & 1) hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<T, HD, QT>), gq, dim3(ATT_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, QT, false>), gq, dim3(ATT_THREADS), 0, s, p);
+    if (dl_study_env("DL_ATTN_BWD_RING", 3) & 2) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<T, HD, KT>), gk, dim3(ATT_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD, KT, false>), gk, dim3(ATT_THREADS), 0, s, p);
+    return DL_OK;
   }
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, QT, false>), gq, dim3(ATT_THREADS), 0, s, p);
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD, KT, false>), gk, dim3(ATT_THREADS), 0, s, p);
