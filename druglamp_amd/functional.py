@@ -43,6 +43,8 @@ def _deferring(fn):
 
 _lowp_cache = {}            # key -> _LowpEntry
 _lowp_tables = {}           # (device, dtype) -> (signature, items_dev, block_map_dev, n_blocks)
+_lowp_retired = []          # replaced tables / dropped images: a captured hipGraph may still point at them (a dl_weight_prep
+                            # node reads its item table on every replay), so device memory handed to a launch is never freed
 _derived_cache = {}         # conv-weight layouts etc.: recomputed per optimiser epoch (small)
 
 
@@ -117,6 +119,9 @@ def _refresh_all_images() -> None:
             items_np = np.array(items, dtype=item_t)
             items_dev = torch.from_numpy(items_np.view(np.uint8).copy()).to(gkey[0])
             bmap_dev = torch.tensor(bmap, dtype=torch.int32).reshape(-1).to(gkey[0])
+            if tab is not None:
+                _lowp_retired.append(tab)      # (a few KB; found by tools/soak.py --graph: fault on the first replay after the
+                                               #  SSL heads had added their images and the table had been rebuilt)
             tab = (sig, items_dev, bmap_dev, len(bmap))
             _lowp_tables[gkey] = tab
         ops.weight_prep(tab[1], tab[2], tab[3], gkey[1])
@@ -145,6 +150,7 @@ def lowp(params: Sequence[torch.Tensor], dtype: torch.dtype, transpose: bool = F
         (not transpose and pad is None and len({p.shape for p in params}) == 1 and
          all(p.dim() == 1 and p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda for p in params))
     if len(_lowp_cache) > 4096:
+        _lowp_retired.append((dict(_lowp_cache), dict(_lowp_tables)))
         _lowp_cache.clear()
         _lowp_tables.clear()
     image = _build_image(params, dtype, transpose, pad)

@@ -55,6 +55,11 @@ class _Workspace:
         self.bufs = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # a captured launch must not point into the shared buffer: that buffer is REPLACED (and the old one freed) the
+            # first time an eager call needs more room, and a later replay would write through the stale address.  Scratch
+            # taken during capture comes from the graph's own pool and stays reserved for as long as the graph lives.
+            return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
         key = (device.type, device.index)
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:

@@ -102,3 +102,79 @@ def test_ssl_and_cm_steps_stay_eager_when_graphs_are_on():
         assert len(tr._graphs) == 1 and next(iter(tr._graphs.values())).replays == 2
     finally:
         ops.use_seed_offset(False)
+
+
+@pytest.mark.gpu
+def test_captured_scratch_survives_growth_of_the_shared_workspace():
+    """A hipGraph-captured split-K GEMM must not point into the shared scratch buffer of ops.py: that buffer is replaced
+    when a later EAGER call needs more room, and a replay would then write its slabs through the freed address (found by
+    tools/soak.py --graph).  Detection: a victim tensor takes the freed block; a replay must leave it untouched."""
+    import torch
+    from druglamp_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    K, M, N = 8192, 256, 256
+    dy = (torch.randn(K, M, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    x = (torch.randn(K, N, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    out = torch.zeros(M, N, device=dev)
+    ops._ws.bufs.clear()
+    ops._ws2.bufs.clear()
+    run = lambda: ops.gemm(dy, x, M=M, N=N, K=K, x_kslow=True, w_kslow=True, ldx=M, ldw=N, out_dtype=torch.float32, split_k=0, out=out)   # noqa: E731
+    run()
+    ref = out.clone()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        run()
+    (old,) = ops._ws.bufs.values()
+    n0, ptr0 = old.numel(), old.data_ptr()
+    del old
+    # an eager call with a far larger scratch need replaces the shared buffer ...
+    big_dy = torch.zeros(65536, 1024, dtype=torch.bfloat16, device=dev)
+    big_x = torch.zeros(65536, 1024, dtype=torch.bfloat16, device=dev)
+    ops.gemm(big_dy, big_x, M=1024, N=1024, K=65536, x_kslow=True, w_kslow=True, ldx=1024, ldw=1024, out_dtype=torch.float32, split_k=0)
+    torch.cuda.synchronize()
+    # ... and the freed block goes to the next tensor of that size
+    victim = torch.full((n0,), 0x5A, dtype=torch.uint8, device=dev)
+    took_it = victim.data_ptr() == ptr0
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        assert bool((victim == 0x5A).all()), "a replay wrote through the stale scratch address"
+    if not took_it:
+        pytest.skip("the allocator did not hand the freed block to the victim: inconclusive on this run")
+
+
+def test_replays_survive_new_weight_images_registered_after_capture():
+    """A captured step's dl_weight_prep node reads its item table on every replay.  When images are registered AFTER the
+    capture (the SSL / CM heads at their first epoch) the table is rebuilt; the old one must stay alive, or the replay reads
+    whatever took its place (tools/soak.py --graph: memory access fault).  Detection: zero-filled victim tensors of the old
+    tables' sizes are allocated right after the rebuild — a replay that reads them refreshes no image, and the losses leave
+    the eager sequence."""
+    from druglamp_amd import functional as Fn
+    from druglamp_amd import ops
+    from druglamp_amd.synthetic import make_batch
+    batch, meta = make_batch(8, DEV, seed=7, with_graph=True, llm_dtype=torch.bfloat16)
+    res = {}
+    try:
+        for graph in (False, True):
+            tr = _make(0.0, graph)
+            losses = [float(tr.training_step(batch, meta=meta, cur_epoch=1)["cls"]) for _ in range(4)]
+            sizes = [(t[1].numel(), t[2].numel()) for t in Fn._lowp_tables.values()]
+            extra = torch.nn.Parameter(torch.randn(64, 64, device=DEV))
+            Fn.lowp((extra,), torch.bfloat16)              # a new planned image: the next refresh rebuilds the table
+            Fn.bump_param_epoch()
+            Fn.lowp((extra,), torch.bfloat16)
+            torch.cuda.synchronize()
+            victims = [torch.zeros(n, dtype=torch.uint8, device=DEV) for a, b in sizes for n in (a, a, a)] + \
+                      [torch.zeros(b, dtype=torch.int32, device=DEV) for a, b in sizes for _ in range(3)]
+            losses += [float(tr.training_step(batch, meta=meta, cur_epoch=1)["cls"]) for _ in range(3)]
+            del victims
+            res[graph] = (losses, _state(tr))
+    finally:
+        ops.use_seed_offset(False)
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    for a, b in zip(res[False][1], res[True][1]):
+        assert torch.equal(a, b)
