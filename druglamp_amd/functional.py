@@ -1073,6 +1073,10 @@ def bn_tick(counter: torch.Tensor) -> None:
 def batch_norm_rows(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor) -> torch.Tensor:
     """nn.BatchNorm1d semantics (incl. running statistics, momentum, unbiased running variance)."""
     C = x2d.shape[1]
+    if bn.training and x2d.shape[0] <= 1:
+        # torch.nn.functional.batch_norm's own check and message: batch statistics of ONE row are meaningless (the
+        # reference's classifier raises here for a training batch of one pair; a silent NaN would be worse)
+        raise ValueError("Expected more than 1 value per channel when training, got input size {}".format(x2d.size()))
     w = bn.weight if bn.weight is not None else torch.ones(C, device=x2d.device)      # affine=False
     b = bn.bias if bn.bias is not None else torch.zeros(C, device=x2d.device)
     y, mean, var = BatchNormRowsFn.apply(x2d, w, b, bn.running_mean, bn.running_var, bn.training, bn.eps,

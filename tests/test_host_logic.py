@@ -211,3 +211,16 @@ def test_load_reference_checkpoint_strips_the_lightning_prefix(tmp_path):
     assert not res.missing_keys and not res.unexpected_keys
     a, b = src.state_dict(), dst.state_dict()
     assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_batchnorm_over_one_row_raises_like_torch():
+    """Training-mode BatchNorm1d over a single row: torch raises ValueError (the reference's MLPDecoder does for a batch of
+    one pair); the HIP path raises the same error before any launch instead of producing NaN statistics."""
+    import pytest
+    import torch
+    from druglamp_amd import functional as Fn
+    bn = torch.nn.BatchNorm1d(4).train()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        torch.nn.functional.batch_norm(torch.zeros(1, 4), bn.running_mean, bn.running_var, bn.weight, bn.bias, True)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        Fn.batch_norm_rows(bn, torch.zeros(1, 4))
