@@ -701,20 +701,26 @@ void launch_big(const GemmP& p, hipStream_t s) {
 #undef DL_BIG
 }
 
-// Large-tile weight-gradient path (gemm_big_tt_kernel): bf16 operands, both K-slow, plain fp32 output through
-// split-K slabs.  Returns the slab count (0 = not eligible); *bm_out is the tile height (256 or 128).
+// Large-tile weight-gradient path (gemm_big_tt2_kernel): bf16 operands, both K-slow, plain fp32 output through
+// split-K slabs.  Returns the slab count (0 = not eligible); *bm_out is the tile height (256 or 128; 256 columns).
 int big_tt_plan(const dl_gemm_args* a, int* bm_out) {
   if (a->algo == DL_GEMM_ALGO_TILE128) return 0;
   if (a->in_dtype != DL_BF16 || !a->x_kslow || !a->w_kslow || a->split_k != 0) return 0;
   const bool plain = !a->bias && !a->residual && !a->act && !a->pre_out && !a->dact_pre && a->dropout_p <= 0.f;
   if (!plain || a->M % 8 != 0 || a->N % 8 != 0 || a->N < 192 || a->M < 96 || a->K < 4096) return 0;
-  const int bm = a->M > 128 ? 256 : 128;
+  // One round of 256 workgroups writes 256 fp32 tiles of slabs whatever the problem, so a tile only pays when the
+  // operand stream dwarfs that.  256x256 tiles from 640K outputs (2048x512, 1536x512); below that 128x256 tiles
+  // (same slab bytes as the 128-tile kernel's 512-workgroup plan) where tools/tt_study.py measured a win:
+  // 1024x256, 256x1024, 768x256, 512x512, 256x648 at K = 65536, 256x392 at K = 131072 (5-17 %), the
+  // 128 x {768, 1152} x 591864 conv gradients (20-25 %); NOT 256x512 / 256x256 at K = 65536 or 128x384x591870.
+  const bool big = a->M > 128 && a->M * a->N >= 640 * 1024;
+  const int bm = big ? 256 : 128;
+  if (!big) {
+    const double work = (double)a->M * (double)a->N * (double)a->K;
+    if (a->M > 128 ? work < 1.0e10 : (a->N < 640 || a->K < 262144)) return 0;
+  }
   const int64_t tiles = ((a->M + bm - 1) / bm) * ((a->N + 255) / 256);
   if (tiles > 256) return 0;
-  // One round of 256 workgroups writes 256 fp32 tiles of slabs (67 MB at 256x256) whatever the problem, so the
-  // large tile only pays when the operand stream dwarfs that: measured win for 1536x512x65536 (244 -> 155 us) and
-  // the 128 x {768, 1152} x 591864 conv gradients (293 -> 260, 443 -> 368 us); break-even or worse below.
-  if (bm == 256 ? (a->M * a->N < 640 * 1024) : (a->N < 640 || a->K < 262144)) return 0;
   int64_t sp = 256 / tiles;                          // one round of at most 256 workgroups
   const int64_t ksteps = (a->K + 63) / 64;
   if (sp > ksteps / 4) sp = ksteps / 4;
@@ -722,16 +728,25 @@ int big_tt_plan(const dl_gemm_args* a, int* bm_out) {
   if (bm_out) *bm_out = bm;
   return (int)sp;
 }
+template <int XF, int KS, int NS, bool PF>
+void launch_big_tt2(const GemmP& p, hipStream_t s, uint32_t nblocks) {
+  if (p.cs_slabs) hipLaunchKernelGGL((gemm_big_tt2_kernel<XF, 2, 4, true, KS, NS, PF>), dim3(nblocks), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((gemm_big_tt2_kernel<XF, 2, 4, false, KS, NS, PF>), dim3(nblocks), dim3(512), 0, s, p);
+}
 void launch_big_tt(const GemmP& p, hipStream_t s, int bm) {
   const uint32_t ntiles = (uint32_t)p.mt * p.nt * p.splits;
   const uint32_t nblocks = ntiles < 256u ? ntiles : 256u;
-  if (p.cs_slabs) {
-    if (bm == 256) hipLaunchKernelGGL((gemm_big_tt_kernel<8, 2, 4, true>), dim3(nblocks), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((gemm_big_tt_kernel<4, 2, 4, true>), dim3(nblocks), dim3(512), 0, s, p);
-  } else {
-    if (bm == 256) hipLaunchKernelGGL((gemm_big_tt_kernel<8, 2, 4, false>), dim3(nblocks), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((gemm_big_tt_kernel<4, 2, 4, false>), dim3(nblocks), dim3(512), 0, s, p);
+#ifdef DL_STUDY
+  // rejected forms (tools/tt_study.py): two 64-row stages (one step in flight), the L2 prefetch, five 32-row stages
+  switch (dl_study_env("DL_GEMM_TTCFG", 0)) {
+    case 1: if (bm == 256) launch_big_tt2<8, 64, 2, false>(p, s, nblocks); else launch_big_tt2<4, 64, 2, false>(p, s, nblocks); return;
+    case 2: if (bm == 256) launch_big_tt2<8, 64, 2, true>(p, s, nblocks); else launch_big_tt2<4, 64, 2, true>(p, s, nblocks); return;
+    case 4: if (bm == 256) launch_big_tt2<8, 32, 4, true>(p, s, nblocks); else launch_big_tt2<4, 64, 3, true>(p, s, nblocks); return;
+    default: break;
   }
+#endif
+  // 256x256: four 32-row stages (three steps in flight); 128x256: three 64-row stages
+  if (bm == 256) launch_big_tt2<8, 32, 4, false>(p, s, nblocks); else launch_big_tt2<4, 64, 3, false>(p, s, nblocks);
 }
 
 template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA>

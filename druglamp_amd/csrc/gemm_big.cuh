@@ -298,27 +298,52 @@ void gemm_big_kernel(const GemmP p) {
 // so K needs no alignment.
 __device__ __attribute__((aligned(16))) const uint32_t dl_zero_page[4] = {0u, 0u, 0u, 0u};
 
-template <int XF, int NWM, int NWN, bool CS>
-__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const GemmP p) {
+// ---------------------------------------------------------------------------------------------------------
+// Round 3: the weight-gradient tile with a deep feed (round 2's gemm_big_tt_kernel: two 64-row stages, DMA through the
+// builtin).  Measured on 2048x512x65536 (tools/tt_study.py): the builtin's DMA made the compiler drain every transposing
+// fragment read (compute-only 218 -> 141 us with the inline-assembly form), and with ONE step in flight the loop waits
+// for first-touch HBM data every step (every k-row of a weight gradient is read once): 32-row steps x 4 stages =
+// three steps in flight, 242 -> 164 us.
+//   * LDS-DMA as inline assembly in the SGPR-base + 32-bit VGPR-offset form: a lane's offset inside an operand tile is
+//     the same for every step and every piece (the 16-row piece stride and the step advance are uniform), so the
+//     per-piece 64-bit pointers of the old kernel (24 VGPRs) become two offsets;
+//   * one DMA instruction per item BETWEEN the MFMA groups, counted vmcnt, one barrier per step;
+//   * K tail (a slab whose last step is partial): that one step takes per-lane pointers with the zero page selected
+//     for rows past the end;
+//   * PF (optional): an L2 prefetch D steps beyond the DMA distance, one dword LDS-DMA per 128-byte line into a
+//     256-byte scratch behind the ring (no destination register; vmcnt returns in order, so it has D + 1 steps).
+__device__ __forceinline__ void dma16s(uint32_t voff, const char* sbase, uint32_t lds_off) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
+template <int XF, int NWM, int NWN, bool CS, int KS, int NSTAGE, bool PF>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const GemmP p) {
   typedef bf16_t T;
-  constexpr int WF = 4, KS = 64, NSTAGE = 2;
+  constexpr int WF = 4;
   constexpr int NT = 64 * NWM * NWN, BM = 16 * XF * NWM, BN = 16 * WF * NWN;
   constexpr int PX = BM * 2, PW = BN * 2;                    // bytes per k-row
   constexpr int CPX = PX / 16, CPW = PW / 16;                // 16-byte chunks per k-row
   constexpr int XB = KS * PX, WB = KS * PW, STAGE = XB + WB;
-  constexpr int XCH = KS * CPX / NT, WCH = KS * CPW / NT;
-  static_assert(KS * CPX % NT == 0 && KS * CPW % NT == 0, "whole DMA instructions per thread");
+  constexpr int XCH = KS * CPX / NT, WCH = KS * CPW / NT, PER = XCH + WCH;
+  constexpr int XRS = NT / CPX, WRS = NT / CPW;              // k-rows between consecutive pieces of a thread
+  constexpr int D = NSTAGE - 1, NPF = PF ? 1 : 0;
+  constexpr int NKF = KS / 32, U = NKF * XF;
+  constexpr int LPR = (PX + PW) / 128;                        // 128-byte lines per k-row of a step (both operands)
+  static_assert(KS * CPX % NT == 0 && KS * CPW % NT == 0 && NT % CPX == 0 && NT % CPW == 0, "whole DMA instructions per thread");
+  static_assert(XRS % 16 == 0 && WRS % 16 == 0, "pieces of a thread share their swizzle");
   static_assert(STAGE >= 4096 * NWM * NWN, "epilogue slices must fit one stage buffer");
   static_assert(CPX >= 16 && CPW >= 16, "swizzle needs 16 chunk columns");
-  static_assert(XF >= WF, "W fragments of the second half-step are fetched during the last WF items of the first");
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
+  static_assert(XF >= WF || NKF == 1, "W fragments of the second half-step are fetched during the last WF items of the first");
+  static_assert(PER <= U, "one DMA instruction per item");
+  static_assert(D >= 1 && D <= 4 && D * NPF + (D - 1) * PER < 64, "vmcnt immediate");
+  static_assert(!PF || KS * LPR <= NT, "one prefetch line per thread");
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE + (PF ? 256 : 0)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int il = lane & 15, g = lane >> 4;
   const int wm = wave / NWN, wn = wave % NWN;
-  // (q = k & 3 -> chunk bits 1..2, (k >> 3) & 1 -> bit 3; bit 0 is left to the two adjacent chunks a lane pair reads:
-  //  the former (k & 3) | ((k >> 3) & 3) << 2 put q on bit 0 as well = 2-way conflicts, half of all LDS cycles)
   auto swz = [](int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); };
+  const uint32_t smem_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int64_t ldx2 = p.ldx * 2, ldw2 = p.ldw * 2;
 
   const uint32_t per_split = (uint32_t)p.mt * p.nt;
   const uint32_t ntiles = per_split * p.splits;
@@ -333,46 +358,73 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
     kbeg = split * p.k_per_split;
     kend = min(p.K, kbeg + p.k_per_split);
   };
-  const char* xs[XCH];
-  const char* ws[WCH];
-  int xk[XCH], wk[WCH];                                       // k-row (within a step) each DMA lane serves
+  // a lane's byte offset inside the operand tile of a step (piece 0); the tile's first byte is uniform
+  const int xkrow = tid / CPX, wkrow = tid / CPW;
+  uint32_t xvoff = 0, wvoff = 0;
+  const char* xtile = nullptr; const char* wtile = nullptr;   // uniform: first byte of the slab's first step
+  const char* pf_base = nullptr; int64_t pf_ld = 0; int pf_row = 0;
   auto point = [&](int m0, int n0, int kbeg) {
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-      const int c = tid + i * NT, krow = c / CPX, pc = c % CPX;
-      int col = m0 + ((pc ^ swz(krow)) << 3);
-      col = col < p.M ? col : p.M - 8;
-      xk[i] = kbeg + krow;
-      xs[i] = p.X + ((int64_t)(kbeg + krow) * p.ldx + col) * 2;
+    {
+      const int pc = tid % CPX;
+      int col = (pc ^ swz(xkrow)) << 3;
+      col = m0 + col < p.M ? col : p.M - 8 - m0;
+      xvoff = (uint32_t)(xkrow * (int)ldx2 + col * 2);
+      xtile = p.X + ((int64_t)kbeg * p.ldx + m0) * 2;
     }
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-      const int c = tid + i * NT, krow = c / CPW, pc = c % CPW;
-      int col = n0 + ((pc ^ swz(krow)) << 3);
-      col = col < p.N ? col : p.N - 8;
-      wk[i] = kbeg + krow;
-      ws[i] = p.W + ((int64_t)(kbeg + krow) * p.ldw + col) * 2;
+    {
+      const int pc = tid % CPW;
+      int col = (pc ^ swz(wkrow)) << 3;
+      col = n0 + col < p.N ? col : p.N - 8 - n0;
+      wvoff = (uint32_t)(wkrow * (int)ldw2 + col * 2);
+      wtile = p.W + ((int64_t)kbeg * p.ldw + n0) * 2;
     }
-  };
-  auto issue = [&](int kt, int kend, uint32_t buf) {
-    char* xb = smem + buf * STAGE;
-    const char* zero = reinterpret_cast<const char*>(dl_zero_page);
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-      const char* src = (xk[i] + kt * KS < kend) ? xs[i] + (int64_t)kt * KS * p.ldx * 2 : zero;
-      const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((wave * 64 + i * NT) * 16));
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(xb + off), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-      const char* src = (wk[i] + kt * KS < kend) ? ws[i] + (int64_t)kt * KS * p.ldw * 2 : zero;
-      const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)(XB + (wave * 64 + i * NT) * 16));
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(xb + off), 16, 0, 0);
+    if constexpr (PF) {
+      const int krow = min(tid / LPR, KS - 1), part = tid % LPR;
+      pf_row = kbeg + krow;
+      if (part < PX / 128) {
+        const int col = min(m0 + part * 64, p.M - 2);
+        pf_base = p.X + (int64_t)col * 2; pf_ld = ldx2;
+      } else {
+        const int col = min(n0 + (part - PX / 128) * 64, p.N - 2);
+        pf_base = p.W + (int64_t)col * 2; pf_ld = ldw2;
+      }
     }
   };
-  // transposing fragment read: 16 tile columns starting at cb0 (bytes), k-rows kf*32 + g*8 + (il>>2) (+4)
+  const char* zero = reinterpret_cast<const char*>(dl_zero_page);
+  // piece q of step kt (X pieces first).  PARTIAL: the slab's last step with only `rows` (< KS) k-rows left
+  auto issue_piece = [&](auto partial, int kt, int rows, uint32_t buf, int q) {
+    constexpr bool PARTIAL = decltype(partial)::value;
+    const uint32_t sb = smem_lds + buf * STAGE;
+    if (q < XCH) {
+      const char* sbase = xtile + ((int64_t)kt * KS + q * XRS) * ldx2;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane(sb + (uint32_t)((wave * 64 + q * NT) * 16));
+      if constexpr (!PARTIAL) dma16s(xvoff, sbase, lo);
+      else dma16((xkrow + q * XRS < rows) ? sbase + xvoff : zero, lo);
+    } else {
+      const int i = q - XCH;
+      const char* sbase = wtile + ((int64_t)kt * KS + i * WRS) * ldw2;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane(sb + (uint32_t)(XB + (wave * 64 + i * NT) * 16));
+      if constexpr (!PARTIAL) dma16s(wvoff, sbase, lo);
+      else dma16((wkrow + i * WRS < rows) ? sbase + wvoff : zero, lo);
+    }
+  };
+  auto issue = [&](int kt, int rows, uint32_t buf) {
+    if (rows >= KS) {
+#pragma unroll
+      for (int q = 0; q < PER; ++q) issue_piece(std::false_type{}, kt, rows, buf, q);
+    } else {
+#pragma unroll
+      for (int q = 0; q < PER; ++q) issue_piece(std::true_type{}, kt, rows, buf, q);
+    }
+  };
+  // L2 prefetch of step kt's lines (rows past the operand's end are clamped to its last row: always a legal address)
+  auto prefetch = [&](int kt) {
+    if constexpr (PF) {
+      const int row = min(pf_row + kt * KS, p.K - 1);
+      const char* src = pf_base + (int64_t)row * pf_ld;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(smem_lds + (uint32_t)(NSTAGE * STAGE)) : "memory");
+    }
+  };
   auto frag = [&](const char* tile, int pitch, int col0, int kf) -> u32x4 {
     const int k0 = kf * 32 + g * 8 + (il >> 2), k1 = k0 + 4;
     const int cb = (col0 + (il & 3) * 4) * 2;
@@ -387,7 +439,16 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
   locate(it, split, m0, n0, kbeg, kend);
   point(m0, n0, kbeg);
   uint32_t gs = 0;
-  issue(0, kend, gs % NSTAGE);
+  // prologue of a tile: steps 0 .. D-1 requested, each followed by the prefetch of step D + s (the loop's pattern)
+  auto prologue = [&]() {
+    const int len = kend - kbeg;
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      if (s * KS < len) issue(s, len - s * KS, (gs + s) % NSTAGE);
+      prefetch(D + s);
+    }
+  };
+  prologue();
 
   for (;;) {
     f32x4 acc[XF][WF];
@@ -398,17 +459,22 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
     float cs[XF];
 #pragma unroll
     for (int i = 0; i < XF; ++i) cs[i] = 0.f;
-    const bool do_cs = CS && n0 == 0 && wn == 0;           // bias gradient: sum of the X fragments over k (two copies of the k loop, wave-uniform choice)
-    const int nk = (kend - kbeg + KS - 1) / KS;
-    auto kloop = [&](auto with_cs) {
-    constexpr bool WCS = decltype(with_cs)::value;
-    for (int kt = 0; kt < nk; ++kt) {
-      wait_vmcnt<0>();
+    const bool do_cs = CS && n0 == 0 && wn == 0;
+    const int len = kend - kbeg;
+    const int nk = (len + KS - 1) / KS;
+    auto kstep = [&](auto with_cs, auto feed, int kt) {
+      constexpr bool WCS = decltype(with_cs)::value;
+      constexpr int FEED = decltype(feed)::value;           // 0: nothing to request, 1: a whole step, 2: the slab's partial last step
+      // step kt has landed once only the younger requests are outstanding: D prefetches and `later` steps of DMA
+      const int later = (kt == 0 || nk < D) ? -1 : min(D - 1, nk - 1 - kt);
+      if (later < 0) wait_vmcnt<0>();                       // (tile start: also drains the previous epilogue's stores)
+      else if (later == 0) wait_vmcnt<D * NPF>();
+      else if (later == 1) wait_vmcnt<D * NPF + PER>();
+      else if (later == 2) wait_vmcnt<D * NPF + (D >= 3 ? 2 : 1) * PER>();
+      else wait_vmcnt<D * NPF + (D >= 4 ? 3 : 1) * PER>();
       wg_barrier();
-      if (kt + 1 < nk) issue(kt + 1, kend, (gs + 1) % NSTAGE);
       const char* cur = smem + (gs % NSTAGE) * STAGE;
-      // same software pipeline as gemm_big_kernel (each fragment is two transposing reads)
-      constexpr int NKF = KS / 32, U = NKF * XF;
+      const int rows_next = len - (kt + D) * KS;
       auto rd_fx = [&](int u) { return frag(cur, PX, wm * 16 * XF + (u % XF) * 16, u / XF); };
       auto rd_fw = [&](int kf, int j) { return frag(cur + XB, PW, wn * 16 * WF + j * 16, kf); };
       u32x4 fx[U], fw[NKF][WF];
@@ -421,7 +487,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
       for (int u = 0; u < U; ++u) {
         int nread = 0;
         if (u + 2 < U) { fx[u + 2] = rd_fx(u + 2); ++nread; }
-        if (u >= XF - WF && u < XF) { fw[1][u - (XF - WF)] = rd_fw(1, u - (XF - WF)); ++nread; }
+        if (NKF == 2 && u >= XF - WF && u < XF) { fw[NKF - 1][u - (XF - WF)] = rd_fw(1, u - (XF - WF)); ++nread; }
+        if (FEED == 1 && u < PER) issue_piece(std::false_type{}, kt + D, rows_next, (gs + D) % NSTAGE, u);
+        if (FEED == 2 && u < PER) issue_piece(std::true_type{}, kt + D, rows_next, (gs + D) % NSTAGE, u);
+        if (u == PER) prefetch(kt + 2 * D);
 #pragma unroll
         for (int j = 0; j < WF; ++j) acc[u % XF][j] = Mma<T>::mma(fw[u / XF][j], fx[u], acc[u % XF][j]);
         if (nread == 2) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -429,8 +498,20 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
         __builtin_amdgcn_sched_group_barrier(0x008, WF, 0);
         if constexpr (WCS) cs[u % XF] = frag_slot_sum<T>(fx[u], cs[u % XF]);
       }
+      if (U <= PER) prefetch(kt + 2 * D);
       ++gs;
-    }
+    };
+    auto kloop = [&](auto with_cs) {
+      typedef std::integral_constant<int, 0> F0; typedef std::integral_constant<int, 1> F1; typedef std::integral_constant<int, 2> F2;
+      if (DL_DBG(p) & 2) {
+        for (int kt = 0; kt < nk; ++kt) kstep(with_cs, F0{}, kt);
+      } else {
+        const int nwhole = len / KS;                        // steps [0, nwhole) are whole; step nwhole (if any) is partial
+        int kt = 0;
+        for (; kt + D < nwhole; ++kt) kstep(with_cs, F1{}, kt);
+        if (kt + D < nk) { kstep(with_cs, F2{}, kt); ++kt; }
+        for (; kt < nk; ++kt) kstep(with_cs, F0{}, kt);
+      }
     };
     if constexpr (CS) {
       if (do_cs) kloop(std::true_type{}); else kloop(std::false_type{});
@@ -444,7 +525,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
     if (have_next) {
       locate(itn, split, m0, n0, kbeg, kend);
       point(m0, n0, kbeg);
-      issue(0, kend, gs % NSTAGE);
+      prologue();
     }
     wg_barrier();
     if (do_cs) {
@@ -467,7 +548,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt_kernel(const Ge
         const u32x4 a0 = lds_read16(st, r * 256 + (((2 * c8) ^ r) << 4));
         const u32x4 a1 = lds_read16(st, r * 256 + (((2 * c8 + 1) ^ r) << 4));
         const int m = cm0 + wm * 16 * XF + i * 16 + r, n = cn0 + wn * 16 * WF + c8 * 8;
-        if (m < p.M && n < p.N) {
+        if (m < p.M && n < p.N && !(DL_DBG(p) & 1)) {
           float* dst = p.slabs + ((int64_t)csplit * p.M + m) * p.N + n;
           *reinterpret_cast<u32x4*>(dst) = a0;
           *reinterpret_cast<u32x4*>(dst + 4) = a1;
