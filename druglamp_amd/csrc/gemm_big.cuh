@@ -312,7 +312,11 @@ __device__ __attribute__((aligned(16))) const uint32_t dl_zero_page[4] = {0u, 0u
 //     for rows past the end;
 //   * PF (optional): an L2 prefetch D steps beyond the DMA distance, one dword LDS-DMA per 128-byte line into a
 //     256-byte scratch behind the ring (no destination register; vmcnt returns in order, so it has D + 1 steps).
-__device__ __forceinline__ void dma16s(uint32_t voff, const char* sbase, uint32_t lds_off) {
+__device__ __forceinline__ void dma16s(uint32_t voff, const char* sbase_, uint32_t lds_off) {
+  // (the base IS uniform; readfirstlane makes the compiler's divergence analysis agree, else "s" may be handed a VGPR pair)
+  const uint64_t b = (uint64_t)sbase_;
+  const char* sbase = (const char*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b));
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory");
 }
 template <int XF, int NWM, int NWN, bool CS, int KS, int NSTAGE, bool PF>
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const G
     const bool do_cs = CS && n0 == 0 && wn == 0;
     const int len = kend - kbeg;
     const int nk = (len + KS - 1) / KS;
-    auto kstep = [&](auto with_cs, auto feed, int kt) {
+    auto kstep = [&](auto with_cs, auto feed, int kt) __attribute__((always_inline)) {
       constexpr bool WCS = decltype(with_cs)::value;
       constexpr int FEED = decltype(feed)::value;           // 0: nothing to request, 1: a whole step, 2: the slab's partial last step
       // step kt has landed once only the younger requests are outstanding: D prefetches and `later` steps of DMA
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const G
       if (U <= PER) prefetch(kt + 2 * D);
       ++gs;
     };
-    auto kloop = [&](auto with_cs) {
+    auto kloop = [&](auto with_cs) __attribute__((always_inline)) {
       typedef std::integral_constant<int, 0> F0; typedef std::integral_constant<int, 1> F1; typedef std::integral_constant<int, 2> F2;
       if (DL_DBG(p) & 2) {
         for (int kt = 0; kt < nk; ++kt) kstep(with_cs, F0{}, kt);

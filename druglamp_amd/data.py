@@ -31,6 +31,23 @@ def repeat_integer_label(codes: np.ndarray, max_length: int = 9 * 256) -> np.nda
     return out
 
 
+def shard_order(n_rows: int, shuffle_seed: Optional[int], rank: int = 0, world: int = 1) -> torch.Tensor:
+    """Row order of one rank's shard.  shuffle_seed given (training): a seeded permutation, padded by wrap-around to
+    ceil(n / world) * world before striding — torch's DistributedSampler, which Lightning's DDP hands the reference
+    (main.py:138-141) — so every rank yields the same number and shapes of batches: ranks issue one collective per step
+    and must agree on the step count.  Evaluation shards (no shuffle) stay unpadded: Trainer.evaluate gathers unequal
+    shards, and a duplicated sample would bias the metrics."""
+    order = torch.arange(n_rows)
+    if shuffle_seed is not None:
+        order = torch.randperm(n_rows, generator=torch.Generator().manual_seed(shuffle_seed))
+        if world > 1 and n_rows > 0:
+            total = -(-n_rows // world) * world
+            if total > n_rows:
+                pad = total - n_rows
+                order = torch.cat([order, order.repeat(-(-pad // n_rows))[:pad]])
+    return order[rank::world]
+
+
 class RowTable:
     """(drug, protein, label) rows + per-entity inputs, device resident.  `batches(split, B)` yields what the reference's
     collate hands the model: ((node_feats, adjacency), residue codes (B, seq_len) float64, labels, llm_d, llm_p), meta."""
@@ -81,12 +98,10 @@ class RowTable:
     def batches(self, split: str, batch_size: int, shuffle_seed: Optional[int] = None, drop_last: bool = False,
                 rank: int = 0, world: int = 1) -> Iterator[Tuple[tuple, List[Dict]]]:
         """shuffle_seed given: a seeded permutation (the reference's DataLoader(shuffle=True, drop_last=True) for training,
-        main.py:138-141); rank / world: the strided shard a DistributedSampler would hand this rank."""
+        main.py:138-141); rank / world: the strided shard a DistributedSampler would hand this rank (training = shuffled:
+        padded by wrap-around to equal length on every rank; evaluation: unpadded)."""
         rows = self.rows[split]
-        order = torch.arange(rows.shape[0])
-        if shuffle_seed is not None:
-            order = torch.randperm(rows.shape[0], generator=torch.Generator().manual_seed(shuffle_seed))
-        order = order[rank::world]
+        order = shard_order(rows.shape[0], shuffle_seed, rank, world)
         for s in range(0, order.numel(), batch_size):
             sel = order[s:s + batch_size]
             if drop_last and sel.numel() < batch_size:

@@ -34,14 +34,16 @@ class _AllGatherRows(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous()
         out = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
-        try:
-            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
-        except RuntimeError:
-            # backends without reduce_scatter (gloo, the CPU tests): same result through an all-reduce + slice
+        # the path is chosen from the backend, never by catching an exception around a collective: a genuine RCCL failure
+        # on one rank must surface, not move that rank to a different collective than its peers are in
+        if dist.get_backend() == "gloo":
+            # gloo has no reduce_scatter: same result through an all-reduce + slice (CPU tests, two ranks on one GPU)
             full = g.clone()
             dist.all_reduce(full, op=dist.ReduceOp.SUM)
             n, r = ctx.shape[0], dist.get_rank()
             out = full[r * n:(r + 1) * n].clone()
+        else:
+            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM)
         return out
 
 

@@ -55,6 +55,11 @@ def bump_param_epoch() -> None:
     _param_epoch += 1
 
 
+def planned_image_count() -> int:
+    """Weight images that the one-launch refresh (dl_weight_prep) maintains."""
+    return sum(1 for e in _lowp_cache.values() if e.planned)
+
+
 class _LowpEntry:
     __slots__ = ("refs", "transpose", "dtype", "image", "versions", "epoch", "planned", "pad")
 

@@ -25,15 +25,29 @@ class MInterface(object):
         return Model(**args1)
 
 
-def load_reference_checkpoint(model, checkpoint, strict: bool = True):
+def load_reference_checkpoint(model, checkpoint, strict: bool = False, allow_pickle: bool = False):
     """Load a checkpoint written by the reference's Lightning run (trainer.py:151-156 ModelCheckpoint on the ExpModule):
     a dict whose "state_dict" maps "exp_model.<key>" to tensors (ExpModule stores the model as self.exp_model,
     trainer.py:43) next to metric-object states.  `checkpoint` is a path or the loaded dict; a bare state_dict (with or
     without the prefix) is accepted too.  The lazily created SimSiam projectors are built first when the checkpoint holds
-    them (the reference needs one SSL forward before it can load such a checkpoint).  Returns load_state_dict's result;
-    the reference itself reloads with strict=False (trainer.py:134)."""
+    them (the reference needs one SSL forward before it can load such a checkpoint).  Returns load_state_dict's result
+    (missing / unexpected keys); strict=False by default, as the reference itself reloads (trainer.py:134) — a Lightning
+    state_dict also holds metric states outside the `exp_model.` prefix.  Files are read with weights_only=True;
+    allow_pickle=True opts in to full unpickling when that fails."""
     import torch
-    ck = torch.load(checkpoint, map_location="cpu") if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "read") else checkpoint
+    if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "read"):
+        try:
+            ck = torch.load(checkpoint, map_location="cpu", weights_only=True)
+        except Exception:
+            # Lightning checkpoints carry callback / hyper-parameter pickles next to the tensors; unpickling arbitrary
+            # objects from a file is the caller's decision, not a silent default
+            if not allow_pickle:
+                raise
+            if hasattr(checkpoint, "seek"):
+                checkpoint.seek(0)
+            ck = torch.load(checkpoint, map_location="cpu", weights_only=False)
+    else:
+        ck = checkpoint
     sd = ck.get("state_dict", ck) if isinstance(ck, dict) else ck
     prefix = "exp_model."
     if any(k.startswith(prefix) for k in sd):

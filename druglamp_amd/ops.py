@@ -544,9 +544,19 @@ def fill_pool(x: torch.Tensor, site_len: int, out_dtype: torch.dtype):
     return fill, pooled
 
 
+_weight_prep_launches = 0
+
+
+def weight_prep_launches() -> int:
+    """dl_weight_prep launches issued so far (GraphedStep checks that its capture recorded one)."""
+    return _weight_prep_launches
+
+
 def weight_prep(items_dev: torch.Tensor, block_map_dev: torch.Tensor, n_blocks: int, out_dtype: torch.dtype) -> None:
     """One launch over a device-side list of (fp32 master -> image) copies; see dl_weight_prep."""
+    global _weight_prep_launches
     _need_gpu(items_dev, block_map_dev)
+    _weight_prep_launches += 1
     check(_lib.lib().dl_weight_prep(items_dev.data_ptr(), block_map_dev.data_ptr(), int(n_blocks), _DT[out_dtype],
                                     _stream()), "dl_weight_prep")
 

@@ -246,15 +246,23 @@ class GraphedStep:
 
     def __init__(self, trainer: "Trainer", batch):
         """Capture only records (nothing executes): the caller has already run eager steps of this shape, so lazy
-        allocations, weight-image tables and workspaces exist, and the parameter epoch is stale (the previous step's
-        AdamW bumped it), which puts the weight-image refresh at the head of the captured forward."""
+        allocations, weight-image tables and workspaces exist."""
         self.tr = trainer
         dev = trainer.device
         self.static = self._clone(batch)
+        # The weight-image refresh (dl_weight_prep) must be a node of the graph whatever ran last: an eager forward with no
+        # optimiser step behind it (evaluate() between the warm-up steps and this capture, a validate-every-N loop) leaves
+        # the images current, lowp() would skip the refresh during capture, and every replay would then compute with the
+        # images frozen at capture time while AdamW keeps moving the fp32 masters.  Making the epoch stale puts the
+        # refresh (and the derived-layout rebuilds) at the head of the captured forward; counted below.
+        Fn.bump_param_epoch()
+        before = ops.weight_prep_launches()
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out, self.idx = self._body()
+        if ops.weight_prep_launches() == before and Fn.planned_image_count() > 0:
+            raise RuntimeError("GraphedStep: no dl_weight_prep launch was captured; replays would use stale weight images")
         self.replays = 0
 
     @staticmethod
@@ -339,15 +347,16 @@ class Trainer:
         # the reference wipes the cls (and ssl) gradients with the next zero_grad before any optimiser steps
         # (header); a backward pass whose gradients nobody consumes is skipped unless asked for
         self.run_dead_backward = os.environ.get("DL_DEAD_BACKWARD", "0") == "1"
-        # Gradient all-reduce at world > 1.  Default ("1"): bucketed all-reduce from inside backward (GradOverlap) for
+        # Gradient all-reduce at world > 1.  "1": bucketed all-reduce from inside backward (GradOverlap) for
         # eagerly run steps; the persistent large-tile GEMMs then hand their tiles out dynamically (ops.dynamic_tiles):
         # a CU that an RCCL channel workgroup occupies for a while takes fewer tiles instead of forcing a second round —
-        # the reason overlap was off by default in round 1.  "0": one reduction after backward.  "force": overlap also at
+        # the reason overlap was off by default in round 1.  "0" (DEFAULT until a multi-GPU RCCL run of the overlapped form
+        # is on record under profiles/): one reduction after backward.  "force": overlap also at
         # world size 1 (RCCL sanity runs).  hipGraph-replayed steps (graph_steps) always reduce after the replay: hooks
         # cannot launch collectives from inside a replay, and at the small per-GPU batches where graphs are used the
         # 5 ms saved on launches outweigh the <= 0.6 ms all-reduce they leave exposed.  UNMEASURED on RCCL with N > 1
         # (no multi-GPU box was available; two ranks sharing one GPU over gloo: tests/test_grad_overlap_gpu.py).
-        ov = os.environ.get("DL_GRAD_OVERLAP", "1")
+        ov = os.environ.get("DL_GRAD_OVERLAP", "0")
         grouped = dist.is_available() and dist.is_initialized()
         want_overlap = ((self.world > 1 and ov not in ("0", "")) or (ov == "force" and grouped)) and not graph_steps
         self.overlap = GradOverlap(self.flat) if want_overlap else None

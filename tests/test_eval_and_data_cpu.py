@@ -144,3 +144,26 @@ def test_epoch_loss_means_average_over_steps():
     out = _epoch_loss_means(sums, 3, 1, "cpu")
     assert out == {"train_loss": 2.0, "ssl_loss": 0.0, "cm_loss": 0.5, "all_loss": 2.5}
     assert _epoch_loss_means({}, 0, 1, "cpu")["all_loss"] == 0.0
+
+
+def test_training_shards_have_equal_length_on_every_rank_and_eval_shards_are_a_partition():
+    """ADVICE (round 2): RowTable.batches(rank, world) must give every rank the same number of training rows
+    (DistributedSampler pads by wrap-around), else ranks disagree on the number of steps / collectives."""
+    from druglamp_amd.data import shard_order
+    for n in (0, 1, 7, 64, 65, 127, 1000):
+        for world in (1, 2, 3, 8):
+            shards = [shard_order(n, 5, r, world) for r in range(world)]
+            lens = {int(s.numel()) for s in shards}
+            assert lens == {-(-n // world)}, (n, world, lens)
+            allrows = torch.cat(shards)
+            assert set(allrows.tolist()) == set(range(n))                    # every row is seen
+            assert allrows.numel() - n < world                                # at most world - 1 wrapped duplicates
+            # with drop_last every rank yields the same number of full batches
+            for bs in (4, 16):
+                assert len({int(s.numel()) // bs for s in shards}) == 1
+            ev = [shard_order(n, None, r, world) for r in range(world)]
+            assert sorted(torch.cat(ev).tolist()) == list(range(n))           # evaluation: an exact partition
+    # same seed -> same permutation on every rank (the shards interleave one permutation)
+    a, b = shard_order(10, 3, 0, 2), shard_order(10, 3, 1, 2)
+    perm = torch.randperm(10, generator=torch.Generator().manual_seed(3))
+    assert torch.equal(a, perm[0::2]) and torch.equal(b, perm[1::2])

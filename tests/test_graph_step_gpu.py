@@ -178,3 +178,30 @@ def test_replays_survive_new_weight_images_registered_after_capture():
     assert res[False][0] == res[True][0], (res[False][0], res[True][0])
     for a, b in zip(res[False][1], res[True][1]):
         assert torch.equal(a, b)
+
+
+def test_capture_right_after_an_evaluation_still_refreshes_the_weight_images():
+    """ADVICE (round 2): if an eager forward with no optimiser step behind it (evaluate()) runs between the warm-up steps
+    and the capturing step, the weight images are current at capture time; the capture must still record the
+    dl_weight_prep refresh, or every replay computes with the images frozen at capture while AdamW moves the masters."""
+    from druglamp_amd import ops
+    from druglamp_amd.synthetic import make_batch
+    batch, meta = make_batch(8, DEV, seed=7, with_graph=True, llm_dtype=torch.bfloat16)
+    res = {}
+    try:
+        for graph in (False, True):
+            tr = _make(0.0, graph)
+            losses = []
+            for step in range(6):
+                if step == tr.graph_warmup:          # right before the step that captures
+                    ev = tr.evaluate([batch])
+                    assert ev["loss"] == ev["loss"]
+                losses.append(float(tr.training_step(batch, meta=meta, cur_epoch=1)["cls"]))
+            if graph:
+                assert len(tr._graphs) == 1
+            res[graph] = (losses, _state(tr))
+    finally:
+        ops.use_seed_offset(False)
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    for a, b in zip(res[False][1], res[True][1]):
+        assert torch.equal(a, b)
