@@ -94,6 +94,15 @@ class AttnBwdArgs(C.Structure):
     ]
 
 
+class NtxentSide(C.Structure):
+    _fields_ = [("q", c_vp), ("k", c_vp), ("n", c_i64), ("gid_offset", c_i64), ("lse", c_vp)]
+
+
+class NtxentArgs(C.Structure):
+    _fields_ = [("a", NtxentSide), ("b", NtxentSide), ("n_global", c_i64), ("d", c_i64), ("dtype", c_i32),
+                ("temperature", c_f32)]
+
+
 # name -> (restype, argtypes); every symbol include/druglamp_hip.h declares
 SIGNATURES = {
     "dl_last_error": (C.c_char_p, []),
@@ -138,6 +147,8 @@ SIGNATURES = {
     "dl_rowmod_sum": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "dl_cos_rowloss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "dl_cos_rowloss_bwd": (c_i32, [c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp]),
+    "dl_ntxent_fwd_ex": (c_i32, [C.POINTER(NtxentArgs), c_vp, c_vp, c_vp, c_vp]),
+    "dl_ntxent_bwd_ex": (c_i32, [C.POINTER(NtxentArgs), c_f32, c_vp, c_vp, c_vp]),
     "dl_ntxent_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "dl_ntxent_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dl_ntxent_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_f32, c_vp, c_vp, c_vp]),

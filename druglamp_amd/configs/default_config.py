@@ -58,7 +58,10 @@ def get_cfg_defaults() -> CfgNode:
     c.RESULT = CN(OUTPUT_DIR=f"{os.getcwd()}/results/")
     c.RS = CN(TASK=False, METHOD="2C2P", SSL=False, CM=False, INIT_EPOCH=-1, EPOCH_STEP=-1, MAX_MARGIN=-1.,
               RESET_EPOCH=-1,
-              GLOBAL_BATCH=False)   # NEW (not in the reference): multi-GPU cross-modal triplets over the all-gathered global batch
+              GLOBAL_BATCH=False,   # NEW (not in the reference): the batch-level heads see the all-gathered GLOBAL batch at
+                                    # world > 1 — cross-modal triplets (CM) and the NT-Xent denominator (SSL, simclr)
+              DRUG_SSL_TYPE="simsiam")   # NEW: the reference hard-codes 'simsiam' (basic_model.py:85), which leaves its
+                                         # nt_xent_loss unreachable; "simclr" selects it (SSL.drug_simclr, :35-41)
     c.COMET = CN(WORKSPACE="lzcstan", PROJECT_NAME="DrugLAMP", USE=True, TAG="Reproduce")
     return c
 

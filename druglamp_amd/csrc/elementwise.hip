@@ -368,6 +368,28 @@ __global__ __launch_bounds__(256) void norm_adj_kernel(const float* __restrict__
   }
 }
 
+// the same for graphs whose fp32 tile does not fit LDS (n > 190): degrees first (only they live in LDS), the adjacency
+// is read from global memory / L2 twice
+template <typename TO>
+__global__ __launch_bounds__(256) void norm_adj_any_kernel(const float* __restrict__ adj, TO* __restrict__ ahat, int n) {
+  extern __shared__ __attribute__((aligned(16))) char na_smem[];
+  float* dout = reinterpret_cast<float*>(na_smem);            // [n]
+  float* din = dout + n;                                      // [n]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* a = adj + (int64_t)b * n * n;
+  for (int r = tid; r < 2 * n; r += 256) {
+    float sum = 0.f;
+    if (r < n) { for (int i = 0; i < n; ++i) sum += a[(int64_t)r * n + i]; dout[r] = rsqrtf(fmaxf(sum, 1.f)); }
+    else { const int c = r - n; for (int j = 0; j < n; ++j) sum += a[(int64_t)j * n + c]; din[c] = rsqrtf(fmaxf(sum, 1.f)); }
+  }
+  __syncthreads();
+  TO* dst = ahat + (int64_t)b * n * n;
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e / n, j = e % n;
+    dst[e] = from_f32<TO>(a[(int64_t)j * n + i] * din[i] * dout[j]);
+  }
+}
+
 // dst[r] = [a[r] | b[r]] for two row-major buffers of ca / cb 16-byte chunks per row (inverse: split dst back into a, b)
 __global__ __launch_bounds__(256) void concat2_kernel(u32x4* __restrict__ a, u32x4* __restrict__ b, u32x4* __restrict__ dst,
                                                        int ca, int cb, int inverse, int64_t total) {
@@ -725,7 +747,15 @@ extern "C" int dl_norm_adjacency(const float* adj, void* ahat, int64_t B, int32_
   hipStream_t s = (hipStream_t)stream;
   DL_CHECK_ARG(adj && ahat && B > 0 && n > 0, DL_ERR_ARG, "dl_norm_adjacency: bad args");
   const size_t lds = ((size_t)n * (n + 1) + 2 * (size_t)n) * sizeof(float);
-  DL_CHECK_ARG(lds <= 150 * 1024, DL_ERR_SHAPE, "dl_norm_adjacency: n=%d does not fit the LDS tile (n <= 190)", n);
+  DL_CHECK_ARG(n <= 4096, DL_ERR_SHAPE, "dl_norm_adjacency: n=%d (at most 4096 nodes per graph)", n);
+  if (lds > 150 * 1024) {                                     // n > 190: the tile does not fit LDS
+    const size_t dl = 2 * (size_t)n * sizeof(float);
+    if (out_dtype == DL_BF16) hipLaunchKernelGGL((norm_adj_any_kernel<bf16_t>), dim3((uint32_t)B), dim3(256), dl, s, adj, (bf16_t*)ahat, (int)n);
+    else if (out_dtype == DL_F32) hipLaunchKernelGGL((norm_adj_any_kernel<float>), dim3((uint32_t)B), dim3(256), dl, s, adj, (float*)ahat, (int)n);
+    else { dl_set_error("dl_norm_adjacency: bad out_dtype"); return DL_ERR_ARG; }
+    DL_CHECK_LAUNCH("dl_norm_adjacency");
+    return DL_OK;
+  }
   if (out_dtype == DL_BF16) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)norm_adj_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((norm_adj_kernel<bf16_t>), dim3((uint32_t)B), dim3(256), lds, s, adj, (bf16_t*)ahat, (int)n);

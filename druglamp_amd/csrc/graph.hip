@@ -92,17 +92,64 @@ __global__ __launch_bounds__(256) void graph_aggregate_kernel(const T* __restric
   }
 }
 
+// Graphs with more than 128 real atoms (rare: drug-like molecules seldom pass 100 heavy atoms; MAX_NODES is 512): the same
+// sums on the vector ALU straight from global memory / L2 — a workgroup takes 32 output rows, a thread 4 rows x 4
+// columns, fp32 accumulation.  9-66 MFLOP per molecule: this path is bound by its launch, not by arithmetic; it exists so
+// that no molecule size leaves the HIP path (round 2 handed these to torch.bmm).
+template <typename T, int C>
+__global__ __launch_bounds__(256) void graph_aggregate_any_kernel(const T* __restrict__ ahat, const T* __restrict__ feat, T* __restrict__ out,
+                                                                   int n, int N, int transpose) {
+  const int b = blockIdx.y, tid = threadIdx.x, c4 = (tid & 31) * 4, rl = tid >> 5;
+  const T* A = ahat + (int64_t)b * n * n;
+  const T* F = feat + (int64_t)b * N * C;
+  T* O = out + (int64_t)b * N * C;
+  const int r0 = blockIdx.x * 32;
+  if (r0 >= n) {                                            // workgroups past the real atoms copy the virtual nodes' rows
+    const int64_t first = (int64_t)n * C, total = (int64_t)(N - n) * C;
+    const int64_t nb = gridDim.x - (n + 31) / 32, me = blockIdx.x - (n + 31) / 32;
+    for (int64_t e = (me * 256 + tid) * 4; e < total; e += nb * 256 * 4) store4<T>(O + first + e, load4<T>(F + first + e));
+    return;
+  }
+  f32x4 acc[4];
+  int rows[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { acc[q] = f32x4{0.f, 0.f, 0.f, 0.f}; rows[q] = r0 + rl + 8 * q; }
+  for (int k = 0; k < n; ++k) {
+    const f32x4 f = load4<T>(F + (int64_t)k * C + c4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = rows[q] < n ? rows[q] : n - 1;
+      const float a = to_f32(transpose ? A[(int64_t)k * n + i] : A[(int64_t)i * n + k]);
+      acc[q] += f * a;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (rows[q] < n) store4<T>(O + (int64_t)rows[q] * C + c4, acc[q]);
+}
+
 }  // namespace
 
 extern "C" int dl_graph_aggregate(const void* ahat, const void* feat, void* out, int64_t B, int32_t n, int32_t N, int32_t C,
                                   int32_t transpose, int32_t dtype, dl_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   DL_CHECK_ARG(ahat && feat && out && B > 0 && n > 0 && N >= n, DL_ERR_ARG, "dl_graph_aggregate: bad args");
-  DL_CHECK_ARG(n <= 128, DL_ERR_UNSUPPORTED, "dl_graph_aggregate: at most 128 real nodes per graph (got %d)", n);
   DL_CHECK_ARG(C == 128, DL_ERR_UNSUPPORTED, "dl_graph_aggregate: feature width %d (only 128, the model's n_hidden)", C);
   DL_CHECK_ARG(dtype == DL_BF16 || dtype == DL_F32, DL_ERR_ARG, "dl_graph_aggregate: bad dtype");
   DL_CHECK_ARG((((uintptr_t)feat | (uintptr_t)out) & 15) == 0, DL_ERR_ALIGN, "dl_graph_aggregate: feat / out must be 16-byte aligned");
-  DL_CHECK_ARG(B <= 0x7fffffff, DL_ERR_SHAPE, "dl_graph_aggregate: batch too large");
+  DL_CHECK_ARG(B <= 0x7fffffff && (n <= 128 || B <= 65535), DL_ERR_SHAPE, "dl_graph_aggregate: batch too large");
+  if (n > 128) {
+    // one workgroup per 32 real rows + (if there are virtual nodes) a few that copy their rows through
+    const uint32_t gx = (uint32_t)((n + 31) / 32) + (N > n ? 4u : 0u);
+    if (dtype == DL_BF16)
+      hipLaunchKernelGGL((graph_aggregate_any_kernel<bf16_t, 128>), dim3(gx, (uint32_t)B), dim3(256), 0, s, (const bf16_t*)ahat,
+                         (const bf16_t*)feat, (bf16_t*)out, (int)n, (int)N, (int)transpose);
+    else
+      hipLaunchKernelGGL((graph_aggregate_any_kernel<float, 128>), dim3(gx, (uint32_t)B), dim3(256), 0, s, (const float*)ahat,
+                         (const float*)feat, (float*)out, (int)n, (int)N, (int)transpose);
+    DL_CHECK_LAUNCH("dl_graph_aggregate");
+    return DL_OK;
+  }
   if (dtype == DL_BF16) {
     const size_t lds = (size_t)2 * 128 * 128 * 2;
     (void)hipFuncSetAttribute((const void*)graph_aggregate_kernel<bf16_t, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

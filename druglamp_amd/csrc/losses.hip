@@ -74,149 +74,6 @@ __global__ void cos_rowloss_bwd_kernel(const float* __restrict__ x, const float*
 }
 
 // ------------------------------------------------------------------------------------------
-// NT-Xent streaming kernels (fp32 MFMA).  Rows of P: i < n -> q[i], else k[i - n].
-// ------------------------------------------------------------------------------------------
-template <int HD>
-__device__ __forceinline__ void stage_p_rows(char* lds, const float* q, const float* k, int64_t n, int64_t n2,
-                                             int64_t j0) {
-  using TL = ATile<float, HD>;
-  for (int c = threadIdx.x; c < 64 * TL::CPR; c += ATT_THREADS) {
-    const int row = c / TL::CPR, ch = c % TL::CPR;
-    const int64_t gr = j0 + row;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (gr < n2) {
-      const float* src = gr < n ? q + gr * HD : k + (gr - n) * HD;
-      v = *reinterpret_cast<const u32x4*>(src + ch * 4);
-    }
-    lds_write16(lds, row * TL::RB + ((ch ^ (row & 7)) << 4), v);
-  }
-}
-
-template <int HD>
-__global__ __launch_bounds__(ATT_THREADS) void ntxent_fwd_kernel(const float* __restrict__ q,
-                                                                const float* __restrict__ k, int64_t n,
-                                                                float inv_t, float* __restrict__ row_lse,
-                                                                float* __restrict__ row_loss) {
-  using TL = ATile<float, HD>;
-  constexpr int NKF = HD / 16, NKT = 4;
-  __shared__ __attribute__((aligned(16))) char Ps[64 * TL::RB];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 15, g = lane >> 4;
-  const int64_t n2 = 2 * n;
-  const int64_t i = (int64_t)blockIdx.x * 64 + wave * 16 + il;
-  const bool iok = i < n2;
-  const float* irow = i < n ? q + i * HD : k + (i - n) * HD;
-  const int64_t pos = i < n ? i + n : i - n;
-  u32x4 qf[NKF];
-#pragma unroll
-  for (int kf = 0; kf < NKF; ++kf) qf[kf] = frag_global<float>(irow, iok, kf, g);
-  const float c = inv_t * LOG2E;
-  float m_run = -INFINITY, l_run = 0.f, pos_logit = 0.f;
-  for (int64_t j0 = 0; j0 < n2; j0 += 64) {
-    stage_p_rows<HD>(Ps, q, k, n, n2, j0);
-    __syncthreads();
-    f32x4 s[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kf = 0; kf < NKF; ++kf) s[kt] = Mma<float>::mma(frag_kc<float, HD>(Ps, kt * 16, kf, il, g), qf[kf], s[kt]);
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t j = j0 + kt * 16 + 4 * g + r;
-        if (j == pos) pos_logit = s[kt][r] * inv_t;
-        if (j == i || j >= n2) s[kt][r] = -INFINITY;
-        mx = fmaxf(mx, s[kt][r]);
-      }
-    mx = group4_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    if (m_new > -INFINITY) {
-      const float alpha = exp2f((m_run - m_new) * c);
-      float rs = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rs += exp2f((s[kt][r] - m_new) * c);
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
-    }
-    __syncthreads();
-  }
-  const float l = group4_sum(l_run);
-  const float pl = group4_sum(pos_logit);
-  if (iok && g == 0) {
-    const float lse = m_run * inv_t + logf(l);
-    row_lse[i] = lse;
-    row_loss[i] = lse - pl;
-  }
-}
-
-template <int HD>
-__global__ __launch_bounds__(ATT_THREADS) void ntxent_bwd_kernel(const float* __restrict__ q,
-                                                                const float* __restrict__ k, int64_t n,
-                                                                float inv_t, const float* __restrict__ row_lse,
-                                                                float gscale, float* __restrict__ dq,
-                                                                float* __restrict__ dk) {
-  using TL = ATile<float, HD>;
-  constexpr int NKF = HD / 16, NKT = 4, NDT = HD / 16;
-  __shared__ __attribute__((aligned(16))) char smem[64 * TL::RB + 64 * sizeof(float)];
-  char* Ps = smem;
-  float* lse_s = reinterpret_cast<float*>(smem + 64 * TL::RB);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 15, g = lane >> 4;
-  const int64_t n2 = 2 * n;
-  const int64_t i = (int64_t)blockIdx.x * 64 + wave * 16 + il;
-  const bool iok = i < n2;
-  const float* irow = i < n ? q + i * HD : k + (i - n) * HD;
-  const int64_t pos = i < n ? i + n : i - n;
-  u32x4 qf[NKF];
-#pragma unroll
-  for (int kf = 0; kf < NKF; ++kf) qf[kf] = frag_global<float>(irow, iok, kf, g);
-  const float c = inv_t * LOG2E;
-  const float lse_i = iok ? row_lse[i] * LOG2E : INFINITY;
-  f32x4 acc[NDT];
-#pragma unroll
-  for (int d = 0; d < NDT; ++d) acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int64_t j0 = 0; j0 < n2; j0 += 64) {
-    stage_p_rows<HD>(Ps, q, k, n, n2, j0);
-    if (threadIdx.x < 64) lse_s[threadIdx.x] = (j0 + threadIdx.x < n2) ? row_lse[j0 + threadIdx.x] * LOG2E : INFINITY;
-    __syncthreads();
-    f32x4 s[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kf = 0; kf < NKF; ++kf) s[kt] = Mma<float>::mma(frag_kc<float, HD>(Ps, kt * 16, kf, il, g), qf[kf], s[kt]);
-      const f32x4 lj = *reinterpret_cast<const f32x4*>(lse_s + kt * 16 + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t j = j0 + kt * 16 + 4 * g + r;
-        const float x = s[kt][r] * c;
-        float cij = exp2f(x - lse_i) + exp2f(x - lj[r]);
-        if (j == pos) cij -= 2.0f;
-        if (j == i || j >= n2 || !iok) cij = 0.f;
-        s[kt][r] = cij;
-      }
-    }
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const u32x4 cb = ctile_frag_f32(s[kt]);
-#pragma unroll
-      for (int d = 0; d < NDT; ++d) acc[d] = Mma<float>::mma(frag_tr<float, HD>(Ps, kt * 16, d * 16, il, g), cb, acc[d]);
-    }
-    __syncthreads();
-  }
-  if (iok) {
-    float* drow = i < n ? dq + i * HD : dk + (i - n) * HD;
-    const float sc = gscale * inv_t;
-#pragma unroll
-    for (int d = 0; d < NDT; ++d) *reinterpret_cast<f32x4*>(drow + d * 16 + 4 * g) = acc[d] * sc;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // triplet loss with D = 1 - sigmoid(cos).  nn.CosineSimilarity eps = 1e-8 (clamps each norm).
 // ------------------------------------------------------------------------------------------
 constexpr float COS_EPS = 1e-8f;
@@ -401,48 +258,6 @@ extern "C" int dl_cos_rowloss_bwd(const float* x, const float* y, float grad_sca
   hipLaunchKernelGGL(cos_rowloss_bwd_kernel, dim3((uint32_t)((n_rows + 3) / 4)), dim3(256), 0, s, x, y, grad_scale,
                      dx, n_rows, (int)D);
   DL_CHECK_LAUNCH("dl_cos_rowloss_bwd");
-  return DL_OK;
-}
-
-extern "C" size_t dl_ntxent_workspace_bytes(int64_t n, int64_t d) { (void)d; return (size_t)(2 * n) * sizeof(float); }
-
-extern "C" int dl_ntxent_fwd(const float* q, const float* k, int64_t n, int64_t d, float temperature, float* loss,
-                             float* row_lse, void* workspace, size_t workspace_bytes, dl_stream stream) {
-  hipStream_t s = (hipStream_t)stream;
-  DL_CHECK_ARG(q && k && loss && row_lse && n > 0, DL_ERR_ARG, "dl_ntxent_fwd: bad args");
-  DL_CHECK_ARG(d == 64 || d == 128, DL_ERR_UNSUPPORTED, "dl_ntxent_fwd: d must be 64 or 128 (got %ld)", (long)d);
-  DL_CHECK_ARG(temperature > 0.f, DL_ERR_ARG, "dl_ntxent_fwd: temperature must be > 0");
-  DL_CHECK_ARG(workspace && workspace_bytes >= dl_ntxent_workspace_bytes(n, d), DL_ERR_WORKSPACE,
-               "dl_ntxent_fwd: workspace too small");
-  const uint32_t blocks = (uint32_t)((2 * n + 63) / 64);
-  float* row_loss = (float*)workspace;
-  if (d == 64)
-    hipLaunchKernelGGL((ntxent_fwd_kernel<64>), dim3(blocks), dim3(ATT_THREADS), 0, s, q, k, n, 1.0f / temperature,
-                       row_lse, row_loss);
-  else
-    hipLaunchKernelGGL((ntxent_fwd_kernel<128>), dim3(blocks), dim3(ATT_THREADS), 0, s, q, k, n, 1.0f / temperature,
-                       row_lse, row_loss);
-  DL_CHECK_LAUNCH("dl_ntxent_fwd");
-  hipLaunchKernelGGL(vec_sum_kernel, dim3(1), dim3(1024), 0, s, (const float*)row_loss, 2 * n,
-                     1.0f / (float)(2 * n), loss);
-  DL_CHECK_LAUNCH("dl_ntxent_fwd(sum)");
-  return DL_OK;
-}
-
-extern "C" int dl_ntxent_bwd(const float* q, const float* k, int64_t n, int64_t d, float temperature,
-                             const float* row_lse, float grad_out, float* dq, float* dk, dl_stream stream) {
-  hipStream_t s = (hipStream_t)stream;
-  DL_CHECK_ARG(q && k && row_lse && dq && dk && n > 0, DL_ERR_ARG, "dl_ntxent_bwd: bad args");
-  DL_CHECK_ARG(d == 64 || d == 128, DL_ERR_UNSUPPORTED, "dl_ntxent_bwd: d must be 64 or 128");
-  const uint32_t blocks = (uint32_t)((2 * n + 63) / 64);
-  const float gscale = grad_out / (float)(2 * n);
-  if (d == 64)
-    hipLaunchKernelGGL((ntxent_bwd_kernel<64>), dim3(blocks), dim3(ATT_THREADS), 0, s, q, k, n, 1.0f / temperature,
-                       row_lse, gscale, dq, dk);
-  else
-    hipLaunchKernelGGL((ntxent_bwd_kernel<128>), dim3(blocks), dim3(ATT_THREADS), 0, s, q, k, n, 1.0f / temperature,
-                       row_lse, gscale, dq, dk);
-  DL_CHECK_LAUNCH("dl_ntxent_bwd");
   return DL_OK;
 }
 

@@ -637,22 +637,68 @@ class CosRowLossFn(torch.autograd.Function):
 
 
 class NTXentFn(torch.autograd.Function):
-    """nt_xent_loss(q, k, T) (self_supervised_learning.py:168-182), streaming: no (2n)^2 matrix."""
+    """nt_xent_loss(q, k, T) (self_supervised_learning.py:168-182), streaming: no (2n)^2 matrix.  Rows keep their dtype
+    (bf16 rows run on the bf16 matrix pipe; log-sum-exp, loss and gradients are fp32).
+
+    global_batch=True under torch.distributed (the north star's "contrastive denominator sees the full global batch";
+    the reference's loss is rank-local): q and k are all-gathered (one collective each), this rank's 2n rows are scored
+    against the 2 * world * n gathered rows, and the value returned is the mean loss of THIS rank's rows — the mean over
+    ranks, which is what the data-parallel gradient averaging forms, is the nt_xent_loss of the concatenated batch.
+    Backward: the gradient of the local rows as softmax rows comes from one pass against the gathered rows; their
+    gradient as other rows' columns is computed for ALL gathered rows against the local softmax rows and returned to
+    the owners by a reduce-scatter (gloo: all-reduce + slice)."""
 
     @staticmethod
-    def forward(ctx, q, k, temperature):
-        q = q.float().contiguous()
-        k = k.float().contiguous()
-        loss, lse = ops.ntxent_fwd(q, k, temperature)
-        ctx.save_for_backward(q, k, lse)
+    def forward(ctx, q, k, temperature, global_batch=False):
+        import torch.distributed as dist
+        if q.dtype not in (torch.float32, torch.bfloat16):
+            q = q.float()
+        q = q.contiguous()
+        k = k.to(q.dtype).contiguous()
+        world = dist.get_world_size() if (global_batch and dist.is_available() and dist.is_initialized()) else 1
+        n = q.shape[0]
+        if world > 1:
+            rank = dist.get_rank()
+            qa = torch.empty((world * n, q.shape[1]), dtype=q.dtype, device=q.device)
+            ka = torch.empty_like(qa)
+            dist.all_gather_into_tensor(qa, q)
+            dist.all_gather_into_tensor(ka, k)
+            loss, lse, _ = ops.ntxent_fwd_ex(q, k, qa, ka, rank * n, 0, world * n, temperature)
+            ctx.save_for_backward(q, k, lse, qa, ka)
+            ctx.dist = (rank, world)
+        else:
+            loss, lse, _ = ops.ntxent_fwd_ex(q, k, q, k, 0, 0, n, temperature)
+            ctx.save_for_backward(q, k, lse)
+            ctx.dist = None
         ctx.t = temperature
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, dl):
-        q, k, lse = ctx.saved_tensors
-        dq, dk = ops.ntxent_bwd(q, k, ctx.t, lse, 1.0)
-        return dq * dl, dk * dl, None
+        t = ctx.t
+        if ctx.dist is None:
+            q, k, lse = ctx.saved_tensors
+            n = q.shape[0]
+            dq, dk = ops.ntxent_bwd_ex(q, k, q, k, 0, 0, n, t, lse, lse, 1.0 / (2 * n))
+            return (dq * dl).to(q.dtype), (dk * dl).to(k.dtype), None, None
+        import torch.distributed as dist
+        q, k, lse, qa, ka = ctx.saved_tensors
+        rank, world = ctx.dist
+        n = q.shape[0]
+        gs = 1.0 / (2 * n)
+        # (1) this rank's rows as softmax rows; (2) every gathered row as a column of this rank's softmax rows
+        dq, dk = ops.ntxent_bwd_ex(q, k, qa, ka, rank * n, 0, world * n, t, lse, None, gs)
+        dqa, dka = ops.ntxent_bwd_ex(qa, ka, q, k, 0, rank * n, world * n, t, None, lse, gs)
+        both = torch.stack((dqa, dka)).reshape(2, world, n, -1).transpose(0, 1).contiguous()     # (world, 2, n, d)
+        mine = torch.empty((2, n, q.shape[1]), dtype=torch.float32, device=q.device)
+        if dist.get_backend() == "gloo":
+            dist.all_reduce(both, op=dist.ReduceOp.SUM)
+            mine.copy_(both[rank])
+        else:
+            dist.reduce_scatter_tensor(mine, both, op=dist.ReduceOp.SUM)
+        # every rank differentiates ITS mean; the data-parallel step then averages parameter gradients over ranks, which
+        # makes the sum over ranks of the column terms (one per rank's loss) the right quantity here
+        return ((dq + mine[0]) * dl).to(q.dtype), ((dk + mine[1]) * dl).to(k.dtype), None, None
 
 
 class TripletSigCosFn(torch.autograd.Function):
@@ -908,38 +954,25 @@ class TokenMeanFn(torch.autograd.Function):
 class GraphAggregateFn(torch.autograd.Function):
     """agg[b] = [ahat[b] @ feat[b, :Nr] ; feat[b, Nr:]] — the normalised neighbourhood sum of a batch of dense graphs
     whose nodes >= Nr are virtual padding nodes with only a self loop (basic_model._GraphConvDense).  One Function
-    so that backward is one clone + one batched product instead of autograd's slice / cat / accumulate chain
-    (two zero fills, two slice copies and an add per layer)."""
+    so that backward is one launch instead of autograd's slice / cat / accumulate chain.  Up to 128 real atoms: the MFMA
+    kernel with both operands in LDS; beyond: the vector-ALU form of the same sums (csrc/graph.hip).  No torch path."""
 
     @staticmethod
-    def _hip(ahat, feat):
-        return (feat.is_cuda and ahat.shape[-1] <= 128 and feat.shape[-1] == 128 and ahat.dtype == feat.dtype
-                and feat.dtype in (torch.float32, torch.bfloat16))
+    def _check(ahat, feat):
+        if not (feat.is_cuda and feat.shape[-1] == 128 and ahat.dtype == feat.dtype and feat.dtype in (torch.float32, torch.bfloat16)):
+            raise RuntimeError("GraphAggregateFn: device tensors of width 128 in one of fp32 / bf16 expected (got %s %s, %s %s): "
+                               "there is no torch fallback" % (tuple(ahat.shape), ahat.dtype, tuple(feat.shape), feat.dtype))
 
     @staticmethod
     def forward(ctx, ahat, feat):
-        Nr = ahat.shape[-1]
+        GraphAggregateFn._check(ahat, feat)
         ctx.save_for_backward(ahat)
-        if GraphAggregateFn._hip(ahat, feat):
-            return ops.graph_aggregate(ahat, feat, transpose=False)        # one launch per layer on the HIP path
-        # graphs with more than 128 real atoms: batched product through the BLAS library
-        if Nr == feat.shape[1]:
-            return torch.bmm(ahat, feat)
-        out = feat.clone()
-        out[:, :Nr] = torch.bmm(ahat, feat[:, :Nr])
-        return out
+        return ops.graph_aggregate(ahat, feat, transpose=False)        # one launch per layer (any number of real atoms)
 
     @staticmethod
     def backward(ctx, dout):
         (ahat,) = ctx.saved_tensors
-        Nr = ahat.shape[-1]
-        if GraphAggregateFn._hip(ahat, dout):
-            return None, ops.graph_aggregate(ahat, dout.contiguous(), transpose=True)
-        if Nr == dout.shape[1]:
-            return None, torch.bmm(ahat.transpose(1, 2), dout)
-        dfeat = dout.clone()
-        dfeat[:, :Nr] = torch.bmm(ahat.transpose(1, 2), dout[:, :Nr])
-        return None, dfeat
+        return None, ops.graph_aggregate(ahat, dout.contiguous(), transpose=True)
 
 
 class EmbeddingFn(torch.autograd.Function):

@@ -52,13 +52,10 @@ class _GraphConvDense(nn.Module):
     def normalised_adjacency(adj, dtype):
         """ahat[b][i][j] = din[i] * adj[b][j][i] * dout[j] (D^-1/2 A^T D^-1/2 with clamped degrees) — computed ONCE per
         batch and shared by every layer (the adjacency carries no gradient)."""
-        if adj.is_cuda and adj.dtype == torch.float32 and adj.shape[-1] <= 190 and dtype in (torch.float32, torch.bfloat16):
-            return ops.norm_adjacency(adj, dtype)                       # one launch instead of eight
-        with torch.no_grad():
-            a = adj.float()
-            dout = a.sum(dim=-1).clamp(min=1).pow(-0.5)                 # out-degree of the source node j
-            din = a.sum(dim=-2).clamp(min=1).pow(-0.5)                  # in-degree of the destination i
-            return (a.transpose(1, 2) * din.unsqueeze(-1) * dout.unsqueeze(-2)).to(dtype).contiguous()
+        if not (adj.is_cuda and dtype in (torch.float32, torch.bfloat16)):
+            raise RuntimeError("normalised_adjacency: a device adjacency and an fp32 / bf16 compute dtype are required "
+                               "(the HIP path has no torch fallback)")
+        return ops.norm_adjacency(adj if adj.dtype == torch.float32 else adj.float(), dtype)   # one launch (any graph size)
 
     def forward(self, ahat, feat):
         """ahat: normalised adjacency (B, Nr, Nr) with Nr <= N nodes.  Nodes >= Nr are virtual padding nodes whose
@@ -224,7 +221,8 @@ class DrugLAMPBase(nn.Module):
         self.protein_extractor = ProteinCNN(n_hidden, [n_hidden] * 3, cfg["PROTEIN"]["KERNEL_SIZE"],
                                             cfg["PROTEIN"]["PADDING"])
         self.ssl_model = SSL(prot_extractor=self.protein_extractor, n_prot_feature=n_prot_feature,
-                             drug_ssl_type="simsiam", n_hidden=n_hidden)
+                             drug_ssl_type=str(cfg["RS"].get("DRUG_SSL_TYPE", "simsiam")), n_hidden=n_hidden,
+                             global_batch=bool(cfg["RS"].get("GLOBAL_BATCH", False)))
         self.cm_model = CrossModality(use_cm=True, hidden_size=n_hidden, max_margin=cfg["RS"]["MAX_MARGIN"],
                                       n_re=cfg["RS"]["RESET_EPOCH"], global_batch=bool(cfg["RS"].get("GLOBAL_BATCH", False)))
         if self.seq_len_q % self.site_len:
@@ -293,11 +291,9 @@ class DrugLAMPBase(nn.Module):
         m, raw = gca(prot_sites.permute(1, 0, 2), drug_nodes.permute(1, 0, 2), drug_nodes.permute(1, 0, 2),
                      need_weights=self.keep_raw_attention, need_raw=True)
         g = m.permute(1, 0, 2)
-        if prot_sites.is_cuda and prot_sites.dtype == g.dtype and (prot_sites.shape[-1] * g.element_size()) % 16 == 0 \
-                and (g.shape[-1] * g.element_size()) % 16 == 0:
-            m = Fn.Concat2Fn.apply(prot_sites, g)
-        else:
-            m = torch.cat((prot_sites, g), 2)
+        if prot_sites.dtype != g.dtype:
+            prot_sites = Fn.cast(prot_sites, g.dtype)
+        m = Fn.Concat2Fn.apply(prot_sites, g)          # dl_concat2 (row widths are multiples of 16 bytes: n_hidden = 128)
         m = mhla(m, add_residual=True)                                  # mhla(h) + h in one launch set
         # inputs arrive in the compute dtype and stay in it (the LayerNorm kernel keeps fp32 statistics either way):
         # no fp32 round trips between PGCA, MHLA, LayerNorm and PMMA

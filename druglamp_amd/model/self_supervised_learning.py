@@ -37,6 +37,14 @@ def prob_mask_like(t, prob):
     return torch.zeros_like(t).float().uniform_(0, 1) < prob
 
 
+def _on_hip(x, what):
+    """The heads run on the HIP path only (no torch fallback: a CPU tensor or an exotic dtype is an error, not a detour)."""
+    if not (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)):
+        raise RuntimeError("%s: a device tensor in fp32 or bf16 is required (got %s on %s); druglamp_amd has no CPU path"
+                           % (what, x.dtype, x.device))
+    return x
+
+
 def _simsiam_mlp(dim, proj_out, hidden=512):
     return nn.Sequential(nn.Linear(dim, hidden, bias=False), nn.BatchNorm1d(hidden), nn.ReLU(inplace=True),
                          nn.Linear(hidden, hidden, bias=False), nn.BatchNorm1d(hidden), nn.ReLU(inplace=True),
@@ -57,9 +65,7 @@ class SimProj(nn.Module):
         """x may carry zero padding columns beyond in_dim (the fill-bit-augmented LLM features are 385 -> 392 wide)."""
         if self.projector is None:
             self.projector = _simsiam_mlp(in_dim or x.shape[1], self.projection_out, self.projection_hidden_size).to(x.device)
-        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
-            return Fn.run_mlp(self.projector, x)
-        return self.projector(x[:, :self.projector[0].in_features])
+        return Fn.run_mlp(self.projector, _on_hip(x, "SimProj"))
 
 
 class SSL(nn.Module):
@@ -68,7 +74,11 @@ class SSL(nn.Module):
         self.extractor = prot_extractor
         self.to_logits = nn.Linear(128, 26 + 1)
         self.llm_to_logits = nn.Linear(n_prot_feature + 1, 26 + 1)
+        if drug_ssl_type not in ("simsiam", "simclr"):
+            raise ValueError("drug_ssl_type must be 'simsiam' or 'simclr' (got %r)" % (drug_ssl_type,))
         self.drug_ssl_type = drug_ssl_type
+        # NEW (RS.GLOBAL_BATCH): at world > 1 the NT-Xent denominator of drug_simclr runs over the all-gathered batch
+        self.global_batch = bool(kwargs.get("global_batch", False))
         self.net = SimProj(n_hidden)
         self.llm_net = SimProj(n_hidden)
         if drug_ssl_type == "simsiam":
@@ -93,20 +103,18 @@ class SSL(nn.Module):
         if isinstance(xd, (tuple, list)) and isinstance(xd[1], int):
             xd, xd_dim = xd
         one, two = vd.reshape(-1, vd.shape[-1]), xd.reshape(-1, xd.shape[-1])
-        if one.is_cuda:
-            one, two = Fn.cast(one, self.compute_dtype), Fn.cast(two, self.compute_dtype)
+        one, two = Fn.cast(_on_hip(one, "SSL"), self.compute_dtype), Fn.cast(_on_hip(two, "SSL"), self.compute_dtype)
         return one, two, xd_dim
 
     def _predict(self, x):
-        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
-            return Fn.run_mlp(self.predictor, x)
-        return self.predictor(x)
+        return Fn.run_mlp(self.predictor, _on_hip(x, "SSL.predictor"))
 
     def drug_simclr(self, vd, xd):
         one, two, xd_dim = self._rows(vd, xd)
         q = self.net(one)
         k = self.llm_net(two, xd_dim)
-        return Fn.NTXentFn.apply(q.float(), k.float(), self.temperature)
+        # rows stay in the compute dtype: bf16 rows take the bf16 matrix pipe, log-sum-exp / loss / gradients are fp32
+        return Fn.NTXentFn.apply(q, k, self.temperature, self.global_batch)
 
     def drug_simsiam(self, vd, xd):
         one, two, xd_dim = self._rows(vd, xd)
@@ -131,9 +139,7 @@ class SSL(nn.Module):
 
         def head(lin, h):
             # nn.Linear on the HIP GEMM path (DenseFn: output padded to 32 columns, input may carry zero padding)
-            if h.is_cuda and h.dtype in (torch.float32, torch.bfloat16):
-                return Fn.dense(h, lin.weight, lin.bias)[..., :n_cls]
-            return lin(h[..., :lin.in_features])
+            return Fn.dense(_on_hip(h, "SSL.prot_mlm"), lin.weight, lin.bias)[..., :n_cls]
 
         def ce(lg):
             # the reference's F.cross_entropy(logits.transpose(1, 2), labels, ignore_index=0) (:93-99) = mean over the
@@ -149,12 +155,9 @@ class SSL(nn.Module):
 
     def forward(self, vp, xp, fill_bit_p, vd, xd, p_mode="double", mask=None, replace=None):
         if isinstance(xp, (tuple, list)):          # (embeddings (B,S,640), fill bit (B,S)) -> (B,S,641)
-            if xp[0].is_cuda and xp[0].dtype in (torch.float32, torch.bfloat16):
-                # one pass: fill-bit-augmented features, zero-padded to 648 columns, compute dtype
-                from .. import ops
-                xp = ops.fill_pool(xp[0], 1, self.compute_dtype)[1]
-            else:
-                xp = torch.cat((xp[0], xp[1].unsqueeze(-1).to(xp[0].dtype)), dim=-1)
+            # one pass: fill-bit-augmented features, zero-padded to 648 columns, compute dtype
+            from .. import ops
+            xp = ops.fill_pool(_on_hip(xp[0], "SSL"), 1, self.compute_dtype)[1]
         if isinstance(xd, (tuple, list)) and not isinstance(xd[1], int):
             xd = torch.cat((xd[0], xd[1].unsqueeze(-1).to(xd[0].dtype)), dim=-1)
         prot = self.prot_mlm(vp, self.extractor, xp, fill_bit_p, p_mode, mask=mask, replace=replace)

@@ -456,6 +456,41 @@ def ntxent_bwd(q, k, temperature: float, lse, grad_out: float):
     return dq, dk
 
 
+def _ntx_args(aq, ak, bq, bk, off_a, off_b, n_global, temperature, lse_a=None, lse_b=None):
+    _need_gpu(aq, ak, bq, bk)
+    assert aq.dtype == ak.dtype == bq.dtype == bk.dtype and aq.dtype in (torch.float32, torch.bfloat16)
+    assert aq.is_contiguous() and ak.is_contiguous() and bq.is_contiguous() and bk.is_contiguous()
+    assert aq.shape == ak.shape and bq.shape == bk.shape and aq.shape[1] == bq.shape[1]
+    a = _lib.NtxentArgs()
+    a.a.q, a.a.k, a.a.n, a.a.gid_offset = aq.data_ptr(), ak.data_ptr(), aq.shape[0], int(off_a)
+    a.b.q, a.b.k, a.b.n, a.b.gid_offset = bq.data_ptr(), bk.data_ptr(), bq.shape[0], int(off_b)
+    a.a.lse = lse_a.data_ptr() if lse_a is not None else None
+    a.b.lse = lse_b.data_ptr() if lse_b is not None else None
+    a.n_global, a.d, a.dtype, a.temperature = int(n_global), aq.shape[1], _dt(aq), float(temperature)
+    return a
+
+
+def ntxent_fwd_ex(aq, ak, bq, bk, off_a: int, off_b: int, n_global: int, temperature: float):
+    """Rows [aq; ak] scored against rows [bq; bk] (dl_ntxent_fwd_ex): returns (mean row loss (1,), row_lse (2 n_a,),
+    row_loss (2 n_a,)), all fp32."""
+    a = _ntx_args(aq, ak, bq, bk, off_a, off_b, n_global, temperature)
+    n2 = 2 * aq.shape[0]
+    loss = torch.empty(1, dtype=torch.float32, device=aq.device)
+    lse = torch.empty(n2, dtype=torch.float32, device=aq.device)
+    row_loss = torch.empty(n2, dtype=torch.float32, device=aq.device)
+    check(_lib.lib().dl_ntxent_fwd_ex(a, lse.data_ptr(), row_loss.data_ptr(), loss.data_ptr(), _stream()), "dl_ntxent_fwd_ex")
+    return loss, lse, row_loss
+
+
+def ntxent_bwd_ex(aq, ak, bq, bk, off_a: int, off_b: int, n_global: int, temperature: float, lse_a, lse_b, grad_scale: float):
+    """Gradient with respect to the rows [aq; ak] (dl_ntxent_bwd_ex), fp32."""
+    a = _ntx_args(aq, ak, bq, bk, off_a, off_b, n_global, temperature, lse_a, lse_b)
+    da_q = torch.empty(aq.shape, dtype=torch.float32, device=aq.device)
+    da_k = torch.empty(ak.shape, dtype=torch.float32, device=aq.device)
+    check(_lib.lib().dl_ntxent_bwd_ex(a, float(grad_scale), da_q.data_ptr(), da_k.data_ptr(), _stream()), "dl_ntxent_bwd_ex")
+    return da_q, da_k
+
+
 def triplet_sigcos_fwd(p_lats, d_lats, gt_i8, margin: float):
     n_p, dim = p_lats.shape
     n_d = d_lats.shape[0]

@@ -370,6 +370,37 @@ int dl_cos_rowloss_fwd(const float* x, const float* y, float* row_loss, float* l
                        int64_t n_rows, int64_t D, dl_stream s);
 int dl_cos_rowloss_bwd(const float* x, const float* y, float grad_scale, float* dx, int64_t n_rows,
                        int64_t D, dl_stream s);
+/* General form (round 3): the rows whose loss / gradient a call produces (side `a`, resident) are scored against a second
+ * set of rows (side `b`, streamed); each side is [q rows ; k rows], n rows per half, row-major (n x d), dtype DL_F32 or
+ * DL_BF16 (bf16 operands on v_mfma_f32_16x16x32_bf16, log-sum-exp / loss / gradients in fp32).  Rows are identified
+ * by their index in the GLOBAL batch: row r of a side's q half is gid_offset + r, of its k half n_global + gid_offset + r;
+ * a row's positive is the same sample in the other half, its own column is excluded (the reference removes the diagonal,
+ * self_supervised_learning.py:172-176).  One process: a = b = {q, k, n, 0}, n_global = n (what dl_ntxent_fwd / _bwd do).
+ * Data parallel (north star: the contrastive denominator sees the global batch; the reference is rank-local): a = this
+ * rank's rows {q_loc, k_loc, n, rank * n}, b = the all-gathered rows {q_all, k_all, world * n, 0}, n_global = world * n.
+ *   dl_ntxent_fwd_ex: row_lse[2 a.n], row_loss[2 a.n] (= lse_i - logit(i, positive)), *loss (optional) = mean row_loss.
+ *   dl_ntxent_bwd_ex: da_q, da_k (fp32, a.n x d) = grad_scale / T * sum_j w_ij b_j with
+ *     w_ij = [a.lse] softmax_i(j) + [b.lse] softmax_j(i) - (#lse given) [j positive of i]; a.lse / b.lse = that side's
+ *     row_lse from the forward call, or NULL if the side's rows are not softmax rows of this call.  Both given = the
+ *     whole gradient of the single-process loss in one pass; the data-parallel path calls it twice (local rows with
+ *     their lse against the gathered rows, and the gathered rows against the local rows with their lse: the latter is
+ *     the key-side gradient that a reduce-scatter returns to its owners). */
+typedef struct dl_ntxent_side {
+  const void* q;          /* n x d rows of the first half */
+  const void* k;          /* n x d rows of the second half */
+  int64_t n;
+  int64_t gid_offset;
+  const float* lse;       /* backward only; 2 n floats or NULL */
+} dl_ntxent_side;
+typedef struct dl_ntxent_args {
+  dl_ntxent_side a, b;
+  int64_t n_global;
+  int64_t d;              /* 64 or 128 */
+  int32_t dtype;          /* DL_F32 | DL_BF16, both sides */
+  float temperature;
+} dl_ntxent_args;
+int dl_ntxent_fwd_ex(const dl_ntxent_args* a, float* row_lse, float* row_loss, float* loss, dl_stream s);
+int dl_ntxent_bwd_ex(const dl_ntxent_args* a, float grad_scale, float* da_q, float* da_k, dl_stream s);
 size_t dl_ntxent_workspace_bytes(int64_t n, int64_t d);
 int dl_ntxent_fwd(const float* q, const float* k, int64_t n, int64_t d, float temperature,
                   float* loss, float* row_lse, void* workspace, size_t workspace_bytes,
@@ -398,7 +429,7 @@ int dl_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
 /* ------------------------------------------------------------------------------------------
  * Kernel timing hooks used by bench.py for the roofline object: when enabled for a kernel
  * family, launches are bracketed by hipEventRecord on their own stream.
- * family: 0 gemm, 1 attn_fwd, 2 attn_bwd, 3 layernorm, 4 attn_fwd_fp8 (quantisation + attention).
+ * family: 0 gemm, 1 attn_fwd, 2 attn_bwd, 3 layernorm, 4 attn_fwd_fp8 (quantisation + attention), 5 ntxent_fwd, 6 ntxent_bwd.
  * These event lists are the library's ONLY process-global state; they exist while a family is enabled and are
  * never touched otherwise (dl_prof_enable(family, 0) frees them).
  * dl_prof_enable(family, on): on = 0 off; on = N >= 1 times one launch in N of the family, picked by a hash

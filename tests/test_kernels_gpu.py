@@ -318,7 +318,7 @@ def test_norm_adjacency_matches_the_torch_formula():
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
-@pytest.mark.parametrize("n", [128, 77, 5])
+@pytest.mark.parametrize("n", [128, 77, 5, 129, 190, 333, 512])
 def test_graph_aggregate_matches_batched_product(dt, tol, n):
     """dl_graph_aggregate (MolecularGCN neighbourhood sum on dense batched graphs, reference basic_model.py:591-617) against
     torch.bmm in fp64, forward (ahat) and gradient (ahat^T) forms; virtual nodes n..N-1 pass through unchanged."""
@@ -333,6 +333,12 @@ def test_graph_aggregate_matches_batched_product(dt, tol, n):
         ref = torch.bmm(a, feat[:, :n].double())
         assert float((out[:, :n].double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
         assert torch.equal(out[:, n:], feat[:, n:])
+    if n > 190:       # adjacency normalisation beyond the LDS tile (round 3: no torch fallback for any graph size)
+        adj = (torch.rand(2, n, n, generator=g) < 0.02).float().cuda()
+        dout = adj.sum(-1).clamp(min=1).pow(-0.5)
+        din = adj.sum(-2).clamp(min=1).pow(-0.5)
+        want = adj.transpose(1, 2) * din.unsqueeze(-1) * dout.unsqueeze(-2)
+        assert (ops.norm_adjacency(adj, torch.float32) - want).abs().max() <= 1e-6
 
 
 @pytest.mark.parametrize("M,N,K", [(49152, 512, 256), (49000, 520, 192), (65536, 1024, 256)])
