@@ -23,6 +23,7 @@
 //           single-process symmetric case (one pass gives the whole gradient); the data-parallel path runs it twice:
 //           (A = local rows with their lse, B = gathered) for the query-side gradient and (A = gathered, B = local rows
 //           with their lse) for the key-side gradient that the reduce-scatter then returns to the owners.
+#include <type_traits>
 #include "tiles.cuh"
 
 namespace {
@@ -48,46 +49,57 @@ __global__ __launch_bounds__(ATT_THREADS) void ntxent_kernel(const NtxP p) {
   constexpr int TILE = 64 * TL::RB;
   constexpr int NCH = 64 * TL::CPR / ATT_THREADS;   // DMA instructions per thread per tile
   static_assert(64 * TL::CPR % ATT_THREADS == 0, "whole DMA instructions per thread");
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + (BWD ? 2 * 64 * (int)sizeof(float) : 0)];
-  float* lse_s = reinterpret_cast<float*>(smem + 2 * TILE);
+  // ring of NST tiles, D = NST - 1 tiles in flight: a 64-column tile is ~1000 cycles of work per wave, less than one
+  // L2 round trip, so with ONE tile in flight (round-3 first version: 304 TFLOP/s) every tile waited for its data
+  constexpr int NST = (TILE <= 16384) ? 4 : 3, D = NST - 1, PERT = NCH + (BWD ? 1 : 0);
+  static_assert(D <= 3 && (D - 1) * PERT < 64, "vmcnt immediate");
+  __shared__ __attribute__((aligned(16))) char smem[NST * TILE + (BWD ? NST * 256 : 0)];
+  const float* lse_s = reinterpret_cast<const float*>(smem + NST * TILE);
+  const uint32_t smem_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, il = lane & 15, g = lane >> 4;
   const int64_t na2 = 2 * p.na, nb2 = 2 * p.nb;
   const float c = p.inv_t * LOG2E;
 
-  // resident rows
+  // resident rows.  jself / jpos: the STREAMED side's row index of this row's own column / of its positive (or a
+  // value no tile contains): the per-score index tests then only run in the few tiles that hold one of them
   u32x4 af[RT][NKF];
-  int64_t arow[RT], gself[RT], gpos[RT];
+  int64_t arow[RT];
+  int jself[RT], jpos[RT];
   bool aok[RT];
+  auto b_index = [&](int64_t gid) -> int {       // row of the streamed side with this global id, or -2^30
+    const bool first = gid < p.ng;
+    const int64_t r = (first ? gid : gid - p.ng) - p.offb;
+    return (r >= 0 && r < p.nb) ? (int)(first ? r : p.nb + r) : -(1 << 30);
+  };
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int64_t a = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT) + rt * 16 + il;
     arow[rt] = a; aok[rt] = a < na2;
     const int64_t ac = aok[rt] ? a : 0;
     const T* src = reinterpret_cast<const T*>(ac < p.na ? p.aq : p.ak) + (ac < p.na ? ac : ac - p.na) * HD;
-    gself[rt] = ntx_gid(ac, p.na, p.offa, p.ng);
-    gpos[rt] = gself[rt] < p.ng ? gself[rt] + p.ng : gself[rt] - p.ng;
+    const int64_t gs = ntx_gid(ac, p.na, p.offa, p.ng);
+    jself[rt] = b_index(gs);
+    jpos[rt] = b_index(gs < p.ng ? gs + p.ng : gs - p.ng);
 #pragma unroll
     for (int kf = 0; kf < NKF; ++kf) af[rt][kf] = frag_global<T>(src, aok[rt], kf, g);
   }
 
   // streamed tiles: LDS slot (row, physical chunk pc) receives the row's logical chunk pc ^ swz(row); rows past the end
-  // are clamped to the last row (their scores are masked)
+  // are clamped to the last row (their scores are masked).  Backward: the tile's 64 log-sum-exp values ride along as one
+  // dword DMA (every wave issues it — same bytes, same place — so that all waves count the same number of requests).
   auto issue = [&](int64_t j0, int buf) {
-    char* dst = smem + buf * TILE;
+    const uint32_t dst = smem_lds + buf * TILE;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int ch = tid + i * ATT_THREADS, row = ch / TL::CPR, pc = ch % TL::CPR;
       int64_t j = j0 + row; j = j < nb2 ? j : nb2 - 1;
       const char* src = (j < p.nb ? p.bq + j * (int64_t)TL::RB : p.bk + (j - p.nb) * (int64_t)TL::RB) + ((pc ^ TL::swz(row)) << 4);
-      const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((ch - (tid & 63)) * 16));
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
+      lds_dma16(src, __builtin_amdgcn_readfirstlane(dst + (uint32_t)((ch - (tid & 63)) * 16)));
     }
     if constexpr (BWD) {
-      if (tid < 64) {
-        const int64_t j = j0 + tid;
-        lse_s[buf * 64 + tid] = (p.lseb && j < nb2) ? p.lseb[j] * LOG2E : INFINITY;
-      }
+      int64_t j = j0 + lane; j = j < nb2 ? j : nb2 - 1;
+      const void* src = p.lseb ? (const void*)(p.lseb + j) : (const void*)p.bq;
+      lds_dma4(src, smem_lds + (uint32_t)(NST * TILE + buf * 256));
     }
   };
 
@@ -101,13 +113,23 @@ __global__ __launch_bounds__(ATT_THREADS) void ntxent_kernel(const NtxP p) {
     for (int d = 0; d < (BWD ? NDT : 1); ++d) acc[rt][d] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float npos = BWD ? ((p.lsea ? 1.f : 0.f) + (p.lseb ? 1.f : 0.f)) : 0.f;
+  const int wmode = BWD ? ((p.lsea && p.lseb) ? 0 : p.lsea ? 1 : 2) : 0;      // which softmax terms a weight has
 
-  issue(0, 0);
+  const int64_t nt = (nb2 + 63) / 64;
+#pragma unroll
+  for (int t0 = 0; t0 < D; ++t0)
+    if (t0 < nt) issue((int64_t)t0 * 64, t0);
   int buf = 0;
-  for (int64_t j0 = 0; j0 < nb2; j0 += 64, buf ^= 1) {
-    __syncthreads();                                   // tile j0 has landed (the barrier's release drains the DMA) and
-                                                       // every wave is done with the other buffer
-    if (j0 + 64 < nb2) issue(j0 + 64, buf ^ 1);
+  for (int64_t t = 0; t < nt; ++t, buf = (buf + 1 == NST) ? 0 : buf + 1) {
+    const int64_t j0 = t * 64;
+    // tile t has landed once only the younger tiles' requests are outstanding (counted: they stay in flight across the
+    // barrier); past the barrier every wave is also done with tile t - 1, whose buffer takes tile t + D
+    const int younger = (int)min((int64_t)(D - 1), nt - 1 - t);
+    if (younger <= 0) vm_wait<0>();
+    else if (younger == 1) vm_wait<PERT>();
+    else vm_wait<2 * PERT>();
+    raw_barrier();
+    if (t + D < nt) issue((t + D) * 64, (buf + D) % NST);
     const char* Bs = smem + buf * TILE;
     f32x4 s[RT][NKT];
 #pragma unroll
@@ -121,50 +143,83 @@ __global__ __launch_bounds__(ATT_THREADS) void ntxent_kernel(const NtxP p) {
         for (int rt = 0; rt < RT; ++rt) s[rt][kt] = Mma<T>::mma(bf, af[rt][kf], s[rt][kt]);
       }
     }
-    // global ids of this lane's 16 columns: j = j0 + kt*16 + 4g + r
-    const int64_t jb = j0 + 4 * g;
+    // does this tile hold the own / positive column of one of the wave's rows, or the end of the streamed side?
+    const int j0i = (int)j0;
+    bool special = j0 + 64 > nb2;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) special |= (unsigned)(jself[rt] - j0i) < 64u || (unsigned)(jpos[rt] - j0i) < 64u || !aok[rt];
+    const bool slow = __builtin_amdgcn_ballot_w64(special) != 0;          // wave-uniform
+    const int jb = j0i + 4 * g;                                          // this lane's columns: jb + kt*16 + r
     if constexpr (!BWD) {
+      // two straight-line copies selected by the wave-uniform `slow` (left to the compiler the index tests became ~500
+      // compare / select instructions executed on EVERY tile)
+      auto softmax_tile = [&](auto slow_) __attribute__((always_inline)) {
+        constexpr bool SLOW = decltype(slow_)::value;
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        float mx = -INFINITY;
+        for (int rt = 0; rt < RT; ++rt) {
+          if constexpr (SLOW) {
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t j = jb + kt * 16 + r;
-            const int64_t gj = ntx_gid(j, p.nb, p.offb, p.ng);
-            if (gj == gpos[rt] && j < nb2) pos_logit[rt] = s[rt][kt][r] * p.inv_t;
-            if (gj == gself[rt] || j >= nb2) s[rt][kt][r] = -INFINITY;
-            mx = fmaxf(mx, s[rt][kt][r]);
+              for (int r = 0; r < 4; ++r) {
+                const int j = jb + kt * 16 + r;
+                if (j == jpos[rt]) pos_logit[rt] = s[rt][kt][r] * p.inv_t;
+                if (j == jself[rt] || j >= nb2) s[rt][kt][r] = -INFINITY;
+              }
           }
-        const float m_new = fmaxf(m_run[rt], mx);
-        if (m_new > -INFINITY) {
-          float rs = 0.f;
+          float mx = fmaxf(fmaxf(s[rt][0][0], s[rt][0][1]), fmaxf(s[rt][0][2], s[rt][0][3]));
 #pragma unroll
-          for (int kt = 0; kt < NKT; ++kt)
+          for (int kt = 1; kt < NKT; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(s[rt][kt][0], s[rt][kt][1]), fmaxf(s[rt][kt][2], s[rt][kt][3])));
+          const float m_new = fmaxf(m_run[rt], mx);
+          // (a lane whose columns so far were all masked keeps m = -inf: its terms are exp2(-inf) = 0, no NaN as long as
+          //  the subtraction is skipped)
+          const float mc = (m_new > -INFINITY) ? m_new * c : 0.f;
+          float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rs += exp2f((s[rt][kt][r] - m_new) * c);
-          l_run[rt] = l_run[rt] * exp2f((m_run[rt] - m_new) * c) + rs;
+          for (int kt = 0; kt < NKT; ++kt) {
+            rs0 += __builtin_amdgcn_exp2f(__builtin_fmaf(s[rt][kt][0], c, -mc)) + __builtin_amdgcn_exp2f(__builtin_fmaf(s[rt][kt][1], c, -mc));
+            rs1 += __builtin_amdgcn_exp2f(__builtin_fmaf(s[rt][kt][2], c, -mc)) + __builtin_amdgcn_exp2f(__builtin_fmaf(s[rt][kt][3], c, -mc));
+          }
+          const float alpha = (m_run[rt] > -INFINITY) ? __builtin_amdgcn_exp2f(__builtin_fmaf(m_run[rt], c, -mc)) : 0.f;
+          l_run[rt] = l_run[rt] * alpha + (rs0 + rs1);
           m_run[rt] = m_new;
         }
-      }
+      };
+      if (!slow) softmax_tile(std::false_type{}); else softmax_tile(std::true_type{});
     } else {
       const float* lj = lse_s + buf * 64;
+      // the weight loop in straight-line copies: which softmax terms exist (wmode) and whether any index test is needed
+      // are wave-uniform, so they are decided OUTSIDE the 16 x RT scores of a lane
+      auto weights = [&](auto mode, auto slow_) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode)::value;
+        constexpr bool SLOW = decltype(slow_)::value;
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {
-        const f32x4 lb = *reinterpret_cast<const f32x4*>(lj + kt * 16 + 4 * g);
+        for (int kt = 0; kt < NKT; ++kt) {
+          f32x4 lb = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (MODE != 1) lb = *reinterpret_cast<const f32x4*>(lj + kt * 16 + 4 * g) * LOG2E;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+          for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t j = jb + kt * 16 + r;
-            const int64_t gj = ntx_gid(j, p.nb, p.offb, p.ng);
-            const float x = s[rt][kt][r] * c;
-            float w = exp2f(x - lse_a[rt]) + exp2f(x - lb[r]);       // a side without lse holds +inf: exp2(-inf) = 0
-            if (gj == gpos[rt]) w -= npos;
-            if (gj == gself[rt] || j >= nb2 || !aok[rt]) w = 0.f;
-            s[rt][kt][r] = w;
-          }
+            for (int r = 0; r < 4; ++r) {
+              const float sv = s[rt][kt][r];
+              float w;
+              if constexpr (MODE == 0) w = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c, -lse_a[rt])) + __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c, -lb[r]));
+              else if constexpr (MODE == 1) w = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c, -lse_a[rt]));
+              else w = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c, -lb[r]));
+              if constexpr (SLOW) {
+                const int j = jb + kt * 16 + r;
+                if (j == jpos[rt]) w -= npos;
+                if (j == jself[rt] || j >= nb2 || !aok[rt]) w = 0.f;
+              }
+              s[rt][kt][r] = w;
+            }
+        }
+      };
+      typedef std::integral_constant<int, 0> M0; typedef std::integral_constant<int, 1> M1; typedef std::integral_constant<int, 2> M2;
+      if (!slow) {
+        if (wmode == 0) weights(M0{}, std::false_type{}); else if (wmode == 1) weights(M1{}, std::false_type{}); else weights(M2{}, std::false_type{});
+      } else {
+        if (wmode == 0) weights(M0{}, std::true_type{}); else if (wmode == 1) weights(M1{}, std::true_type{}); else weights(M2{}, std::true_type{});
       }
 #pragma unroll
       for (int kp = 0; kp < NKT / CT; ++kp) {
@@ -257,6 +312,7 @@ int ntx_fill(const dl_ntxent_args* a, NtxP& p, const char* what) {
   DL_CHECK_ARG(a->d == 64 || a->d == 128, DL_ERR_UNSUPPORTED, "%s: d must be 64 or 128 (got %ld)", what, (long)a->d);
   DL_CHECK_ARG(a->dtype == DL_F32 || a->dtype == DL_BF16, DL_ERR_ARG, "%s: bad dtype", what);
   DL_CHECK_ARG(a->temperature > 0.f, DL_ERR_ARG, "%s: temperature must be > 0", what);
+  DL_CHECK_ARG(a->a.n < (1ll << 29) && a->b.n < (1ll << 29), DL_ERR_SHAPE, "%s: at most 2^29 rows per half", what);
   DL_CHECK_ARG(a->n_global >= a->a.gid_offset + a->a.n && a->n_global >= a->b.gid_offset + a->b.n, DL_ERR_SHAPE,
                "%s: a side does not fit the global batch (n_global %ld)", what, (long)a->n_global);
   p.aq = (const char*)a->a.q; p.ak = (const char*)a->a.k; p.bq = (const char*)a->b.q; p.bk = (const char*)a->b.k;

@@ -101,4 +101,18 @@ __device__ __forceinline__ u32x4 frag_from_acc(const f32x4* t) {
 }
 
 
+// ---- LDS-DMA as inline assembly (invisible to the compiler's wait-count model: counted vmcnt waits stay counted) ----
+// one instruction = 64 lanes x 16 (4) bytes -> 1 KB (256 B) of LDS at lds_off + 16 (4) * lane
+__device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_off) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_off) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void* gsrc, uint32_t lds_off) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lds_off) : "memory");
+}
+template <int N> __device__ __forceinline__ void vm_wait() {
+  static_assert(N >= 0 && N < 64, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
 }  // namespace dltile
