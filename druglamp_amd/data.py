@@ -81,6 +81,7 @@ class RowTable:
             adj[d, extra[:, 0], extra[:, 1]] = 1
             adj[d, extra[:, 1], extra[:, 0]] = 1
             adj[d].fill_diagonal_(1)
+            adj[d, torch.arange(n), torch.arange(n)] = 2             # real atoms carry two self loops in the reference's graphs
         self.h, self.adj = h.to(self.device), adj.to(self.device)
         # synthetic "pre-extracted" LLM embeddings in a device-resident store (rows: Lp + 2 protein tokens, <= 128 drug tokens)
         self.prot_store = EmbeddingStore(640, dtype=llm_dtype, device=self.device)

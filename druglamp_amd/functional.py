@@ -134,6 +134,11 @@ def _refresh_all_images() -> None:
             e.versions, e.epoch = tuple(p._version for p in ps), _param_epoch
 
 
+def refresh_images() -> None:
+    """Refresh every weight image now (and rebuild the refresh's item tables if the set of live images changed)."""
+    _refresh_all_images()
+
+
 def lowp(params: Sequence[torch.Tensor], dtype: torch.dtype, transpose: bool = False, pad=None) -> torch.Tensor:
     """Compute-dtype tensor holding cat(params, dim=0) (a single fp32 param is returned as is in fp32).
     transpose=True gives the [in][out] copy used by the data-gradient products, so that those are

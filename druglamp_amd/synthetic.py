@@ -47,7 +47,9 @@ def make_batch(B: int, device, seed: int = 0, with_graph: bool = True, llm_dtype
             extra = torch.randint(0, n, (max(n // 5, 1), 2), generator=g)
             adj[b, extra[:, 0], extra[:, 1]] = 1
             adj[b, extra[:, 1], extra[:, 0]] = 1
-            adj[b].fill_diagonal_(1)
+            adj[b].fill_diagonal_(1)                                # nodes n..adj_nodes-1 of the block: virtual, one self loop
+            adj[b, torch.arange(n), torch.arange(n)] = 2             # real atoms: TWO self loops, as handler/dataset.py:211-222 builds them
+                                                                     # (smiles_to_bigraph(add_self_loop=True), then add_self_loop() again)
         feat_d = (h.to(device), adj.to(device))
     else:
         vd = torch.randn(B, 512, 128, generator=g)

@@ -255,6 +255,10 @@ class GraphedStep:
         # the images current, lowp() would skip the refresh during capture, and every replay would then compute with the
         # images frozen at capture time while AdamW keeps moving the fp32 masters.  Making the epoch stale puts the
         # refresh (and the derived-layout rebuilds) at the head of the captured forward; counted below.
+        # (the item tables of the refresh are rebuilt — a host-to-device copy, illegal during capture — whenever the set of
+        #  live images changed, e.g. an earlier model's images were garbage-collected: do that eagerly first)
+        Fn.bump_param_epoch()
+        Fn.refresh_images()
         Fn.bump_param_epoch()
         before = ops.weight_prep_launches()
         torch.cuda.synchronize(dev)

@@ -156,6 +156,36 @@ def protein_cnn(sd: SD, p: str, ids: torch.Tensor, fill: torch.Tensor, bn_traini
     return v.reshape(v.size(0), v.size(2), -1)
 
 
+def molecular_gcn(sd: SD, p: str, h: torch.Tensor, adj: torch.Tensor, bn_training: bool) -> torch.Tensor:
+    """MolecularGCN.forward (basic_model.py:137-153) -> GCN / GCNLayer (:342-436) -> GraphConv norm='both' (:545-638) on a
+    batch of DENSE graphs.  h: (B, N, 75) node features (N = 512: real atoms first, then the virtual padding nodes of
+    handler/dataset.py:211-222); adj: (B, n, n) edge counts adj[b][u][v] = number of edges u -> v among the first n nodes,
+    self loops included (real atoms carry TWO: smiles_to_bigraph(add_self_loop=True), then add_self_loop() again); nodes
+    >= n have exactly one edge, their self loop.  GraphConv (:594-631):
+        rst[v] = in_deg[v]^-1/2 * sum_{u -> v} out_deg[u]^-1/2 * feat[u]  (W applied after the sum: in_feats == out_feats)
+    with degrees clamped at 1; dgl's `update_all(copy_u, sum)` is the sum over incoming edges, written here as a dense
+    product with the edge-count matrix.  Pinned by tests/golden/gcn.npz: the reference's own GCN classes driven through
+    a scipy.sparse stand-in for the DGL graph (tests/golden/make_golden.py gen_gcn)."""
+    B, N, _ = h.shape
+    n = adj.shape[-1]
+    A = torch.zeros(B, N, N, dtype=h.dtype)
+    A[:, :n, :n] = adj
+    idx = torch.arange(n, N)
+    A[:, idx, idx] = 1.0
+    dout = A.sum(-1).clamp(min=1).pow(-0.5).unsqueeze(-1)             # out-degree of the source
+    din = A.sum(-2).clamp(min=1).pow(-0.5).unsqueeze(-1)              # in-degree of the destination
+    x = h @ sd[p + ".init_transform.weight"].t()
+    i = 0
+    while "%s.gnn.gnn_layers.%d.graph_conv.weight" % (p, i) in sd:
+        q = "%s.gnn.gnn_layers.%d" % (p, i)
+        rst = torch.bmm(A.transpose(1, 2), x * dout) @ sd[q + ".graph_conv.weight"]
+        conv = F.relu(rst * din + sd[q + ".graph_conv.bias"])                         # activation=F.relu inside GraphConv
+        new = conv + F.relu(_lin(sd, q + ".res_connection", x))                      # GCNLayer: residual, dropout 0
+        x = _bn(sd, q + ".bn_layer", new.reshape(B * N, -1), bn_training).reshape(B, N, -1)
+        i += 1
+    return x
+
+
 def _fill_bit(x: torch.Tensor) -> torch.Tensor:
     return (x.sum(dim=-1) == 0).to(x.dtype)                               # DrugLAMP.py:11-19
 

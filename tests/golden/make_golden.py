@@ -410,9 +410,100 @@ def gen_train_steps():
          didx=didx.numpy(), dsample=np.stack(rec["dsample"]), n_total=np.int64(n_total))
 
 
+# ---- MolecularGCN: the reference's OWN GCN / GCNLayer / GraphConv code (basic_model.py:137-153, 342-638) on a batched graph
+# object that stands in for DGL's batched DGLGraph.  DGL (1.0.2 in the reference's environment) is absent here; what the
+# reference takes from it on this path is exactly:  graph.in_degrees() / out_degrees(),  graph.update_all(copy_u('h','m'),
+# sum('m','h'))  (dgl message passing: every edge u -> v carries the source's feature, a destination sums what arrives),
+# local_scope(), srcdata / dstdata, ndata, batch_size, is_block.  The stand-in implements those with scipy.sparse from an
+# edge list (multi-edges kept: DGL counts them).  So this fixture pins everything the reference's source says about the
+# GCN; DGL's own SpMM is replaced by the published semantics, not executed ("partially pinned").
+def gen_gcn():
+    import contextlib
+    import scipy.sparse as sp
+    import dgl.function as dfn                      # the harness' empty stand-in module: give it the two descriptors
+    dfn.copy_u = lambda u, out: ("copy_u", u, out)
+    dfn.sum = lambda msg, out: ("sum", msg, out)
+    from model.basic_model import MolecularGCN
+
+    class _SpMM(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, mat, x):
+            ctx.mat = mat
+            return torch.from_numpy(np.asarray(mat @ x.detach().double().numpy())).to(x.dtype)
+
+        @staticmethod
+        def backward(ctx, g):
+            return None, torch.from_numpy(np.asarray(ctx.mat.T @ g.double().numpy())).to(g.dtype)
+
+    class BatchedGraph:
+        is_block = False
+
+        def __init__(self, src, dst, n_nodes, batch_size, h):
+            self.src, self.dst, self.n, self.batch_size = src, dst, n_nodes, batch_size
+            self.ndata = {"h": h}
+            self.srcdata = self.dstdata = {}
+            # destination-by-source incidence counts: rst[v] = sum over edges u -> v of feat[u]
+            self.m = sp.coo_matrix((np.ones(len(src)), (dst, src)), shape=(n_nodes, n_nodes)).tocsr()
+
+        @contextlib.contextmanager
+        def local_scope(self):
+            saved = dict(self.srcdata)
+            try:
+                yield
+            finally:
+                self.srcdata.clear()
+                self.srcdata.update(saved)
+
+        def out_degrees(self):
+            return torch.from_numpy(np.bincount(self.src, minlength=self.n))
+
+        def in_degrees(self):
+            return torch.from_numpy(np.bincount(self.dst, minlength=self.n))
+
+        def update_all(self, message, reduce):
+            assert message[0] == "copy_u" and reduce[0] == "sum" and message[2] == reduce[1]
+            self.dstdata[reduce[2]] = _SpMM.apply(self.m, self.srcdata[message[1]])
+
+    # graphs as handler/dataset.py:211-222 builds them: bond edges in both directions + a self loop per atom
+    # (smiles_to_bigraph(add_self_loop=True)), 512 - n virtual nodes appended, then add_self_loop() over ALL nodes — DGL's
+    # add_self_loop does not de-duplicate, so real atoms end up with TWO self loops, virtual nodes with one
+    rng = np.random.RandomState(5)
+    B, N = 3, 512
+    n_atoms = [23, 77, 150]
+    src, dst = [], []
+    h = np.zeros((B, N, 75), np.float32)
+    adj = np.zeros((B, max(n_atoms), max(n_atoms)), np.float32)
+    for b, n in enumerate(n_atoms):
+        bonds = [(i, i + 1) for i in range(n - 1)] + [tuple(rng.randint(0, n, 2)) for _ in range(n // 5)]
+        bonds = sorted({(min(u, v), max(u, v)) for u, v in bonds if u != v})
+        e = [(u, v) for u, v in bonds] + [(v, u) for u, v in bonds] + [(i, i) for i in range(n)] + [(i, i) for i in range(N)]
+        for u, v in e:
+            src.append(b * N + u); dst.append(b * N + v)
+            if u < adj.shape[1] and v < adj.shape[1]:
+                adj[b, u, v] += 1.0                   # adj[source][destination] over the first max(n_atoms) nodes, multiplicities
+                                                      # kept: diagonal 2 for real atoms, 1 for the virtual nodes inside the block
+        h[b, :n, :74] = (rng.rand(n, 74) < 0.1)
+        h[b, n:, 74] = 1.0
+    gcn = fill_module(MolecularGCN(75, 128, True, [128] * 3), salt=41)
+    with torch.no_grad():                              # padding=True zeroes the last output row at construction (:141-143); keep it
+        gcn.init_transform.weight[-1].fill_(0)
+    gcn.train()
+    ht = torch.from_numpy(h.reshape(B * N, 75))
+    g = BatchedGraph(np.asarray(src), np.asarray(dst), B * N, B, ht)
+    out = gcn(g)
+    w = T("gcn.cot", (B, N, 128), 1.0)
+    (out * w).sum().backward()
+    grads = {k: v.grad.detach().clone() for k, v in gcn.named_parameters()}
+    save("gcn", sd=sd_spec(gcn), h=h, adj=adj, n_atoms=np.asarray(n_atoms), out=out.detach(),
+         g_init=grads["init_transform.weight"], g_conv1=grads["gnn.gnn_layers.1.graph_conv.weight"],
+         g_res2=grads["gnn.gnn_layers.2.res_connection.weight"], g_bn0=grads["gnn.gnn_layers.0.bn_layer.weight"],
+         gnorm={k.replace(".", "_"): v.norm() for k, v in grads.items()},
+         rm2=gcn.gnn.gnn_layers[2].bn_layer.running_mean.detach())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pmma", "pgca", "mhla", "losses", "models", "sslcm", "train", "pmma_long", "model_long"]
+    which = sys.argv[1:] or ["pmma", "pgca", "mhla", "losses", "models", "sslcm", "train", "pmma_long", "model_long", "gcn"]
     table = dict(pmma=gen_pmma, pgca=gen_pgca, mhla=gen_mhla, losses=gen_losses, models=gen_models, sslcm=gen_ssl_cm,
-                 train=gen_train_steps, pmma_long=gen_pmma_long, model_long=gen_model_long)
+                 train=gen_train_steps, pmma_long=gen_pmma_long, model_long=gen_model_long, gcn=gen_gcn)
     for w in which:
         table[w]()

@@ -197,6 +197,38 @@ def test_gcn_dense_restatement_vs_plain_torch():
     assert relerr(go[0], gr[0]) <= 1e-3 and relerr(go[1], gr[1]) <= 1e-3
 
 
+@pytest.mark.parametrize("dt,tol_o,tol_g", [(torch.float32, 1e-4, 1e-3), (torch.bfloat16, 3e-2, 5e-2)])
+def test_gcn_hip_path_vs_the_reference_gcn_classes_golden(dt, tol_o, tol_g):
+    """MolecularGCN on the HIP path (dl_norm_adjacency, dl_graph_aggregate incl. the > 128-atom form, dl_gemm, dl_bn_*)
+    against tests/golden/gcn.npz — the reference's own GCN / GCNLayer / GraphConv code driven through a scipy.sparse
+    stand-in for the DGL graph (DGL's SpMM itself is not executed: "partially pinned")."""
+    from druglamp_amd.model.basic_model import MolecularGCN
+    from tests.helpers import T, det_state_dict, load
+    g = load("gcn")
+    sd = det_state_dict(g, salt=41)
+    sd["init_transform.weight"][-1].fill_(0)
+    gcn = MolecularGCN(75, 128, True, [128] * 3).to(DEV).train()
+    gcn.load_state_dict(sd, strict=True)
+    gcn.compute_dtype = dt
+    h, adj = torch.from_numpy(g["h"]).to(DEV), torch.from_numpy(g["adj"]).to(DEV)
+    out = gcn((h, adj))
+    assert relerr(out.float(), g["out"]) <= tol_o
+    (out.float() * T("gcn.cot", tuple(out.shape)).to(DEV)).sum().backward()
+    pairs = [(gcn.init_transform.weight.grad, g["g_init"]), (gcn.gnn.gnn_layers[1].graph_conv.weight.grad, g["g_conv1"]),
+             (gcn.gnn.gnn_layers[2].res_connection.weight.grad, g["g_res2"]), (gcn.gnn.gnn_layers[0].bn_layer.weight.grad, g["g_bn0"])]
+    for got, want in pairs:
+        if dt == torch.float32:
+            assert relerr(got, want) <= tol_g
+        else:
+            # bf16 activations through three BatchNorm layers (and their backward): element-wise errors of the earliest
+            # layer's gradient reach 10 % of its largest entry; what is checked is direction and size
+            a, b = got.double().flatten().cpu(), torch.from_numpy(np.asarray(want)).double().flatten()
+            assert float(torch.dot(a, b) / (a.norm() * b.norm())) >= 0.99
+            assert abs(float(a.norm() / b.norm()) - 1.0) <= tol_g
+    if dt == torch.float32:
+        assert relerr(gcn.gnn.gnn_layers[2].bn_layer.running_mean, g["rm2"]) <= 1e-4
+
+
 def test_skipping_dead_backward_passes_leaves_the_same_parameters(monkeypatch):
     """On an SSL + CM step the reference wipes the cls (and ssl) gradients before any optimiser steps; Trainer does not
     run those backward passes.  With DL_DEAD_BACKWARD=1 it does: the parameter arenas must be bit-identical."""

@@ -235,3 +235,25 @@ def test_model_long_forward_and_gradients():
         got = float(sd[k].grad.double().norm()) if sd[k].grad is not None else 0.0
         worst = max(worst, abs(got - n_ref) / max(n_ref, 1e-5))
     assert worst <= 2e-3, worst
+
+
+def test_molecular_gcn_vs_reference_gcn_classes():
+    """tests/golden/gcn.npz: the reference's OWN MolecularGCN / GCN / GCNLayer / GraphConv code
+    (/root/reference/model/basic_model.py:137-153,342-638) run on a scipy.sparse stand-in for the batched DGL graph
+    (make_golden.py gen_gcn: DGL is absent; its update_all(copy_u, sum) / in_degrees / out_degrees follow the published
+    semantics).  Graphs of 23 / 77 / 150 atoms, double self loops on real atoms as handler/dataset.py:211-222 builds them."""
+    g = load("gcn")
+    sd = det_state_dict(g, salt=41)
+    sd["init_transform.weight"][-1].fill_(0)                               # basic_model.py:141-143 (padding=True)
+    for v in sd.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    sd = {"gcn." + k: v for k, v in sd.items()}
+    h, adj = torch.from_numpy(g["h"]), torch.from_numpy(g["adj"])
+    out = O.molecular_gcn(sd, "gcn", h, adj, bn_training=True)
+    assert relerr(out, g["out"]) <= TOL
+    (out * T("gcn.cot", tuple(out.shape))).sum().backward()
+    assert relerr(sd["gcn.init_transform.weight"].grad, g["g_init"]) <= 1e-4
+    assert relerr(sd["gcn.gnn.gnn_layers.1.graph_conv.weight"].grad, g["g_conv1"]) <= 1e-4
+    assert relerr(sd["gcn.gnn.gnn_layers.2.res_connection.weight"].grad, g["g_res2"]) <= 1e-4
+    assert relerr(sd["gcn.gnn.gnn_layers.0.bn_layer.weight"].grad, g["g_bn0"]) <= 1e-4
