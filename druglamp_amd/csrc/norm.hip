@@ -177,6 +177,147 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
   }
 }
 
+// ---- bf16 rows of 256 / 512 columns (every LayerNorm of the path) with 16-byte accesses --------------------------------
+// A lane owns 8 consecutive columns (one 16-byte load / store per tensor and row): 32 lanes per 256-column row (two
+// rows per wave pass), 64 per 512-column row, four passes in flight per wave.  The 8-byte one-wave-per-row kernels above
+// reached 2.7 TB/s (backward) / 3.9-4.9 TB/s (forward) — 8-byte accesses run at 0.54-0.70 of the 16-byte rate.
+template <int LPR> __device__ __forceinline__ float seg_sum(float v) {      // sum over the LPR (32 / 64) lanes of a row
+  v = row16_sum(v);
+  const float lo = lane_f32(v, 0) + lane_f32(v, 16), hi = lane_f32(v, 32) + lane_f32(v, 48);
+  if constexpr (LPR == 64) return lo + hi;
+  else return (threadIdx.x & 32) ? hi : lo;
+}
+__device__ __forceinline__ void unpack8(u32x4 w, float (&f)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = bf16lo(w[e]); f[2 * e + 1] = bf16hi(w[e]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  return u32x4{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+}
+constexpr int LN16_PASSES = 4;
+
+template <int D>
+__global__ __launch_bounds__(256) void ln_fwd16_kernel(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, bf16_t* __restrict__ y, int64_t ldy,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t M, float eps) {
+  constexpr int LPR = D / 8, RPP = 64 / LPR, P = LN16_PASSES;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPR, cl = lane % LPR;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (RPP * P) + sub;
+  u32x4 w[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    const int64_t row = row0 + q * RPP;
+    w[q] = u32x4{0u, 0u, 0u, 0u};
+    if (row < M) w[q] = *reinterpret_cast<const u32x4*>(x + row * ldx + cl * 8);
+  }
+  float gm[8], bt[8];
+  { const f32x4 a = *reinterpret_cast<const f32x4*>(gamma + cl * 8), b = *reinterpret_cast<const f32x4*>(gamma + cl * 8 + 4);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(beta + cl * 8), d = *reinterpret_cast<const f32x4*>(beta + cl * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gm[e] = a[e]; gm[4 + e] = b[e]; bt[e] = c[e]; bt[4 + e] = d[e]; } }
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    const int64_t row = row0 + q * RPP;
+    float v[8];
+    unpack8(w[q], v);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e];
+    const float mean = seg_sum<LPR>(s) * (1.0f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; sq += d * d; }
+    const float rstd = rsqrtf(seg_sum<LPR>(sq) * (1.0f / D) + eps);
+    if (row < M) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
+      *reinterpret_cast<u32x4*>(y + row * ldy + cl * 8) = pack8(o);
+      if (cl == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+      }
+    }
+  }
+}
+
+// partial layout as ln_bwd_kernel: [M / LN_BWD_ROWS workgroups][2][D]
+template <int D>
+__global__ __launch_bounds__(256) void ln_bwd16_kernel(const bf16_t* __restrict__ dy, int64_t lddy, int64_t dy_share,
+                                                       const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const bf16_t* __restrict__ dres, int64_t lddres, bf16_t* __restrict__ dx,
+                                                       int64_t lddx, float* __restrict__ partial, int64_t M) {
+  constexpr int LPR = D / 8, RPP = 64 / LPR, P = LN16_PASSES, NIT = LN_BWD_ROWS / (4 * RPP * P);
+  static_assert(NIT >= 1 && NIT * 4 * RPP * P == LN_BWD_ROWS, "a workgroup covers LN_BWD_ROWS rows");
+  __shared__ __attribute__((aligned(16))) float sm[4 * RPP * 2 * D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPR, cl = lane % LPR;
+  float gm[8], dg[8], db[8];
+  { const f32x4 a = *reinterpret_cast<const f32x4*>(gamma + cl * 8), b = *reinterpret_cast<const f32x4*>(gamma + cl * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gm[e] = a[e]; gm[4 + e] = b[e]; } }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+#pragma unroll 1
+  for (int it = 0; it < NIT; ++it) {
+    const int64_t row0 = (int64_t)blockIdx.x * LN_BWD_ROWS + (it * 4 + wave) * (RPP * P) + sub;
+    u32x4 wx[P], wd[P], wr[P];
+    float mu[P], rs[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      const int64_t row = row0 + q * RPP;
+      wx[q] = wd[q] = wr[q] = u32x4{0u, 0u, 0u, 0u};
+      mu[q] = 0.f; rs[q] = 0.f;
+      if (row < M) {
+        const int64_t dr = dy_share == 1 ? row : row / dy_share;
+        wx[q] = *reinterpret_cast<const u32x4*>(x + row * ldx + cl * 8);
+        wd[q] = *reinterpret_cast<const u32x4*>(dy + dr * lddy + cl * 8);
+        if (dres) wr[q] = *reinterpret_cast<const u32x4*>(dres + row * lddres + cl * 8);
+        mu[q] = mean[row]; rs[q] = rstd[row];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      const int64_t row = row0 + q * RPP;
+      float xv[8], dv[8], g[8];
+      unpack8(wx[q], xv);
+      unpack8(wd[q], dv);
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xv[e] = (xv[e] - mu[q]) * rs[q];                       // xhat (rows past the end: x = dy = 0, rs = 0 -> no contribution)
+        g[e] = dv[e] * gm[e];
+        c1 += g[e];
+        c2 += g[e] * xv[e];
+        dg[e] += dv[e] * xv[e];
+        db[e] += dv[e];
+      }
+      c1 = seg_sum<LPR>(c1) * (1.0f / D);
+      c2 = seg_sum<LPR>(c2) * (1.0f / D);
+      if (row < M) {
+        float rv[8], o[8];
+        unpack8(wr[q], rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rs[q] * (g[e] - c1 - xv[e] * c2) + rv[e];
+        *reinterpret_cast<u32x4*>(dx + row * lddx + cl * 8) = pack8(o);
+      }
+    }
+  }
+  // dgamma / dbeta: the wave's row groups and the four waves through LDS, then one partial row per workgroup
+  float* mine = sm + (size_t)(wave * RPP + sub) * 2 * D;
+  *reinterpret_cast<f32x4*>(mine + cl * 8) = f32x4{dg[0], dg[1], dg[2], dg[3]};
+  *reinterpret_cast<f32x4*>(mine + cl * 8 + 4) = f32x4{dg[4], dg[5], dg[6], dg[7]};
+  *reinterpret_cast<f32x4*>(mine + D + cl * 8) = f32x4{db[0], db[1], db[2], db[3]};
+  *reinterpret_cast<f32x4*>(mine + D + cl * 8 + 4) = f32x4{db[4], db[5], db[6], db[7]};
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4 * RPP; ++w) s += sm[(size_t)w * 2 * D + i];
+    partial[(int64_t)blockIdx.x * 2 * D + i] = s;
+  }
+}
+
 }  // namespace
 
 extern "C" int dl_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta,
@@ -189,6 +330,19 @@ extern "C" int dl_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, 
   DL_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0, DL_ERR_ALIGN, "dl_layernorm_fwd: ld must be multiple of 4");
   const uint32_t blocks = (uint32_t)((M + 4 * LN_FWD_RPW - 1) / (4 * LN_FWD_RPW));
   dl_prof_before(3, s);
+  if (dtype == DL_BF16 && (D == 256 || D == 512) && ldx % 8 == 0 && ldy % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 &&
+      (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0) {
+    if (D == 256) {
+      const uint32_t nb = (uint32_t)((M + 31) / 32);
+      hipLaunchKernelGGL((ln_fwd16_kernel<256>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd, M, eps);
+    } else {
+      const uint32_t nb = (uint32_t)((M + 15) / 16);
+      hipLaunchKernelGGL((ln_fwd16_kernel<512>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd, M, eps);
+    }
+    DL_CHECK_LAUNCH("dl_layernorm_fwd");
+    dl_prof_after(3, s, 8.0 * M * D, 2.0 * M * D * dl_dtype_size(dtype));
+    return DL_OK;
+  }
 #define LN_FWD(TT, NVV) hipLaunchKernelGGL((ln_fwd_kernel<TT, NVV>), dim3(blocks), dim3(256), 0, s, (const TT*)x, ldx, \
                                           gamma, beta, (TT*)y, ldy, mean, rstd, M, (int)D, eps)
   const int nvg = (int)((D + 255) / 256);
@@ -224,6 +378,15 @@ extern "C" int dl_layernorm_bwd(const void* dy, int64_t lddy, int64_t dy_share, 
                                           (const TT*)x, ldx, mean, rstd, gamma, (const TT*)dres, lddres, (TT*)dx, lddx, \
                                           (float*)workspace, M, (int)D)
   const int nvg = (int)((D + 255) / 256);
+  const bool v16 = dtype == DL_BF16 && (D == 256 || D == 512) && lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 &&
+                   (!dres || lddres % 8 == 0) && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres | (uintptr_t)gamma) & 15) == 0;
+  if (v16 && D == 256)
+    hipLaunchKernelGGL((ln_bwd16_kernel<256>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy, lddy, dy_share, (const bf16_t*)x, ldx, mean, rstd,
+                       gamma, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, (float*)workspace, M);
+  else if (v16)
+    hipLaunchKernelGGL((ln_bwd16_kernel<512>), dim3(nb), dim3(256), 0, s, (const bf16_t*)dy, lddy, dy_share, (const bf16_t*)x, ldx, mean, rstd,
+                       gamma, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, (float*)workspace, M);
+  else
   if (dtype == DL_BF16) { if (nvg <= 1) LN_BWD(bf16_t, 1); else if (nvg <= 2) LN_BWD(bf16_t, 2); else if (nvg <= 4) LN_BWD(bf16_t, 4); else LN_BWD(bf16_t, 8); }
   else { if (nvg <= 1) LN_BWD(float, 1); else if (nvg <= 2) LN_BWD(float, 2); else if (nvg <= 4) LN_BWD(float, 4); else LN_BWD(float, 8); }
 #undef LN_BWD
