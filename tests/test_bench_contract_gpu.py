@@ -39,6 +39,9 @@ def test_default_line_has_the_contract_keys():
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3 and 0 < r["frac"] < 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == "pairs/s"
+    assert [r["batch"] for r in c["sweep"]] == [16, 32, 64] and c["value"] == max(r["value"] for r in c["sweep"])
+    for name in ("attn_fwd", "attn_bwd"):
+        assert 0 < r[name]["hbm_frac"] < 1 and 0 < r[name]["mfma_frac"] < 1
 
 
 def test_small_batch_line_replays_a_graph_and_says_so():
