@@ -43,11 +43,20 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# Per-file flags.  norm.hip: no SLP vectorisation.  hipcc (ROCm 7.2) turned the per-element fp32 arithmetic of the 16-byte
+# LayerNorm backward into v_pk_mul/add/fma_f32 pairs whose LOW-half operands are written by the directly preceding
+# v_lshlrev_b32 / v_and_b32 (bf16 unpacking); on MI355X those packed ops then read stale low halves in lanes 48-63 in a few
+# launches per hundred WHEN ANOTHER PROCESS LOADS THE GPU (tools/contention_repeat.py: 8-27 mismatching launches of 80,
+# always pass 1, lanes 48-63, even elements; 0 of 80 without the packed forms) — a timing-dependent forwarding hazard the
+# compiler does not pad.  Found through the two-rank graph-vs-eager bit-identity test.
+FILE_FLAGS = {"norm.hip": ["-fno-slp-vectorize"]}
+
+
 def _compile(src, force, objdir=OBJDIR, extra=()):
     obj = os.path.join(objdir, src[:-4] + ".o")
     path = os.path.join(CSRC, src)
-    if force or _stale(obj, [path] + _headers()):
-        cmd = [HIPCC] + FLAGS + list(extra) + ["-c", path, "-o", obj]
+    if force or _stale(obj, [path] + _headers() + [os.path.abspath(__file__)]):
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + list(extra) + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

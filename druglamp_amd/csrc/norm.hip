@@ -333,10 +333,12 @@ extern "C" int dl_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, 
   if (dtype == DL_BF16 && (D == 256 || D == 512) && ldx % 8 == 0 && ldy % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 &&
       (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0) {
     if (D == 256) {
-      const uint32_t nb = (uint32_t)((M + 31) / 32);
+      constexpr int RPB = 4 * 2 * LN16_PASSES;            // rows per workgroup: 4 waves x 2 rows x passes
+      const uint32_t nb = (uint32_t)((M + RPB - 1) / RPB);
       hipLaunchKernelGGL((ln_fwd16_kernel<256>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd, M, eps);
     } else {
-      const uint32_t nb = (uint32_t)((M + 15) / 16);
+      constexpr int RPB = 4 * 1 * LN16_PASSES;
+      const uint32_t nb = (uint32_t)((M + RPB - 1) / RPB);
       hipLaunchKernelGGL((ln_fwd16_kernel<512>), dim3(nb), dim3(256), 0, s, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd, M, eps);
     }
     DL_CHECK_LAUNCH("dl_layernorm_fwd");

@@ -290,7 +290,19 @@ class GraphedStep:
         tr._zero_grad()
         _, cls_loss = binary_cross_entropy(score, labels) if tr.n_class == 1 else cross_entropy_logits(score, labels)
         cls_loss.backward()
-        return {"cls": cls_loss.detach()}, tr.flat.pack_grads()
+        idx = tr.flat.pack_grads()
+        self.reduced = False
+        if tr.graph_allreduce and (tr.world > 1 or tr.graph_allreduce == "force"):
+            # the gradient all-reduce as nodes of the graph (RCCL collectives can be captured: tools/graph_allreduce_probe.py):
+            # no host launch between backward and the collective.  The agreed parameter set must be cached already (the
+            # eager warm-up steps of this shape did that): agreeing needs a host sync, which capture forbids.
+            if tr.world > 1:
+                if "cls" not in (tr._agreed_sets or {}):
+                    raise RuntimeError("GraphedStep: the agreed gradient set of cls steps must exist before capture")
+                idx = tr._agreed("cls", idx)
+            tr._all_reduce_runs(idx)
+            self.reduced = True
+        return {"cls": cls_loss.detach()}, idx
 
     def run(self, batch):
         if not self._is_static(batch):                  # copy into the static inputs (device-to-device)
@@ -360,6 +372,12 @@ class Trainer:
         # cannot launch collectives from inside a replay, and at the small per-GPU batches where graphs are used the
         # 5 ms saved on launches outweigh the <= 0.6 ms all-reduce they leave exposed.  UNMEASURED on RCCL with N > 1
         # (no multi-GPU box was available; two ranks sharing one GPU over gloo: tests/test_grad_overlap_gpu.py).
+        self.grad_bf16 = os.environ.get("DL_GRAD_BF16", "0") == "1"     # bf16 gradient all-reduce (see _all_reduce_runs)
+        # DL_GRAPH_ALLREDUCE=1: graph-replayed steps capture their gradient all-reduce (RCCL) instead of issuing it after
+        # the replay; "force": also at world size 1 (single-GPU check of the capture path).  Off by default until a
+        # multi-GPU run of it is on record.
+        ga = os.environ.get("DL_GRAPH_ALLREDUCE", "0")
+        self.graph_allreduce = "force" if ga == "force" else (ga == "1")
         ov = os.environ.get("DL_GRAD_OVERLAP", "0")
         grouped = dist.is_available() and dist.is_initialized()
         want_overlap = ((self.world > 1 and ov not in ("0", "")) or (ov == "force" and grouped)) and not graph_steps
@@ -410,9 +428,23 @@ class Trainer:
         idx = self.flat.pack_grads()
         if self.world > 1:
             idx = self._agreed(kind, idx)
-            for s, e, _ in self.flat.runs(idx, lambda i: 0):
-                dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM)
+            self._all_reduce_runs(idx)
         return idx
+
+    def _all_reduce_runs(self, idx: List[int]):
+        """Sum the flat gradient buffer over the ranks, one collective per contiguous run of parameters (usually one).
+        grad_bf16 (DL_GRAD_BF16=1, off by default: the reference's DDP reduces fp32 and bit-parity tests need it): the
+        run is cast to bf16, reduced (half the bytes on the xGMI links: 28 MB instead of 56 MB) and cast back into the
+        fp32 buffer the optimiser reads — fp32 master weights and moments are untouched; every rank applies the same
+        rounded sum, so replicas stay bit-identical to each other."""
+        for s, e, _ in self.flat.runs(idx, lambda i: 0):
+            g = self.flat.grads[s:e]
+            if self.grad_bf16:
+                h = ops.cast(g, torch.bfloat16)
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                g.copy_(h)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
 
     def _agreed(self, kind: str, have: List[int]) -> List[int]:
         """The parameter set every rank reduces for a backward pass of `kind`: the union over ranks of the parameters that
@@ -513,10 +545,9 @@ class Trainer:
         if g is None:
             g = self._graphs[sig] = GraphedStep(self, batch)     # records only; the replay below is the step
         out, idx = g.run(batch)
-        if self.world > 1:
+        if self.world > 1 and not g.reduced:
             idx = self._agreed("cls", idx)
-            for s, e, _ in self.flat.runs(idx, lambda i: 0):
-                dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM)
+            self._all_reduce_runs(idx)
         self.opt.step(idx, 1.0 / self.world)
         Fn.bump_param_epoch()
         return out

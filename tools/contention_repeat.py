@@ -1,0 +1,82 @@
+"""Bitwise repeatability of kernels while a second process hammers the same GPU (races on counted waits / LDS rings show up
+as rare mismatching launches only under contention).  usage: contention_repeat.py [reps]"""
+import os, sys, time, subprocess, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROLE = os.environ.get("CR_ROLE", "main")
+from druglamp_amd import ops
+dev = torch.device("cuda:0")
+torch.manual_seed(1 if ROLE == "main" else 2)
+dt = torch.bfloat16
+def tt(M, N, K):
+    dy = (torch.randn(K, M, device=dev) * 0.5).to(dt); x = (torch.randn(K, N, device=dev) * 0.5).to(dt); db = torch.empty(M, device=dev)
+    return lambda: (ops.gemm(dy, x, M=M, N=N, K=K, x_kslow=True, w_kslow=True, ldx=M, ldw=N, out_dtype=torch.float32, split_k=0, x_colsum=db), db.clone())
+def nn(M, N, K):
+    x = (torch.randn(M, K, device=dev) * 0.5).to(dt); w = (torch.randn(N, K, device=dev) * 0.1).to(dt); b = torch.randn(N, device=dev)
+    return lambda: (ops.gemm(x, w, M=M, N=N, K=K, bias=b),)
+def ln(M, D):
+    x = torch.randn(M, D, device=dev).to(dt); dy = torch.randn(M, D, device=dev).to(dt); g = torch.randn(D, device=dev); b = torch.randn(D, device=dev)
+    def f():
+        y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
+        dx, dg, dbb = ops.layernorm_bwd(dy, x, mean, rstd, g, dres=dy)
+        return y, dx, dg, dbb, mean, rstd
+    return f
+only_ln = os.environ.get("CR_ONLY_LN") == "1"
+def nn_gelu(M, N, K):
+    x = (torch.randn(M, K, device=dev) * 0.5).to(dt); w = (torch.randn(N, K, device=dev) * 0.1).to(dt); b = torch.randn(N, device=dev)
+    pre = torch.empty(M, N, device=dev, dtype=dt)
+    return lambda: (ops.gemm(x, w, M=M, N=N, K=K, bias=b, act=1, pre_out=pre, dropout_p=0.1, seed=7), pre.clone())
+def nn_dgelu(M, N, K):
+    x = (torch.randn(M, K, device=dev) * 0.5).to(dt); w = (torch.randn(N, K, device=dev) * 0.1).to(dt)
+    pre = torch.randn(M, N, device=dev).to(dt)
+    return lambda: (ops.gemm(x, w, M=M, N=N, K=K, dact_pre=pre, dropout_p=0.1, seed=7),)
+def nn_res(M, N, K):
+    x = (torch.randn(M, K, device=dev) * 0.5).to(dt); w = (torch.randn(N, K, device=dev) * 0.1).to(dt); b = torch.randn(N, device=dev)
+    r = torch.randn(M, N, device=dev).to(dt)
+    return lambda: (ops.gemm(x, w, M=M, N=N, K=K, bias=b, residual=r, dropout_p=0.1, seed=9),)
+def misc():
+    x = torch.randn(256, 2304, 640, device=dev).to(dt)
+    h = torch.randn(591872, 128, device=dev).to(dt)
+    def f():
+        outs = list(ops.fill_pool(x, 9, dt))
+        outs.append(ops.dropout_apply(h, 0.1, 11))
+        return tuple(outs)
+    return f
+cases = {"tt 2048x512x65536": tt(2048, 512, 65536), "tt 1024x256x65536": tt(1024, 256, 65536), "tt 128x768x591867": tt(128, 768, 591867),
+         "tt 256x256x65536 (128-tile)": tt(256, 256, 65536), "nn 65536x512x2048": nn(65536, 512, 2048), "nn 65536x768x256": nn(65536, 768, 256),
+         "nn gelu+pre+dropout 65536x2048x512": nn_gelu(65536, 2048, 512), "nn gelu'(pre)+dropout 65536x2048x512": nn_dgelu(65536, 2048, 512),
+         "nn bias+dropout+residual 65536x512x2048": nn_res(65536, 512, 2048), "nn gelu 128-tile 65536x128x648": nn_gelu(65536, 128, 648),
+         "fill_pool + dropout_apply": misc(),
+         "ln 65536x256": ln(65536, 256), "ln 65536x512": ln(65536, 512), "ln 65536x384 (8-byte kernels)": ln(65536, 384)}
+if only_ln and ROLE == "main":
+    cases = {k: v for k, v in cases.items() if k.startswith("ln")}
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+if ROLE == "load":
+    t_end = time.time() + float(os.environ.get("CR_SECONDS", "60"))
+    fs = list(cases.values())
+    while time.time() < t_end:
+        for f in fs: f()
+        torch.cuda.synchronize()
+    sys.exit(0)
+env = dict(os.environ, CR_ROLE="load", CR_SECONDS="90")
+p = subprocess.Popen([sys.executable, os.path.abspath(__file__)], env=env)
+time.sleep(8)
+for name, f in cases.items():
+    ref = [t.clone() for t in f()]; torch.cuda.synchronize()
+    bad = 0
+    for _ in range(reps):
+        out = f(); torch.cuda.synchronize()
+        eq = [torch.equal(a, b) for a, b in zip(out, ref)]
+        bad += int(not all(eq))
+        if not all(eq) and bad <= 2:
+            for i, (a, b) in enumerate(zip(out, ref)):
+                if not eq[i]:
+                    d = (a.float() - b.float()).abs()
+                    print("    output %d: %d elements differ, max |diff| %.3e, first at flat index %d" % (
+                        i, int((d > 0).sum()), float(d.max()), int((d.flatten() > 0).nonzero()[0])), flush=True)
+                    if d.dim() == 2:
+                        rows = (d > 0).any(1).nonzero().flatten().tolist()
+                        print("      rows:", rows[:24], " columns of the first row:", (d[rows[0]] > 0).nonzero().flatten().tolist()[:40], flush=True)
+                    else:
+                        print("      columns:", (d > 0).nonzero().flatten().tolist(), flush=True)
+    print("%-32s mismatching launches %d / %d" % (name, bad, reps), flush=True)
+p.terminate(); p.wait()
