@@ -33,6 +33,13 @@ def nn_res(M, N, K):
     x = (torch.randn(M, K, device=dev) * 0.5).to(dt); w = (torch.randn(N, K, device=dev) * 0.1).to(dt); b = torch.randn(N, device=dev)
     r = torch.randn(M, N, device=dev).to(dt)
     return lambda: (ops.gemm(x, w, M=M, N=N, K=K, bias=b, residual=r, dropout_p=0.1, seed=9),)
+def ntx(n, d, dtype):
+    q = (torch.randn(n, d, device=dev) * 0.3).to(dtype); k = (torch.randn(n, d, device=dev) * 0.3).to(dtype)
+    def f():
+        loss, lse, rl = ops.ntxent_fwd_ex(q, k, q, k, 0, 0, n, 0.1)
+        dq, dk = ops.ntxent_bwd_ex(q, k, q, k, 0, 0, n, 0.1, lse, lse, 1.0 / (2 * n))
+        return loss, lse, dq, dk
+    return f
 def misc():
     x = torch.randn(256, 2304, 640, device=dev).to(dt)
     h = torch.randn(591872, 128, device=dev).to(dt)
@@ -45,7 +52,7 @@ cases = {"tt 2048x512x65536": tt(2048, 512, 65536), "tt 1024x256x65536": tt(1024
          "tt 256x256x65536 (128-tile)": tt(256, 256, 65536), "nn 65536x512x2048": nn(65536, 512, 2048), "nn 65536x768x256": nn(65536, 768, 256),
          "nn gelu+pre+dropout 65536x2048x512": nn_gelu(65536, 2048, 512), "nn gelu'(pre)+dropout 65536x2048x512": nn_dgelu(65536, 2048, 512),
          "nn bias+dropout+residual 65536x512x2048": nn_res(65536, 512, 2048), "nn gelu 128-tile 65536x128x648": nn_gelu(65536, 128, 648),
-         "fill_pool + dropout_apply": misc(),
+         "fill_pool + dropout_apply": misc(), "ntxent bf16 n=8192": ntx(8192, 128, dt), "ntxent f32 n=2048": ntx(2048, 128, torch.float32),
          "ln 65536x256": ln(65536, 256), "ln 65536x512": ln(65536, 512), "ln 65536x384 (8-byte kernels)": ln(65536, 384)}
 if only_ln and ROLE == "main":
     cases = {k: v for k, v in cases.items() if k.startswith("ln")}
