@@ -165,6 +165,66 @@ SIGNATURES = {
 
 _lib = None
 
+# ---- pointer audit of captured launches (debug: DL_GRAPH_PTR_AUDIT=1; run by tests/test_graph_step_gpu.py and tools/soak.py) --
+# A hipGraph replay re-issues every captured launch with the SAME addresses, so each device pointer a captured launch
+# received must stay alive and in place for the life of the graph.  Round 2 found two caches that broke this (shared
+# scratch, weight-image tables).  With the audit on, every libdruglamp_hip call made while a stream is capturing records
+# the device pointers among its arguments (plain void* arguments and the void* fields of argument blocks);
+# trainer.GraphedStep then checks each one against the allocator's snapshot: it must lie in the graph's private pool or
+# inside a buffer registered as pinned for the life of the trainer.
+AUDIT = os.environ.get("DL_GRAPH_PTR_AUDIT") == "1"
+_audit_log = None
+
+
+def audit_begin() -> None:
+    global _audit_log
+    _audit_log = []
+
+
+def audit_end():
+    global _audit_log
+    log, _audit_log = _audit_log, None
+    return log or []
+
+
+def _struct_ptrs(obj, out, name):
+    for fname, ftype in getattr(obj, "_fields_", []):
+        v = getattr(obj, fname)
+        if ftype is c_vp:
+            if v:
+                out.append(("%s.%s" % (name, fname), int(v)))
+        elif isinstance(v, C.Structure):
+            _struct_ptrs(v, out, "%s.%s" % (name, fname))
+
+
+def _audited(name, fn, argtypes):
+    def call(*args):
+        if _audit_log is not None:
+            import torch
+            if torch.cuda.is_current_stream_capturing():
+                found = []
+                n_items = next((a for a, t in zip(args, argtypes) if t is c_i32), 0) if name == "dl_reduce_batch" else 0
+                for i, (a, t) in enumerate(zip(args, argtypes)):
+                    if t is c_vp:
+                        v = a.value if isinstance(a, C.c_void_p) else a
+                        if v:
+                            found.append(("arg%d" % i, int(v)))
+                    elif isinstance(a, C.Array):
+                        for k in range(int(n_items) or len(a)):
+                            _struct_ptrs(a[k], found, "arg%d[%d]" % (i, k))
+                    elif isinstance(a, C.Structure):
+                        _struct_ptrs(a, found, "arg%d" % i)
+                    elif hasattr(a, "_obj") and isinstance(getattr(a, "_obj"), C.Structure):     # byref(struct)
+                        _struct_ptrs(a._obj, found, "arg%d" % i)
+                    elif hasattr(a, "contents") and a:                                            # pointer(struct)
+                        try:
+                            _struct_ptrs(a.contents, found, "arg%d" % i)
+                        except ValueError:
+                            pass
+                _audit_log.extend((name, w, v) for w, v in found)
+        return fn(*args)
+    return call
+
 
 def lib():
     """Load the shared library (once).  Raises if it has not been built — there is no fallback."""
@@ -179,6 +239,9 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+            if AUDIT and name not in ("dl_last_error", "dl_version") and not name.endswith("_bytes") and not name.endswith("_floats") \
+                    and not name.startswith("dl_prof_"):
+                setattr(L, name, _audited(name, fn, args))
         _lib = L
     return _lib
 

@@ -263,11 +263,58 @@ class GraphedStep:
         before = ops.weight_prep_launches()
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
+        from . import _lib as _L
+        if _L.AUDIT:
+            _L.lib()
+            _L.audit_begin()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out, self.idx = self._body()
+        if _L.AUDIT:
+            self.audit = self._audit_pointers(_L.audit_end())
         if ops.weight_prep_launches() == before and Fn.planned_image_count() > 0:
             raise RuntimeError("GraphedStep: no dl_weight_prep launch was captured; replays would use stale weight images")
         self.replays = 0
+
+    def _pinned_ranges(self):
+        """(address, bytes) of every buffer that lives as long as the trainer / process: what a captured launch may point at
+        besides memory of the graph's own pool."""
+        tr = self.tr
+        ts = [tr.flat.arena, tr.flat.grads] + [t for o in (tr.opt, tr.opt_ssl, tr.opt_cm) if o is not None for t in (o.exp_avg, o.exp_avg_sq)]
+        ts += [b for b in tr.model.buffers()] + [p_ for p_ in tr.model.parameters()]
+        ts += [t for b in self.static for t in (b if isinstance(b, (tuple, list)) else (b,))]
+        ts += list(ops._seed_offsets.values()) + list(ops._tickets.values())
+        ts += [e.image for e in Fn._lowp_cache.values() if torch.is_tensor(e.image)]
+        for tab in list(Fn._lowp_tables.values()) + [t for t in Fn._lowp_retired if isinstance(t, tuple) and len(t) == 4]:
+            ts += [tab[1], tab[2]]
+        out = []
+        for t in ts:
+            if torch.is_tensor(t) and t.is_cuda:
+                st = t.untyped_storage()
+                out.append((st.data_ptr(), st.nbytes()))
+        return out
+
+    def _audit_pointers(self, log):
+        """DL_GRAPH_PTR_AUDIT=1: every device pointer a captured library launch received lies in the graph's private pool or
+        in a pinned buffer; anything else could be freed and re-used under the graph (the two use-after-free classes of
+        round 2 were exactly that).  Raises with the offending entry points; returns (pointers checked, in pool, pinned)."""
+        segs = [(s["address"], s["address"] + s["total_size"], tuple(s.get("segment_pool_id", (0, 0)))) for s in torch.cuda.memory_snapshot()]
+        pinned = self._pinned_ranges()
+        n_pool = n_pin = 0
+        bad = []
+        for fn, what, ptr in log:
+            seg = next((s for s in segs if s[0] <= ptr < s[1]), None)
+            if seg is not None and seg[2] != (0, 0):
+                n_pool += 1
+            elif any(a <= ptr < a + n for a, n in pinned):
+                n_pin += 1
+            elif seg is None:
+                pass        # not device memory of the caching allocator (e.g. a module-scope constant of the library)
+            else:
+                bad.append((fn, what, hex(ptr)))
+        if bad:
+            raise RuntimeError("GraphedStep: %d pointers of captured launches lie in neither the graph's pool nor a pinned buffer "
+                               "(first: %s)" % (len(bad), bad[:6]))
+        return len(log), n_pool, n_pin
 
     @staticmethod
     def _clone(batch):

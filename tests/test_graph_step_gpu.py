@@ -205,3 +205,46 @@ def test_capture_right_after_an_evaluation_still_refreshes_the_weight_images():
     assert res[False][0] == res[True][0], (res[False][0], res[True][0])
     for a, b in zip(res[False][1], res[True][1]):
         assert torch.equal(a, b)
+
+
+def test_pointer_audit_of_a_captured_step_finds_only_pool_or_pinned_memory():
+    """DL_GRAPH_PTR_AUDIT=1 (a debug mode: every library call goes through a Python shim): each device pointer that a
+    captured launch received must lie in the graph's private pool or in a buffer pinned for the trainer's life — the
+    systematic form of the two use-after-free fixes of round 2.  Runs in a subprocess (the flag is read at import)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import torch
+from druglamp_amd import ops
+from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
+from druglamp_amd.model import MInterface
+from druglamp_amd.synthetic import make_batch
+from druglamp_amd.trainer import Trainer
+dev = torch.device("cuda", 0)
+torch.manual_seed(1); ops.manual_seed(2)
+cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP")
+model = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
+tr = Trainer(model, cfg, device=dev, compute_dtype=torch.bfloat16, graph_steps=True)
+tr.set_lrs(1e-3, 1e-3, 1e-3)
+batch, meta = make_batch(8, dev, seed=7, with_graph=True, llm_dtype=torch.bfloat16)
+for _ in range(5):
+    out = tr.training_step(batch, meta=meta, cur_epoch=1)
+g = next(iter(tr._graphs.values()))
+n, n_pool, n_pin = g.audit
+assert n > 500 and n_pool > 0 and n_pin > 0, g.audit
+assert float(out["cls"]) == float(out["cls"])
+victim = torch.zeros(1024, device=dev)          # an eagerly allocated buffer nobody pinned: the audit must reject it
+try:
+    g._audit_pointers([("dl_fake", "arg0", victim.data_ptr())])
+    raise SystemExit("audit accepted an unpinned default-pool pointer")
+except RuntimeError as e:
+    assert "neither the graph's pool nor a pinned buffer" in str(e)
+assert g._audit_pointers([("dl_fake", "arg0", tr.flat.arena.data_ptr() + 64)]) == (1, 0, 1)
+print("AUDIT", n, n_pool, n_pin)
+'''
+    env = dict(os.environ, DL_GRAPH_PTR_AUDIT="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "AUDIT" in r.stdout

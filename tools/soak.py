@@ -26,5 +26,8 @@ for epoch in range(1, 13):
     print("epoch %2d  %s  alloc %.2f GB  reserved %.2f GB  max %.2f GB" % (
         epoch, {k: round(v, 4) for k, v in vals.items()}, torch.cuda.memory_allocated() / 2**30,
         torch.cuda.memory_reserved() / 2**30, torch.cuda.max_memory_allocated() / 2**30), flush=True)
+for g_ in tr._graphs.values():      # DL_GRAPH_PTR_AUDIT=1 python tools/soak.py --graph : pointer audit of every captured step
+    if getattr(g_, "audit", None):
+        print("pointer audit of a captured step: %d device pointers, %d in the graph's pool, %d in pinned buffers, 0 elsewhere" % g_.audit)
 print("%d steps in %.1f s%s" % (12 * (100 if graph else 10), time.perf_counter() - t0,
                               "  (graph replays: %d)" % sum(g.replays for g in tr._graphs.values()) if graph else ""))
