@@ -159,7 +159,7 @@ def main():
     ep = args.epoch
     kinds = ["cls"] + (["ssl"] if trainer.use_ssl and ep % trainer.ssl_epoch_step == 0 else []) + \
         (["cm"] if trainer.use_cm and ep >= trainer.cm_init_epoch else [])
-    graphed = use_graph and kinds == ["cls"]
+    graphed = use_graph and "cm" not in kinds            # cls steps and SSL-epoch steps replay a hipGraph; CM steps run eagerly
 
     def sync():
         if world > 1:
@@ -237,7 +237,7 @@ def main():
                                    "global batch %d = %d per GPU x %d%s%s%s" % (
                                        args.model, "+".join(kinds) + " step, epoch %d" % ep, args.seq_len, args.seq_len // 9,
                                        args.batch * world, args.batch, world,
-                                       ", cls step replayed as a hipGraph" if graphed else "",
+                                       ", step replayed as a hipGraph" if graphed else "",
                                        (", batch-level heads over the all-gathered global batch (RS.GLOBAL_BATCH)" if args.global_batch_cm else "") +
                                        (", drug SSL = NT-Xent (simclr)" if args.drug_ssl == "simclr" else ""),
                                        ", PMMA attention forward in MXFP8" if args.attention == "fp8" else ""),

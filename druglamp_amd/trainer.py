@@ -244,9 +244,14 @@ class GraphedStep:
       * the weight images are refreshed from the fp32 masters by the dl_weight_prep launch at the head of the graph;
       * BatchNorm running statistics are updated by the in-graph dl_bn_finalize launches."""
 
-    def __init__(self, trainer: "Trainer", batch):
-        """Capture only records (nothing executes): the caller has already run eager steps of this shape, so lazy
-        allocations, weight-image tables and workspaces exist."""
+    def __init__(self, trainer: "Trainer", batch, kind: str = "cls"):
+        """Capture only records (nothing executes): the caller has already run eager steps of this shape AND kind, so lazy
+        allocations (the SimSiam projectors of the first SSL forward), weight-image tables and workspaces exist.
+        kind "ssl" (round 3): a step of an SSL epoch without the CM head — forward, BCE (logged only: its backward is dead,
+        the next zero_grad wipes it, trainer.py:196-212 of the reference), SSL heads, their backward, gradient packing.  The
+        MLM mask draw (rand / topk / scatter on the device) is captured with the step: torch's device generator is
+        graph-safe (its Philox offset is advanced per replay), so every replay draws fresh masks."""
+        self.kind = kind
         self.tr = trainer
         dev = trainer.device
         self.static = self._clone(batch)
@@ -333,10 +338,18 @@ class GraphedStep:
         tr, m = self.tr, self.tr.model
         ops.seed_offset_tensor(tr.device).add_(1)
         feat_d, feat_p, labels, llm_d, llm_p = self.static
-        _, _, _, _, score = m(feat_d, feat_p, llm_d, llm_p)
+        _, _, ssl_input, _, score = m(feat_d, feat_p, llm_d, llm_p)
         tr._zero_grad()
         _, cls_loss = binary_cross_entropy(score, labels) if tr.n_class == 1 else cross_entropy_logits(score, labels)
-        cls_loss.backward()
+        out = {"cls": cls_loss.detach()}
+        if self.kind == "ssl":
+            with m._glue():
+                d = m.ssl_model(**ssl_input)
+            ssl_loss = (d["prot_ssl"] + d["drug_ssl"]) * 0.1
+            ssl_loss.backward()
+            out["ssl"] = ssl_loss.detach()
+        else:
+            cls_loss.backward()
         idx = tr.flat.pack_grads()
         self.reduced = False
         if tr.graph_allreduce and (tr.world > 1 or tr.graph_allreduce == "force"):
@@ -344,12 +357,12 @@ class GraphedStep:
             # no host launch between backward and the collective.  The agreed parameter set must be cached already (the
             # eager warm-up steps of this shape did that): agreeing needs a host sync, which capture forbids.
             if tr.world > 1:
-                if "cls" not in (tr._agreed_sets or {}):
-                    raise RuntimeError("GraphedStep: the agreed gradient set of cls steps must exist before capture")
-                idx = tr._agreed("cls", idx)
+                if self.kind not in (tr._agreed_sets or {}):
+                    raise RuntimeError("GraphedStep: the agreed gradient set of %s steps must exist before capture" % self.kind)
+                idx = tr._agreed(self.kind, idx)
             tr._all_reduce_runs(idx)
             self.reduced = True
-        return {"cls": cls_loss.detach()}, idx
+        return out, idx
 
     def run(self, batch):
         if not self._is_static(batch):                  # copy into the static inputs (device-to-device)
@@ -366,8 +379,8 @@ class GraphedStep:
 
 class Trainer:
     """ExpModule restated (trainer.py:39-292).  `cfg` is the merged config tree.
-    graph_steps=True: cls-only steps run as hipGraph replays (GraphedStep); SSL / CM steps and the first step of every
-    new batch shape stay eager."""
+    graph_steps=True: cls-only steps and SSL-epoch steps run as hipGraph replays (GraphedStep); steps with the CM head and the
+    first steps of every new (batch shape, step kind) stay eager."""
     overlap = None
     _agreed_sets = None
 
@@ -536,10 +549,13 @@ class Trainer:
             m.train()                  # (walks every submodule: 0.7 ms per call)
         compute_ssl = self.use_ssl and (cur_epoch % self.ssl_epoch_step == 0)
         compute_cm = self.use_cm and (cur_epoch >= self.cm_init_epoch)
-        if self.graph_steps and not compute_ssl and not compute_cm and not self.run_dead_backward:
-            sig = GraphedStep.signature(batch)
+        if self.graph_steps and not compute_cm and not self.run_dead_backward and (not compute_ssl or ssl_masks is None):
+            # cls steps and (round 3) SSL-epoch steps replay a graph; steps with the CM head stay eager: its unique-id
+            # gather and label matrix are host work and its BatchNorms see a batch-dependent number of rows
+            kind = "ssl" if compute_ssl else "cls"
+            sig = (kind,) + GraphedStep.signature(batch)
             if sig in self._graphs or self._eager_seen.get(sig, 0) >= self.graph_warmup:
-                return self._graphed_step(batch, sig)
+                return self._graphed_step(batch, sig, kind)
             self._eager_seen[sig] = self._eager_seen.get(sig, 0) + 1
         feat_d, feat_p, labels, llm_d, llm_p = batch
         _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p)
@@ -587,22 +603,24 @@ class Trainer:
         Fn.bump_param_epoch()
         return out
 
-    def _graphed_step(self, batch, sig) -> Dict[str, float]:
+    def _graphed_step(self, batch, sig, kind: str = "cls") -> Dict[str, float]:
         g = self._graphs.get(sig)
         if g is None:
-            g = self._graphs[sig] = GraphedStep(self, batch)     # records only; the replay below is the step
+            g = self._graphs[sig] = GraphedStep(self, batch, kind)     # records only; the replay below is the step
         out, idx = g.run(batch)
         if self.world > 1 and not g.reduced:
-            idx = self._agreed("cls", idx)
+            idx = self._agreed(kind, idx)
             self._all_reduce_runs(idx)
         self.opt.step(idx, 1.0 / self.world)
+        if kind == "ssl":
+            self.opt_ssl.step(idx, 1.0 / self.world)
         Fn.bump_param_epoch()
         return out
 
     def static_batch(self, batch):
         """The captured graph's own input tensors for batches of this shape (or `batch` itself while no graph exists):
         a producer that fills them in place — and passes them back — saves the per-step input copy."""
-        g = self._graphs.get(GraphedStep.signature(batch))
+        g = self._graphs.get(("cls",) + GraphedStep.signature(batch)) or self._graphs.get(("ssl",) + GraphedStep.signature(batch))
         return batch if g is None else g.static
 
     def on_train_epoch_end(self, cur_epoch: int):

@@ -88,7 +88,7 @@ def test_graph_replays_draw_fresh_dropout_masks():
         ops.use_seed_offset(False)
 
 
-def test_ssl_and_cm_steps_stay_eager_when_graphs_are_on():
+def test_cm_steps_stay_eager_when_graphs_are_on():
     from druglamp_amd import ops
     from druglamp_amd.synthetic import make_batch
     batch, meta = make_batch(8, DEV, seed=7, with_graph=True, llm_dtype=torch.bfloat16)
@@ -248,3 +248,38 @@ print("AUDIT", n, n_pool, n_pin)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "AUDIT" in r.stdout
+
+
+def test_ssl_epoch_steps_replay_a_graph_with_fresh_masks():
+    """Round 3: steps of an SSL epoch (DrugLAMP: cls forward + SimSiam + masked-LM heads, reference trainer.py:192-212) are
+    captured too (kind "ssl").  The MLM mask is drawn on the device inside the graph: with lr = 0 two replays must give
+    DIFFERENT ssl losses (fresh masks per replay) but the same cls loss; with training on, graphed and eager runs must
+    both stay finite and reach comparable ssl losses (the mask streams differ, so no bit comparison)."""
+    from druglamp_amd import ops
+    from druglamp_amd.synthetic import make_batch
+    batch, meta = make_batch(8, DEV, seed=7, with_graph=True, llm_dtype=torch.bfloat16)
+    try:
+        tr = _make(0.0, True)
+        tr.set_lrs(0.0, 0.0, 0.0)
+        outs = []
+        for _ in range(5):                                   # (a replay returns the graph's own output tensors: read them now)
+            o = tr.training_step(batch, meta=meta, cur_epoch=5)
+            outs.append({k: float(v) for k, v in o.items()})
+        g = tr._graphs[("ssl",) + type(next(iter(tr._graphs.values()))).signature(batch)]
+        assert g.kind == "ssl" and g.replays == 3
+        ssl = [o["ssl"] for o in outs[2:]]
+        cls = [o["cls"] for o in outs[2:]]
+        assert len(set(ssl)) == 3, ssl                      # three replays, three different mask draws
+        assert len(set(cls)) == 1, cls                      # ... over the same weights and inputs
+        # cls steps of the same trainer get their own graph
+        tr.training_step(batch, meta=meta, cur_epoch=1); tr.training_step(batch, meta=meta, cur_epoch=1)
+        tr.training_step(batch, meta=meta, cur_epoch=1)
+        assert len(tr._graphs) == 2
+        res = {}
+        for graph in (False, True):
+            t2 = _make(0.0, graph)
+            res[graph] = [float(t2.training_step(batch, meta=meta, cur_epoch=5)["ssl"]) for _ in range(8)]
+            assert torch.isfinite(t2.flat.arena).all()
+        assert all(v == v for v in res[True]) and abs(res[True][-1] - res[False][-1]) <= 0.25 * abs(res[False][-1]), res
+    finally:
+        ops.use_seed_offset(False)
