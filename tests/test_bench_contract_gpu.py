@@ -48,3 +48,27 @@ def test_small_batch_line_replays_a_graph_and_says_so():
     d = _run("--batch", "32", "--steps", "6", "--warmup", "4", "--no-cpu-baseline")
     assert d["config"]["hip_graph"] is True and d["scaling"] == "weak" and d["config"]["per_gpu_batch"] == 32
     assert "EAGER" in d["roofline"]["timing_source"] and "cpu_baseline" not in d
+
+
+def test_two_rank_launch_line_over_gloo_on_one_gpu():
+    """The driver's N > 1 command line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`)
+    with two ranks sharing cuda:0 over gloo (DL_DIST_BACKEND=gloo: a one-GPU box cannot host two RCCL ranks): replica
+    broadcast, agreed gradient set, all-reduce after the replayed step, barrier + max-over-ranks timing, the weak-scaling
+    leg and the untimed busy tail must all run, and rank 0 prints ONE line with strong scaling of the global batch."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3",
+                        "--min-busy-seconds", "0.5"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 256 and d["config"]["per_gpu_batch"] == 128
+    assert d["config"]["hip_graph"] is True and d["value"] > 0 and "weak" in d and d["weak"]["per_gpu_batch"] == 256
+    assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]
