@@ -199,6 +199,13 @@ def dynamic_tiles(on: bool) -> None:
     _tickets_on = bool(on)
 
 
+def reset_tickets() -> None:
+    """Zero the ticket words (Trainer construction; after a failed launch they could hold a stale count and later
+    ticketed GEMMs would skip tiles — ADVICE round 2)."""
+    for t in _tickets.values():
+        t.zero_()
+
+
 def _tickets_ptr(device):
     if not _tickets_on:
         return None

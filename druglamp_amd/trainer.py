@@ -444,6 +444,7 @@ class Trainer:
         self.overlap = GradOverlap(self.flat) if want_overlap else None
         if self.overlap is not None:
             ops.dynamic_tiles(True)      # persistent GEMMs hand their tiles out dynamically while collectives share the CUs
+            ops.reset_tickets()
         # hook-driven collectives cannot be launched from inside a graph replay: graphed steps reduce after the replay
         self.graph_steps = bool(graph_steps) and self.overlap is None
         self._graphs: Dict[tuple, GraphedStep] = {}
