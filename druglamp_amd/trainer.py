@@ -383,6 +383,8 @@ class Trainer:
     first steps of every new (batch shape, step kind) stay eager."""
     overlap = None
     _agreed_sets = None
+    grad_bf16 = False
+    graph_allreduce = False
 
     def __init__(self, model, cfg, device=None, compute_dtype=torch.float32, graph_steps: bool = False):
         self.model = model
