@@ -272,6 +272,16 @@ def gen_models():
         n, loss = binary_cross_entropy(score_t, y)
         loss.backward()
         out.update(score_train=score_t, cls_loss=loss, gradnorm=grad_norms(m))
+        # a fixed sample of the WHOLE gradient vector (parameters with a gradient, named_parameters order; aliases of the
+        # shared ProteinCNN counted once): norms alone pass with a wrong direction
+        seen, parts = set(), []
+        for k, p_ in m.named_parameters():
+            if p_.grad is not None and id(p_) not in seen:
+                seen.add(id(p_))
+                parts.append(p_.grad.detach().flatten())
+        gvec = torch.cat(parts).double()
+        gi = torch.from_numpy(np.random.RandomState(123).randint(0, gvec.numel(), 8192))
+        out.update(gsample=gvec[gi].float(), gidx=gi, gtotal=np.int64(gvec.numel()), gmax=np.float64(gvec.abs().max().item()))
         save("model_" + kind, **out)
 
 
