@@ -128,3 +128,52 @@ def test_a_captured_step_may_contain_its_rccl_all_reduce():
         p.join(60)
     assert res[0][1] is False and res[1][1] is True and res[0][2] == res[1][2] == 4
     assert np.array_equal(res[0][0], res[1][0])
+
+
+def _worker_c3(rank, world, port, q):
+    """BASELINE config C3 in miniature: DrugLAMP, SSL epoch, NT-Xent (simclr) over the ALL-GATHERED batch, two ranks."""
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from druglamp_amd import ops
+    from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
+    from druglamp_amd.model import MInterface
+    from druglamp_amd.synthetic import make_batch
+    from druglamp_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1234)
+    ops.manual_seed(1000 + rank)
+    cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP")
+    cfg["RS"]["GLOBAL_BATCH"] = True
+    cfg["RS"]["DRUG_SSL_TYPE"] = "simclr"
+    model = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
+    tr = Trainer(model, cfg, device=dev, compute_dtype=torch.bfloat16, graph_steps=False)
+    tr.set_lrs(1e-3, 1e-3, 1e-3)
+    batch, meta = make_batch(4, dev, seed=100 + rank, with_graph=True, llm_dtype=torch.bfloat16)
+    losses = []
+    for ep in (1, 5, 5, 1):
+        out = tr.training_step(batch, meta=meta, cur_epoch=ep)
+        losses.append({k: float(v) for k, v in out.items()})
+    torch.cuda.synchronize()
+    q.put((rank, losses, tr.replicas_in_sync(), bool(torch.isfinite(tr.flat.arena).all())))
+    dist.destroy_process_group()
+
+
+def test_config_c3_step_global_batch_ntxent_on_two_ranks():
+    """DrugLAMP with RS.GLOBAL_BATCH + RS.DRUG_SSL_TYPE = simclr on two ranks: the SSL-epoch steps run the NT-Xent head over
+    the all-gathered node rows (2 x 4 x 512 rows per half), gradients are reduced, replicas stay bit-identical."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_c3, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    for rank, losses, in_sync, finite in res:
+        assert in_sync and finite
+        assert "ssl" in losses[1] and "ssl" in losses[2] and "ssl" not in losses[0]
+        assert all(v == v for l in losses for v in l.values())
+    # the ranks see different pairs: their (rank-mean) NT-Xent values differ, but both are losses over the same 2 x 4096 columns
+    assert res[0][1][1]["ssl"] != res[1][1][1]["ssl"]
