@@ -141,6 +141,21 @@ def test_model_forward(kind):
         # norms are fp32 rounding noise (~1e-8), hence the absolute floor
         worst = max(worst, abs(got - n_ref) / max(n_ref, 1e-5))
     assert worst <= 2e-3, worst
+    # the fixed sample of the reference's whole gradient vector (direction, not just norms): keys in the reference's
+    # state_dict order, the shared ProteinCNN's alias keys once
+    from tests.helpers import sd_spec
+    parts, seen = [], set()
+    for k, _, _ in sd_spec(g):
+        if k.startswith("ssl_model.extractor."):
+            continue
+        v = sd.get(k)
+        if v is not None and v.grad is not None and id(v) not in seen:
+            seen.add(id(v))
+            parts.append(v.grad.detach().flatten().double())
+    gv = torch.cat(parts)
+    assert gv.numel() == int(g["gtotal"]), (gv.numel(), int(g["gtotal"]))
+    got = gv[torch.from_numpy(g["gidx"])]
+    assert float((got - torch.from_numpy(g["gsample"]).double()).abs().max()) <= 2e-3 * float(g["gmax"])
 
 
 def _unpack(bits, shape):
