@@ -159,7 +159,9 @@ def main():
     ep = args.epoch
     kinds = ["cls"] + (["ssl"] if trainer.use_ssl and ep % trainer.ssl_epoch_step == 0 else []) + \
         (["cm"] if trainer.use_cm and ep >= trainer.cm_init_epoch else [])
-    graphed = use_graph and "cm" not in kinds            # cls steps and SSL-epoch steps replay a hipGraph; CM steps run eagerly
+    # cls, SSL-epoch and CM steps replay a hipGraph; eager: the epoch the CM head starts in (its loss weight is scaled on
+    # the host there) and the global-batch CM form at N > 1 (object collectives)
+    graphed = use_graph and ("cm" not in kinds or (ep > trainer.cm_init_epoch and not (args.global_batch_cm and world > 1)))
 
     def sync():
         if world > 1:

@@ -1,6 +1,15 @@
 """Cross-modality 2C2P head (reference: model/cross_modality.py).  Label-matrix construction stays on
 the host (python dicts in the reference, one numpy matrix here); the O(n_p * n_d) python triplet loop
-of ccpp_p_tri_loss is replaced by the all-pairs sigmoid-cosine + masked triplet HIP kernel."""
+of ccpp_p_tri_loss is replaced by the all-pairs sigmoid-cosine + masked triplet HIP kernel.
+
+Round 3: the device side is SHAPE-STATIC.  A batch of B pairs has n_p <= B unique proteins and n_d <= B unique
+drugs; the reference runs its BatchNorms / Linears / triplet loop over (n_p, ...) and (n_d, ...) tensors whose
+size changes from batch to batch.  Here every tensor has B rows: the unique-row gathers are padded with row 0, the
+four BatchNorm1d layers take their statistics over the first n_p / n_d rows only (row mask + device-side row count),
+the label matrix is (B, B) with the padding marked "ignored" (-1: no triplet is formed with it, and a padded
+row's gradient is exactly zero).  Values are those of the unpadded computation (the padding adds exact zeros to
+every sum); the shapes no longer depend on the batch's ids, so a step with this head can be captured in a hipGraph
+(trainer.GraphedStep kind "cm"): per step only the CMLabels tensors are refreshed from the host."""
 from __future__ import annotations
 
 import numpy as np
@@ -56,6 +65,60 @@ def Mean2Embed(hidden=128):
     return nn.Sequential(nn.BatchNorm1d(hidden), nn.ReLU(inplace=True), nn.Linear(hidden, hidden))
 
 
+class CMLabels:
+    """Device-side form of label_matrix() for batches of `rows` pairs, padded to static shapes: idx[0] / idx[1] = sample index
+    of each unique protein / drug (padding: 0), mask[0] / mask[1] = 1.0 on real rows, n = (n_p, n_d) as floats,
+    gt (rows, rows) int8 with -1 outside [n_p) x [n_d).  fill() refreshes the SAME tensors (a captured graph points at
+    them)."""
+
+    def __init__(self, rows: int, device):
+        self.rows = rows
+        self.idx = torch.zeros(2, rows, dtype=torch.int64, device=device)
+        self.mask = torch.zeros(2, rows, 1, dtype=torch.float32, device=device)
+        self.n = torch.ones(2, dtype=torch.float32, device=device)
+        self.gt = torch.full((rows, rows), -1, dtype=torch.int8, device=device)
+
+    def fill(self, meta, use_cm=True):
+        pidx, didx, gt = label_matrix(meta, use_cm)
+        B = self.rows
+        if len(meta) != B:
+            raise ValueError("CMLabels: %d meta rows for a %d-row label block" % (len(meta), B))
+        n_p, n_d = len(pidx), len(didx)
+        idx = np.zeros((2, B), dtype=np.int64)
+        idx[0, :n_p], idx[1, :n_d] = pidx, didx
+        mask = np.zeros((2, B, 1), dtype=np.float32)
+        mask[0, :n_p], mask[1, :n_d] = 1.0, 1.0
+        g = np.full((B, B), -1, dtype=np.int8)
+        g[:n_p, :n_d] = gt
+        self.idx.copy_(torch.from_numpy(idx))
+        self.mask.copy_(torch.from_numpy(mask))
+        self.n.copy_(torch.tensor([float(n_p), float(n_d)]))
+        self.gt.copy_(torch.from_numpy(g))
+        return self
+
+
+def _bn_rows(bn: nn.BatchNorm1d, x, mask, n):
+    """nn.BatchNorm1d over the rows with mask == 1 (n of them, a device scalar) of a padded (rows, hidden) block:
+    batch statistics (biased variance) for the normalisation, running statistics updated with the unbiased variance
+    and the module's momentum — what torch's layer does on the unpadded rows."""
+    if bn.training:
+        mean = (x * mask).sum(0) / n
+        xc = (x - mean) * mask
+        var = (xc * xc).sum(0) / n
+        with torch.no_grad():
+            mom = bn.momentum
+            bn.running_mean.mul_(1.0 - mom).add_(mean * mom)
+            bn.running_var.mul_(1.0 - mom).add_(var * (n / (n - 1.0).clamp(min=1.0)) * mom)
+            bn.num_batches_tracked.add_(1)
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    return (x - mean) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias
+
+
+def _mean2embed(seq: nn.Sequential, x, mask, n):
+    return seq[2](F.relu(_bn_rows(seq[0], x, mask, n)))
+
+
 class CrossModality(nn.Module):
     def __init__(self, *, use_cm=True, hidden_size=128, max_margin=0.5, n_re=100, **kwargs):
         super().__init__()
@@ -72,20 +135,30 @@ class CrossModality(nn.Module):
     def step(self):
         self.m_sch_loss_fn.step()
 
-    def latents_from_means(self, pm, apm, dm, adm, pidx, didx):
-        """pm/apm/dm/adm: per-sample token means (n, hidden).  Mean2Embed x4 -> concat -> Linear -> l2norm."""
-        pe = torch.cat([self.prot2latent(pm[pidx]), self.aug_prot2latent(apm[pidx])], dim=-1)
-        de = torch.cat([self.drug2latent(dm[didx]), self.aug_drug2latent(adm[didx])], dim=-1)
+    def latents_from_means(self, pm, apm, dm, adm, labels: CMLabels):
+        """pm/apm/dm/adm: per-sample token means (n, hidden).  Mean2Embed x4 -> concat -> Linear -> l2norm, on the padded
+        unique-row blocks of `labels`."""
+        pi, di = labels.idx[0], labels.idx[1]
+        (pk, dk), (n_p, n_d) = labels.mask, labels.n
+        pe = torch.cat([_mean2embed(self.prot2latent, pm.index_select(0, pi), pk, n_p),
+                        _mean2embed(self.aug_prot2latent, apm.index_select(0, pi), pk, n_p)], dim=-1)
+        de = torch.cat([_mean2embed(self.drug2latent, dm.index_select(0, di), dk, n_d),
+                        _mean2embed(self.aug_drug2latent, adm.index_select(0, di), dk, n_d)], dim=-1)
         return F.normalize(self.to_prot_latent(pe), dim=-1), F.normalize(self.to_drug_latent(de), dim=-1)
 
-    def forward(self, prot, aug_prot, drug, aug_drug, meta):
+    def forward(self, prot, aug_prot, drug, aug_drug, meta=None, labels: CMLabels = None):
+        """meta: the batch's id / label records (the reference's argument); labels: the same thing already on the device
+        (CMLabels.fill — what a captured step hands over).  One of the two."""
         means = [t.float().mean(dim=1) for t in (prot, aug_prot, drug, aug_drug)]
         if self.global_batch and dist_ops.world_size() > 1:
             # NEW vs the reference (off by default): the label matrix and the triplets span the GLOBAL batch.
             # Only the (n, hidden) token means and the ids travel: 4 x 128 floats per pair over xGMI.
+            if meta is None:
+                raise RuntimeError("CrossModality: the global-batch form needs the id records (meta); it is not capturable")
             means = [dist_ops.all_gather_rows(m) for m in means]
             meta = dist_ops.all_gather_meta(meta)
-        pidx, didx, gt = label_matrix(meta, self.use_cm)
-        p_lats, d_lats = self.latents_from_means(*means, pidx, didx)
-        gt_dev = torch.from_numpy(gt).to(p_lats.device)
-        return Fn.TripletSigCosFn.apply(p_lats.float(), d_lats.float(), gt_dev, float(self.m_sch_loss_fn.margin))
+            labels = None
+        if labels is None:
+            labels = CMLabels(len(meta), means[0].device).fill(meta, self.use_cm)
+        p_lats, d_lats = self.latents_from_means(*means, labels)
+        return Fn.TripletSigCosFn.apply(p_lats.float(), d_lats.float(), labels.gt, float(self.m_sch_loss_fn.margin))

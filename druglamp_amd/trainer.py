@@ -244,17 +244,26 @@ class GraphedStep:
       * the weight images are refreshed from the fp32 masters by the dl_weight_prep launch at the head of the graph;
       * BatchNorm running statistics are updated by the in-graph dl_bn_finalize launches."""
 
-    def __init__(self, trainer: "Trainer", batch, kind: str = "cls"):
+    def __init__(self, trainer: "Trainer", batch, kind: str = "cls", meta=None):
         """Capture only records (nothing executes): the caller has already run eager steps of this shape AND kind, so lazy
         allocations (the SimSiam projectors of the first SSL forward), weight-image tables and workspaces exist.
         kind "ssl" (round 3): a step of an SSL epoch without the CM head — forward, BCE (logged only: its backward is dead,
         the next zero_grad wipes it, trainer.py:196-212 of the reference), SSL heads, their backward, gradient packing.  The
         MLM mask draw (rand / topk / scatter on the device) is captured with the step: torch's device generator is
-        graph-safe (its Philox offset is advanced per replay), so every replay draws fresh masks."""
+        graph-safe (its Philox offset is advanced per replay), so every replay draws fresh masks.
+        kinds "cm" / "sslcm" (round 3): a step with the cross-modality head (and, on SSL epochs, the SSL forward whose loss
+        is logged and whose backward is dead).  The head is shape-static (model/cross_modality.py: unique-row blocks padded
+        to the batch, masked BatchNorm statistics, (B, B) label matrix with ignored padding); the batch's label matrix is
+        built on the host and copied into this graph's CMLabels before every replay.  The margin of the triplet loss and
+        Trainer.cm_weight are by-value arguments of the capture: the trainer keys its graphs by them."""
         self.kind = kind
         self.tr = trainer
         dev = trainer.device
         self.static = self._clone(batch)
+        self.labels = None
+        if "cm" in kind:
+            from .model.cross_modality import CMLabels
+            self.labels = CMLabels(int(batch[2].shape[0]), dev).fill(meta, trainer.model.cm_model.use_cm)
         # The weight-image refresh (dl_weight_prep) must be a node of the graph whatever ran last: an eager forward with no
         # optimiser step behind it (evaluate() between the warm-up steps and this capture, a validate-every-N loop) leaves
         # the images current, lowp() would skip the refresh during capture, and every replay would then compute with the
@@ -287,6 +296,8 @@ class GraphedStep:
         ts = [tr.flat.arena, tr.flat.grads] + [t for o in (tr.opt, tr.opt_ssl, tr.opt_cm) if o is not None for t in (o.exp_avg, o.exp_avg_sq)]
         ts += [b for b in tr.model.buffers()] + [p_ for p_ in tr.model.parameters()]
         ts += [t for b in self.static for t in (b if isinstance(b, (tuple, list)) else (b,))]
+        if self.labels is not None:
+            ts += [self.labels.idx, self.labels.mask, self.labels.n, self.labels.gt]
         ts += list(ops._seed_offsets.values()) + list(ops._tickets.values())
         ts += [e.image for e in Fn._lowp_cache.values() if torch.is_tensor(e.image)]
         for tab in list(Fn._lowp_tables.values()) + [t for t in Fn._lowp_retired if isinstance(t, tuple) and len(t) == 4]:
@@ -338,17 +349,24 @@ class GraphedStep:
         tr, m = self.tr, self.tr.model
         ops.seed_offset_tensor(tr.device).add_(1)
         feat_d, feat_p, labels, llm_d, llm_p = self.static
-        _, _, ssl_input, _, score = m(feat_d, feat_p, llm_d, llm_p)
+        _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p)
         tr._zero_grad()
         _, cls_loss = binary_cross_entropy(score, labels) if tr.n_class == 1 else cross_entropy_logits(score, labels)
         out = {"cls": cls_loss.detach()}
-        if self.kind == "ssl":
+        if "ssl" in self.kind:
             with m._glue():
                 d = m.ssl_model(**ssl_input)
             ssl_loss = (d["prot_ssl"] + d["drug_ssl"]) * 0.1
-            ssl_loss.backward()
+            if self.kind == "ssl":               # with the CM head behind it this backward is dead too
+                ssl_loss.backward()
             out["ssl"] = ssl_loss.detach()
-        else:
+        if "cm" in self.kind:
+            with m._glue():
+                cm_loss = m.cm_model(**cm_input, labels=self.labels)
+            cm_loss = cm_loss * tr.cm_weight
+            cm_loss.backward()
+            out["cm"] = cm_loss.detach()
+        elif self.kind == "cls":
             cls_loss.backward()
         idx = tr.flat.pack_grads()
         self.reduced = False
@@ -357,14 +375,21 @@ class GraphedStep:
             # no host launch between backward and the collective.  The agreed parameter set must be cached already (the
             # eager warm-up steps of this shape did that): agreeing needs a host sync, which capture forbids.
             if tr.world > 1:
-                if self.kind not in (tr._agreed_sets or {}):
-                    raise RuntimeError("GraphedStep: the agreed gradient set of %s steps must exist before capture" % self.kind)
-                idx = tr._agreed(self.kind, idx)
+                if self.last not in (tr._agreed_sets or {}):
+                    raise RuntimeError("GraphedStep: the agreed gradient set of %s steps must exist before capture" % self.last)
+                idx = tr._agreed(self.last, idx)
             tr._all_reduce_runs(idx)
             self.reduced = True
         return out, idx
 
-    def run(self, batch):
+    @property
+    def last(self) -> str:
+        """The backward pass the optimisers consume (the key of the agreed gradient set)."""
+        return "cm" if "cm" in self.kind else self.kind
+
+    def run(self, batch, meta=None):
+        if self.labels is not None:
+            self.labels.fill(meta, self.tr.model.cm_model.use_cm)      # host label matrix -> the graph's static tensors
         if not self._is_static(batch):                  # copy into the static inputs (device-to-device)
             for dst, src in zip(self.static, batch):
                 if isinstance(dst, tuple):
@@ -379,8 +404,8 @@ class GraphedStep:
 
 class Trainer:
     """ExpModule restated (trainer.py:39-292).  `cfg` is the merged config tree.
-    graph_steps=True: cls-only steps and SSL-epoch steps run as hipGraph replays (GraphedStep); steps with the CM head and the
-    first steps of every new (batch shape, step kind) stay eager."""
+    graph_steps=True: cls, SSL-epoch and CM steps run as hipGraph replays (GraphedStep); the first steps of every new
+    (batch shape, step kind), the epoch the CM head starts in and the global-batch CM form stay eager."""
     overlap = None
     _agreed_sets = None
     grad_bf16 = False
@@ -552,13 +577,16 @@ class Trainer:
             m.train()                  # (walks every submodule: 0.7 ms per call)
         compute_ssl = self.use_ssl and (cur_epoch % self.ssl_epoch_step == 0)
         compute_cm = self.use_cm and (cur_epoch >= self.cm_init_epoch)
-        if self.graph_steps and not compute_cm and not self.run_dead_backward and (not compute_ssl or ssl_masks is None):
-            # cls steps and (round 3) SSL-epoch steps replay a graph; steps with the CM head stay eager: its unique-id
-            # gather and label matrix are host work and its BatchNorms see a batch-dependent number of rows
-            kind = "ssl" if compute_ssl else "cls"
-            sig = (kind,) + GraphedStep.signature(batch)
+        # steps with the CM head replay a graph too (round 3) except: in the epoch the head starts (the cm_weight
+        # auto-scale below reads losses on the host), without id records, and in the global-batch form (object collectives)
+        cm_ok = (not compute_cm) or (cur_epoch > self.cm_init_epoch and meta is not None and
+                                     not (m.cm_model.global_batch and self.world > 1))
+        if self.graph_steps and cm_ok and not self.run_dead_backward and (not compute_ssl or ssl_masks is None):
+            kind = (("ssl" if compute_ssl else "") + ("cm" if compute_cm else "")) or "cls"
+            byval = (float(m.cm_model.m_sch_loss_fn.margin), float(self.cm_weight)) if compute_cm else ()
+            sig = (kind,) + GraphedStep.signature(batch) + byval
             if sig in self._graphs or self._eager_seen.get(sig, 0) >= self.graph_warmup:
-                return self._graphed_step(batch, sig, kind)
+                return self._graphed_step(batch, sig, kind, meta)
             self._eager_seen[sig] = self._eager_seen.get(sig, 0) + 1
         feat_d, feat_p, labels, llm_d, llm_p = batch
         _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p)
@@ -606,24 +634,33 @@ class Trainer:
         Fn.bump_param_epoch()
         return out
 
-    def _graphed_step(self, batch, sig, kind: str = "cls") -> Dict[str, float]:
+    def _graphed_step(self, batch, sig, kind: str = "cls", meta=None) -> Dict[str, float]:
         g = self._graphs.get(sig)
         if g is None:
-            g = self._graphs[sig] = GraphedStep(self, batch, kind)     # records only; the replay below is the step
-        out, idx = g.run(batch)
+            if "cm" in kind:
+                # margin / cm_weight are by-value arguments of a capture: a graph of the same kind and shapes with older
+                # values (the margin moves once per epoch) will not be replayed again — release its pool first
+                n_shape = len(GraphedStep.signature(batch))
+                for old in [k for k in self._graphs if k[:1 + n_shape] == sig[:1 + n_shape]]:
+                    del self._graphs[old]
+            g = self._graphs[sig] = GraphedStep(self, batch, kind, meta)     # records only; the replay below is the step
+        out, idx = g.run(batch, meta)
         if self.world > 1 and not g.reduced:
-            idx = self._agreed(kind, idx)
+            idx = self._agreed(g.last, idx)
             self._all_reduce_runs(idx)
         self.opt.step(idx, 1.0 / self.world)
-        if kind == "ssl":
+        if "ssl" in kind:
             self.opt_ssl.step(idx, 1.0 / self.world)
+        if "cm" in kind:
+            self.opt_cm.step(idx, 1.0 / self.world)
         Fn.bump_param_epoch()
         return out
 
     def static_batch(self, batch):
         """The captured graph's own input tensors for batches of this shape (or `batch` itself while no graph exists):
         a producer that fills them in place — and passes them back — saves the per-step input copy."""
-        g = self._graphs.get(("cls",) + GraphedStep.signature(batch)) or self._graphs.get(("ssl",) + GraphedStep.signature(batch))
+        shape = GraphedStep.signature(batch)
+        g = next((v for k, v in self._graphs.items() if k[1:1 + len(shape)] == shape), None)
         return batch if g is None else g.static
 
     def on_train_epoch_end(self, cur_epoch: int):

@@ -88,7 +88,71 @@ def test_graph_replays_draw_fresh_dropout_masks():
         ops.use_seed_offset(False)
 
 
-def test_cm_steps_stay_eager_when_graphs_are_on():
+def test_cm_steps_replay_a_graph_bit_identical_to_eager_steps():
+    """Round 3: steps with the cross-modality head (DrugLAMP2C2P from RS.INIT_EPOCH + 1 on; reference trainer.py:213-221) are
+    captured (kind "cm"): the head is shape-static (padded unique-row blocks, masked BatchNorm statistics, (B, B) label
+    matrix) and the batch's label matrix is refreshed from the host before each replay.  Dropout off: graphed and eager
+    steps leave bit-identical parameters, moments of all optimisers that stepped, BatchNorm buffers and losses — also when
+    a replay gets another batch with other ids (other n_p / n_d)."""
+    from druglamp_amd import ops
+    from druglamp_amd.synthetic import make_batch
+    batch, meta = make_batch(8, DEV, seed=7, with_graph=True, llm_dtype=torch.bfloat16)
+    other, meta2 = make_batch(8, DEV, seed=8, with_graph=True, llm_dtype=torch.bfloat16)
+    meta2 = [dict(m, Prot_ID=m["Prot_ID"] if i % 3 else meta2[0]["Prot_ID"]) for i, m in enumerate(meta2)]   # fewer unique proteins
+    seq = [(batch, meta), (batch, meta), (batch, meta), (other, meta2), (batch, meta)]
+    res = {}
+    try:
+        for graph in (False, True):
+            tr = _make(0.0, graph, kind="DrugLAMP2C2P")
+            tr.cm_weight = 10.0
+            outs = []
+            for b, mt in seq:
+                o = tr.training_step(b, meta=mt, cur_epoch=6)
+                outs.append((float(o["cls"]), float(o["cm"])))
+            if graph:
+                (sig, g), = tr._graphs.items()
+                assert g.kind == "cm" and g.replays == len(seq) - tr.graph_warmup and sig[-2:] == (tr.model.cm_model.m_sch_loss_fn.margin, 10.0)
+            res[graph] = (outs, _state(tr) + (tr.opt_cm.exp_avg.clone(), tr.opt_cm.exp_avg_sq.clone()))
+    finally:
+        ops.use_seed_offset(False)
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    assert len({o[1] for o in res[True][0]}) > 2          # the head's loss moves (it trains, and step 4 has other labels)
+    for a, b in zip(res[False][1], res[True][1]):
+        assert torch.equal(a, b)
+
+
+def test_cm_graphs_follow_the_margin_schedule_and_ssl_epochs():
+    """The triplet margin is a by-value argument of the capture: when the schedule moves it (once per epoch) the next CM
+    step is eager again, then re-captured, and the graph with the old margin is released.  On an SSL epoch the step kind is
+    "sslcm" (SSL forward for the logged loss, its backward dead like in the eager step)."""
+    from druglamp_amd import ops
+    from druglamp_amd.synthetic import make_batch
+    batch, meta = make_batch(8, DEV, seed=7, with_graph=True, llm_dtype=torch.bfloat16)
+    try:
+        tr = _make(0.0, True, kind="DrugLAMP2C2P")
+        for _ in range(4):
+            tr.training_step(batch, meta=meta, cur_epoch=6)
+        (sig0, g0), = tr._graphs.items()
+        assert g0.replays == 2
+        tr.on_train_epoch_end(6)                               # margin schedule steps
+        m1 = tr.model.cm_model.m_sch_loss_fn.margin
+        assert m1 != sig0[-2]
+        for _ in range(4):
+            out = tr.training_step(batch, meta=meta, cur_epoch=7)
+        (sig1, g1), = tr._graphs.items()                       # the old graph is gone
+        assert sig1[-2] == m1 and g1.replays == 2 and g1 is not g0
+        for _ in range(4):
+            out = tr.training_step(batch, meta=meta, cur_epoch=10)
+            assert set(out) == {"cls", "ssl", "cm"} and all(torch.isfinite(v).all() for v in out.values())
+        kinds = sorted(g.kind for g in tr._graphs.values())
+        assert kinds == ["cm", "sslcm"], kinds
+        assert torch.isfinite(tr.flat.arena).all()
+    finally:
+        ops.use_seed_offset(False)
+
+
+def test_cm_steps_stay_eager_in_the_epoch_the_head_starts():
+    """cur_epoch == RS.INIT_EPOCH: the cm_weight auto-scale reads losses on the host (trainer.py:216-220 of the reference)."""
     from druglamp_amd import ops
     from druglamp_amd.synthetic import make_batch
     batch, meta = make_batch(8, DEV, seed=7, with_graph=True, llm_dtype=torch.bfloat16)
