@@ -33,6 +33,7 @@ class ReduceItem(C.Structure):
 
 
 REDUCE_BATCH_MAX = 24
+GEMM_GROUP_MAX = 16
 
 
 class GemmArgs(C.Structure):
@@ -110,6 +111,8 @@ SIGNATURES = {
     "dl_gemm_workspace_bytes": (c_sz, [C.POINTER(GemmArgs)]),
     "dl_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "dl_gemm_pair": (c_i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), c_vp]),
+    "dl_gemm_group_plan": (c_i32, [C.POINTER(GemmArgs), c_i32, C.POINTER(c_i32)]),
+    "dl_gemm_group": (c_i32, [C.POINTER(GemmArgs), c_i32, c_vp]),
     "dl_reduce_batch": (c_i32, [C.POINTER(ReduceItem), c_i32, c_vp]),
     "dl_colsum": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_sz, c_vp]),
     "dl_colsum_workspace_bytes": (c_sz, [c_i64, c_i64]),

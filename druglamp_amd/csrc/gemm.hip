@@ -12,6 +12,8 @@
 // The MFMA is issued "swapped" (A = W fragment, B = X fragment) so each lane ends up holding 4
 // CONSECUTIVE output columns of one output row: 8-byte (bf16) / 16-byte (f32) stores.
 #include <stdlib.h>
+#include <stdint.h>
+#include <algorithm>
 #include <type_traits>
 #include "common.cuh"
 
@@ -992,6 +994,99 @@ int gemm_run(const dl_gemm_args* a, const dl_gemm_args* b, dl_stream stream) {
   return DL_OK;
 }
 }  // namespace
+
+// ---- grouped weight gradients (dl_gemm_group) -------------------------------------------------------------
+namespace {
+bool group_member_ok(const dl_gemm_args* a) {
+  const bool plain = !a->bias && !a->residual && !a->act && !a->pre_out && !a->dact_pre && a->dropout_p <= 0.f && !a->accumulate;
+  return a->X && a->W && a->C && a->in_dtype == DL_BF16 && a->out_dtype == DL_F32 && a->x_kslow && a->w_kslow && a->split_k == 0 && plain &&
+         a->algo == DL_GEMM_ALGO_AUTO && a->M >= 8 && a->N >= 8 && a->M % 8 == 0 && a->N % 8 == 0 && a->K >= 64 &&
+         a->M < (1ll << 30) && a->N < (1ll << 30) && a->K < (1ll << 30) && a->ldx % 8 == 0 && a->ldw % 8 == 0 &&
+         (((uintptr_t)a->X | (uintptr_t)a->W | (uintptr_t)a->C) & 15) == 0 && a->ldc % 4 == 0;
+}
+// 128 x 256 tiles; one common slab count `sp` so that all tiles x slabs make about one round of 256 workgroups, at least
+// eight 64-row k-steps per slab; per problem trimmed so that no slab is empty.  Returns 0 when the group is not eligible.
+int group_plan(const dl_gemm_args* args, int n, int* splits) {
+  if (!args || n < 1 || n > DL_GROUP_MAX) return 0;
+  int64_t tiles = 0, min_steps = INT64_MAX;
+  for (int i = 0; i < n; ++i) {
+    if (!group_member_ok(&args[i])) return 0;
+    tiles += ((args[i].M + 127) / 128) * ((args[i].N + 255) / 256);
+    min_steps = std::min<int64_t>(min_steps, (args[i].K + 63) / 64);
+  }
+  int64_t sp = 256 / tiles;
+  if (sp > min_steps / 8) sp = min_steps / 8;
+  if (sp < 1) sp = 1;
+  for (int i = 0; i < n; ++i) splits[i] = trim_splits(args[i].K, 64, (int)sp);
+  return 1;
+}
+}  // namespace
+
+extern "C" int dl_gemm_group_plan(const dl_gemm_args* args, int32_t n, int32_t* splits_out) {
+  DL_CHECK_ARG(splits_out, DL_ERR_ARG, "dl_gemm_group_plan: null splits_out");
+  int sp[DL_GROUP_MAX];
+  if (!group_plan(args, n, sp)) {
+    dl_set_error("dl_gemm_group_plan: not a group of at most %d bf16 weight-gradient products (x_kslow, w_kslow, f32 plain output, split_k = 0, "
+                 "M, N multiples of 8, K >= 64, 16-byte aligned operands)", DL_GROUP_MAX);
+    return DL_ERR_UNSUPPORTED;
+  }
+  for (int i = 0; i < n; ++i) splits_out[i] = sp[i];
+  return DL_OK;
+}
+
+extern "C" int dl_gemm_group(const dl_gemm_args* args, int32_t n, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int sp[DL_GROUP_MAX];
+  DL_CHECK_ARG(group_plan(args, n, sp), DL_ERR_UNSUPPORTED, "dl_gemm_group: the group is not eligible (see dl_gemm_group_plan)");
+  GemmGroupP gp;
+  gp.n = n; gp.dbg = dl_study_env("DL_GEMM_DBG", 0);
+  uint32_t end = 0;
+  double flops = 0.0, bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const dl_gemm_args* a = &args[i];
+    const size_t need = (size_t)sp[i] * (size_t)a->M * ((size_t)a->N + (a->x_colsum ? 1 : 0)) * sizeof(float);
+    DL_CHECK_ARG(a->workspace && a->workspace_bytes >= need && ((uintptr_t)a->workspace & 15) == 0, DL_ERR_WORKSPACE,
+                 "dl_gemm_group: problem %d needs %zu workspace bytes (16-byte aligned), got %zu", i, need, a->workspace_bytes);
+    GroupProb& q = gp.q[i];
+    q.X = (const char*)a->X; q.W = (const char*)a->W; q.ldx = a->ldx; q.ldw = a->ldw;
+    q.M = (int)a->M; q.N = (int)a->N; q.K = (int)a->K;
+    q.mt = (int)((a->M + 127) / 128); q.nt = (int)((a->N + 255) / 256);
+    const int64_t ksteps = (a->K + 63) / 64;
+    q.k_per_split = (int)(((ksteps + sp[i] - 1) / sp[i]) * 64);
+    q.slabs = (float*)a->workspace;
+    q.cs_slabs = a->x_colsum ? (float*)a->workspace + (size_t)sp[i] * a->M * a->N : nullptr;
+    end += (uint32_t)q.mt * q.nt * sp[i];
+    q.end = end; q.pad = 0;
+    flops += 2.0 * (double)a->M * (double)a->N * (double)a->K;
+    bytes += ((double)a->M * a->K + (double)a->N * a->K) * 2.0 + (double)a->M * a->N * 4.0;
+  }
+  for (int i = n; i < DL_GROUP_MAX; ++i) { gp.q[i] = gp.q[n - 1]; }
+  const uint32_t nblocks = end < 256u ? end : 256u;
+  dl_prof_before(0, s);
+  hipLaunchKernelGGL((gemm_big_tt2_kernel<4, 2, 4, true, 64, 3, false, true>), dim3(nblocks), dim3(512), 0, s, gp);
+  DL_CHECK_LAUNCH("dl_gemm_group");
+  dl_prof_after(0, s, flops, bytes);
+  for (int i = 0; i < n; ++i) {
+    const dl_gemm_args* a = &args[i];
+    const int64_t mn = a->M * a->N;
+    if (a->deferred) {
+      dl_reduce_item& it = *a->deferred;
+      it.kind = DL_REDUCE_SPLITK; it.out_dtype = a->out_dtype;
+      it.src = (const float*)a->workspace; it.out = a->C; it.mn = mn; it.ldc = a->ldc; it.N = (int32_t)a->N;
+      it.splits = sp[i]; it.accumulate = 0; it.M = a->x_colsum ? (int32_t)a->M : 0;
+      it.cs_slabs = gp.q[i].cs_slabs; it.cs_out = a->x_colsum;
+      continue;
+    }
+    const int threads = 256;
+    const int64_t blocks = (mn / 4 + threads - 1) / threads;
+    const int64_t cs_blocks = a->x_colsum ? (a->M + threads - 1) / threads : 0;
+    hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((uint32_t)(blocks + cs_blocks)), dim3(threads), 0, s,
+                       (const float*)a->workspace, (float*)a->C, mn, a->ldc, (int)a->N, sp[i], 0,
+                       (const float*)gp.q[i].cs_slabs, a->x_colsum, (int)a->M, (uint32_t)blocks);
+    DL_CHECK_LAUNCH("dl_gemm_group(split reduce)");
+  }
+  return DL_OK;
+}
 
 // ---- column sums ------------------------------------------------------------------------------
 namespace {

@@ -319,8 +319,22 @@ __device__ __forceinline__ void dma16s(uint32_t voff, const char* sbase_, uint32
                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b));
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory");
 }
-template <int XF, int NWM, int NWN, bool CS, int KS, int NSTAGE, bool PF>
-__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const GemmP p) {
+// GROUP (round 3, dl_gemm_group): up to DL_GROUP_MAX weight-gradient products of DIFFERENT shapes in one launch — the
+// weight gradients of a block's backward at the strong-scaling batches, where each of them alone is a handful of tiles
+// over a few thousand k-rows and pays a launch, a prologue and a 16- to 32-way slab round trip for a few microseconds of
+// matrix work.  The tile lists of the problems are concatenated (GroupProb::end = running tile count); a workgroup
+// re-reads the problem's fields whenever it takes a tile (wave-uniform scalar loads from the kernel arguments).
+constexpr int DL_GROUP_MAX = 16;
+struct GroupProb {
+  const char* X; const char* W; float* slabs; float* cs_slabs;
+  int64_t ldx, ldw;
+  int M, N, K, k_per_split, mt, nt;
+  uint32_t end; int pad;
+};
+struct GemmGroupP { int n; int dbg; GroupProb q[DL_GROUP_MAX]; };
+
+template <int XF, int NWM, int NWN, bool CS, int KS, int NSTAGE, bool PF, bool GROUP = false>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const std::conditional_t<GROUP, GemmGroupP, GemmP> p) {
   typedef bf16_t T;
   constexpr int WF = 4;
   constexpr int NT = 64 * NWM * NWN, BM = 16 * XF * NWM, BN = 16 * WF * NWN;
@@ -347,20 +361,39 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const G
   const int wm = wave / NWN, wn = wave % NWN;
   auto swz = [](int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); };
   const uint32_t smem_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
-  const int64_t ldx2 = p.ldx * 2, ldw2 = p.ldw * 2;
-
-  const uint32_t per_split = (uint32_t)p.mt * p.nt;
-  const uint32_t ntiles = per_split * p.splits;
+  // the problem of the tile being located (loop-invariant unless GROUP)
+  const char* qX; const char* qW; float* qslabs; float* qcs;
+  int64_t ldx2, ldw2;
+  int qM, qN, qK, qkps, qnt;
+  uint32_t per_split, ntiles;
+  if constexpr (GROUP) {
+    ntiles = p.q[p.n - 1].end;
+    qX = qW = nullptr; qslabs = qcs = nullptr; ldx2 = ldw2 = 0; qM = qN = qK = qkps = qnt = 0; per_split = 1;
+  } else {
+    qX = p.X; qW = p.W; qslabs = p.slabs; qcs = p.cs_slabs; ldx2 = p.ldx * 2; ldw2 = p.ldw * 2;
+    qM = p.M; qN = p.N; qK = p.K; qkps = p.k_per_split; qnt = p.nt;
+    per_split = (uint32_t)p.mt * p.nt;
+    ntiles = per_split * p.splits;
+  }
   const uint32_t G = gridDim.x;
   auto locate = [&](uint32_t it, int& split, int& m0, int& n0, int& kbeg, int& kend) {
     const uint32_t round0 = (it / G) * G;
     const uint32_t span = min(G, ntiles - round0);
-    const uint32_t t = round0 + xcd_remap(it - round0, span);
+    uint32_t t = round0 + xcd_remap(it - round0, span);
+    if constexpr (GROUP) {
+      int i = 0;
+      while (t >= p.q[i].end) ++i;
+      const GroupProb& q = p.q[i];
+      t -= i ? p.q[i - 1].end : 0u;
+      qX = q.X; qW = q.W; qslabs = q.slabs; qcs = q.cs_slabs; ldx2 = q.ldx * 2; ldw2 = q.ldw * 2;
+      qM = q.M; qN = q.N; qK = q.K; qkps = q.k_per_split; qnt = q.nt;
+      per_split = (uint32_t)q.mt * q.nt;
+    }
     split = (int)(t / per_split);
     const uint32_t tile = t % per_split;
-    m0 = (int)(tile / p.nt) * BM; n0 = (int)(tile % p.nt) * BN;
-    kbeg = split * p.k_per_split;
-    kend = min(p.K, kbeg + p.k_per_split);
+    m0 = (int)(tile / qnt) * BM; n0 = (int)(tile % qnt) * BN;
+    kbeg = split * qkps;
+    kend = min(qK, kbeg + qkps);
   };
   // a lane's byte offset inside the operand tile of a step (piece 0); the tile's first byte is uniform
   const int xkrow = tid / CPX, wkrow = tid / CPW;
@@ -371,26 +404,26 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const G
     {
       const int pc = tid % CPX;
       int col = (pc ^ swz(xkrow)) << 3;
-      col = m0 + col < p.M ? col : p.M - 8 - m0;
+      col = m0 + col < qM ? col : qM - 8 - m0;
       xvoff = (uint32_t)(xkrow * (int)ldx2 + col * 2);
-      xtile = p.X + ((int64_t)kbeg * p.ldx + m0) * 2;
+      xtile = qX + (int64_t)kbeg * ldx2 + (int64_t)m0 * 2;
     }
     {
       const int pc = tid % CPW;
       int col = (pc ^ swz(wkrow)) << 3;
-      col = n0 + col < p.N ? col : p.N - 8 - n0;
+      col = n0 + col < qN ? col : qN - 8 - n0;
       wvoff = (uint32_t)(wkrow * (int)ldw2 + col * 2);
-      wtile = p.W + ((int64_t)kbeg * p.ldw + n0) * 2;
+      wtile = qW + (int64_t)kbeg * ldw2 + (int64_t)n0 * 2;
     }
     if constexpr (PF) {
       const int krow = min(tid / LPR, KS - 1), part = tid % LPR;
       pf_row = kbeg + krow;
       if (part < PX / 128) {
-        const int col = min(m0 + part * 64, p.M - 2);
-        pf_base = p.X + (int64_t)col * 2; pf_ld = ldx2;
+        const int col = min(m0 + part * 64, qM - 2);
+        pf_base = qX + (int64_t)col * 2; pf_ld = ldx2;
       } else {
-        const int col = min(n0 + (part - PX / 128) * 64, p.N - 2);
-        pf_base = p.W + (int64_t)col * 2; pf_ld = ldw2;
+        const int col = min(n0 + (part - PX / 128) * 64, qN - 2);
+        pf_base = qW + (int64_t)col * 2; pf_ld = ldw2;
       }
     }
   };
@@ -424,7 +457,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const G
   // L2 prefetch of step kt's lines (rows past the operand's end are clamped to its last row: always a legal address)
   auto prefetch = [&](int kt) {
     if constexpr (PF) {
-      const int row = min(pf_row + kt * KS, p.K - 1);
+      const int row = min(pf_row + kt * KS, qK - 1);
       const char* src = pf_base + (int64_t)row * pf_ld;
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(smem_lds + (uint32_t)(NSTAGE * STAGE)) : "memory");
     }
@@ -463,7 +496,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const G
     float cs[XF];
 #pragma unroll
     for (int i = 0; i < XF; ++i) cs[i] = 0.f;
-    const bool do_cs = CS && n0 == 0 && wn == 0;
+    const bool do_cs = CS && n0 == 0 && wn == 0 && (!GROUP || qcs != nullptr);
     const int len = kend - kbeg;
     const int nk = (len + KS - 1) / KS;
     auto kstep = [&](auto with_cs, auto feed, int kt) __attribute__((always_inline)) {
@@ -524,6 +557,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const G
     }
 
     const int cm0 = m0, cn0 = n0, csplit = split;
+    const int eM = qM, eN = qN;                    // this tile's problem: locate() moves q* on to the next tile's
+    float* const eslabs = qslabs; float* const ecs = qcs;
     const uint32_t itn = it + G;
     const bool have_next = itn < ntiles;
     if (have_next) {
@@ -537,7 +572,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const G
       for (int i = 0; i < XF; ++i) {
         const float v = group4_sum(cs[i]);
         const int m = cm0 + wm * 16 * XF + i * 16 + il;
-        if (g == 0 && m < p.M) p.cs_slabs[(int64_t)csplit * p.M + m] = v;
+        if (g == 0 && m < eM) ecs[(int64_t)csplit * eM + m] = v;
       }
     }
     char* st = smem + ((gs + NSTAGE - 1) % NSTAGE) * STAGE + wave * 4096;
@@ -552,8 +587,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const G
         const u32x4 a0 = lds_read16(st, r * 256 + (((2 * c8) ^ r) << 4));
         const u32x4 a1 = lds_read16(st, r * 256 + (((2 * c8 + 1) ^ r) << 4));
         const int m = cm0 + wm * 16 * XF + i * 16 + r, n = cn0 + wn * 16 * WF + c8 * 8;
-        if (m < p.M && n < p.N && !(DL_DBG(p) & 1)) {
-          float* dst = p.slabs + ((int64_t)csplit * p.M + m) * p.N + n;
+        if (m < eM && n < eN && !(DL_DBG(p) & 1)) {
+          float* dst = eslabs + ((int64_t)csplit * eM + m) * eN + n;
           *reinterpret_cast<u32x4*>(dst) = a0;
           *reinterpret_cast<u32x4*>(dst + 4) = a1;
         }

@@ -131,6 +131,18 @@ int dl_gemm(const dl_gemm_args* a, dl_stream s);
  * deferred reductions, different flags) the two run one after the other exactly as two dl_gemm calls.  Results are
  * bit-identical to two dl_gemm calls either way (tested). */
 int dl_gemm_pair(const dl_gemm_args* a, const dl_gemm_args* b, dl_stream s);
+/* n <= 16 weight-gradient products of DIFFERENT shapes in ONE launch (round 3): the dW = dY^T X products of one block's
+ * backward (reference model/PMMA/block.py:33-62 as autograd differentiates it: fc1 / fc2 / out / fc / qkv of both streams).
+ * At the strong-scaling batches each of them alone is a few 128 x 128 tiles over 8192-16384 rows: a launch, a prologue and a
+ * 16- to 32-way split-K slab round trip for microseconds of matrix work.  Grouped, the tile lists are concatenated, the
+ * parallelism comes from the number of products and the slab count drops to 1-4.  Every member is a dl_gemm_args in the
+ * weight-gradient form (bf16 operands, x_kslow = w_kslow = 1, plain f32 output, split_k = 0, accumulate = 0; optional
+ * x_colsum and `deferred`); dl_gemm_group_plan returns the slab count the library will use for each member (its workspace
+ * must hold splits * M * (N + (x_colsum ? 1 : 0)) floats) or DL_ERR_UNSUPPORTED for a group it does not take (the caller
+ * then issues dl_gemm calls).  A member's result is the fixed-order sum of its slabs like dl_gemm's, but NOT bit-identical
+ * to the dl_gemm call (different slab count). */
+int dl_gemm_group_plan(const dl_gemm_args* args, int32_t n, int32_t* splits_out);
+int dl_gemm_group(const dl_gemm_args* args, int32_t n, dl_stream s);
 
 /* column sums: out[n] (+)= sum_m X[m,n] — bias gradients of every Linear above. */
 int dl_colsum(const void* X, int64_t ldx, int64_t M, int64_t N, int32_t dtype, float* out,

@@ -406,13 +406,18 @@ def test_deferred_reductions_are_bitwise_equal_to_immediate_ones():
         return outs + [dx, dg, dbt]
 
     ref = [t.clone() for t in run()]
-    with ops.deferred_reductions():
-        got = run()
-        assert len(ops._pending) == len(shapes) + 1          # every reduction is queued, none has run
+    keep = ops.group_wgrad_max_k, ops.group_wgrad_small_mn    # (grouped weight gradients change the slab counts: own test below)
+    try:
+        ops.group_wgrad_max_k, ops.group_wgrad_small_mn = 0, 0
+        with ops.deferred_reductions():
+            got = run()
+            assert len(ops._pending) == len(shapes) + 1          # every reduction is queued, none has run
+    finally:
+        ops.group_wgrad_max_k, ops.group_wgrad_small_mn = keep
     torch.cuda.synchronize()
     for r, o in zip(ref, got):
         assert torch.equal(r, o)
-    # accumulate=True is never deferred, and flushes what is queued before it runs
+    # accumulate=True is never deferred (nor grouped), and flushes what is queued before it runs
     with ops.deferred_reductions():
         a, b = ops_in[0]
         dw = ops.gemm(a, b, M=1024, N=256, K=K, x_kslow=True, w_kslow=True, ldx=1024, ldw=256, out_dtype=torch.float32, split_k=0)
@@ -421,6 +426,56 @@ def test_deferred_reductions_are_bitwise_equal_to_immediate_ones():
         assert not ops._pending
     torch.cuda.synchronize()
     assert torch.equal(dw, ref[0] * 2)
+
+
+@pytest.mark.gpu
+def test_grouped_weight_gradients_match_single_launches():
+    """dl_gemm_group (round 3): the weight-gradient products queued inside a deferred_reductions() block leave as one launch
+    per 16 with 1-4 slabs each; against the same products as single dl_gemm calls (16-32 slabs): fp32 sums of the same
+    bf16 products in another association, so equal to ~1e-6 of the largest entry, column sums (bias gradients) included.
+    Covers ragged tiles (M, N not multiples of the 128 x 256 tile), different K inside one group, more than 16 products
+    (two launches), outputs that are row slices of a larger tensor, and members the group does not take (K over the
+    threshold: launched one by one)."""
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(22)
+    dt = torch.bfloat16
+    probs = [(1024, 256, 8192), (256, 1024, 8192), (256, 256, 8192), (256, 512, 8192), (768, 256, 8192), (512, 2048, 8192),
+             (1000, 648, 4160), (8, 1024, 8192), (128, 128, 16384), (136, 264, 8192), (2048, 512, 4096), (1536, 512, 8192)]
+    probs = probs + probs[:6]                                   # 18 products: two group launches
+    data = [((torch.randn(K, M, generator=g) * 0.5).to(dt).cuda(), (torch.randn(K, N, generator=g) * 0.5).to(dt).cuda()) for M, N, K in probs]
+    big = ((torch.randn(32768, 256, generator=g) * 0.5).to(dt).cuda(), (torch.randn(32768, 512, generator=g) * 0.5).to(dt).cuda())
+
+    def run():
+        outs = []
+        for i, ((M, N, K), (a, b)) in enumerate(zip(probs, data)):
+            db = torch.empty(M, dtype=torch.float32, device="cuda") if i % 3 else None
+            whole = torch.empty(M + 16, N, dtype=torch.float32, device="cuda") if i % 4 == 1 else None
+            dw = ops.gemm(a, b, M=M, N=N, K=K, x_kslow=True, w_kslow=True, ldx=M, ldw=N, out_dtype=torch.float32, split_k=0, x_colsum=db,
+                          out=None if whole is None else whole[8:8 + M])
+            outs += [dw] + ([db] if db is not None else [])
+        outs.append(ops.gemm(big[0], big[1], M=256, N=512, K=32768, x_kslow=True, w_kslow=True, ldx=256, ldw=512, out_dtype=torch.float32, split_k=0))
+        return outs
+
+    keep = ops.group_wgrad_max_k, ops.group_wgrad_small_mn
+    try:
+        ops.group_wgrad_max_k, ops.group_wgrad_small_mn = 0, 0
+        ref = [t.clone() for t in run()]
+        ops.group_wgrad_max_k = 16384
+        with ops.deferred_reductions():
+            got = run()
+            assert len(ops._wgroup) == len(probs) and len(ops._pending) == 1     # queued; only the K = 32768 product has been launched (its reduction waits)
+        torch.cuda.synchronize()
+        # run-to-run: the grouped launch is deterministic
+        with ops.deferred_reductions():
+            again = run()
+        torch.cuda.synchronize()
+    finally:
+        ops.group_wgrad_max_k, ops.group_wgrad_small_mn = keep
+    for r, o in zip(ref, got):
+        assert o.shape == r.shape
+        assert float((o - r).abs().max()) <= 2e-6 * float(r.abs().max()) + 1e-30, (r.shape, float((o - r).abs().max()), float(r.abs().max()))
+    for a_, b_ in zip(got, again):
+        assert torch.equal(a_, b_)
 
 
 @pytest.mark.gpu
