@@ -1006,18 +1006,30 @@ bool group_member_ok(const dl_gemm_args* a) {
 }
 // 128 x 256 tiles; one common slab count `sp` so that all tiles x slabs make about one round of 256 workgroups, at least
 // eight 64-row k-steps per slab; per problem trimmed so that no slab is empty.  Returns 0 when the group is not eligible.
-int group_plan(const dl_gemm_args* args, int n, int* splits) {
+int group_plan(const dl_gemm_args* args, int n, int* splits, int* bm_out) {
   if (!args || n < 1 || n > DL_GROUP_MAX) return 0;
-  int64_t tiles = 0, min_steps = INT64_MAX;
+  int64_t min_steps = INT64_MAX, big_mn = 0, all_mn = 0, min_m = INT64_MAX;
   for (int i = 0; i < n; ++i) {
     if (!group_member_ok(&args[i])) return 0;
-    tiles += ((args[i].M + 127) / 128) * ((args[i].N + 255) / 256);
     min_steps = std::min<int64_t>(min_steps, (args[i].K + 63) / 64);
+    const int64_t mn = args[i].M * args[i].N;
+    all_mn += mn;
+    if (mn >= 640 * 1024) big_mn += mn;
+    min_m = std::min<int64_t>(min_m, args[i].M);
   }
+  // 256-row tiles (four 32-row stages) when most of the group's outputs belong to large members (the d = 512 blocks) over at
+  // least 16384 rows: half the W-operand re-reads of the 128-row tile; elsewhere the 128-row tile's parallelism wins.
+  // Batch 256 with every block grouped: 15.80 ms with 128-row tiles only, 15.52 with this rule (15.60 with the large
+  // products left on their own launches); batch 128: 8.87 -> 8.77; batch 64: 5.79 -> 5.75; batch 32: no difference
+  const int want = dl_study_env("DL_GROUP_BM", 0);       // study: 128 / 256 force a tile height
+  const int bm = want == 128 ? 128 : (2 * big_mn >= all_mn && min_m >= 256 && min_steps >= dl_study_env("DL_GROUP_BM_MINSTEPS", 256)) ? 256 : 128;
+  int64_t tiles = 0;
+  for (int i = 0; i < n; ++i) tiles += ((args[i].M + bm - 1) / bm) * ((args[i].N + 255) / 256);
   int64_t sp = 256 / tiles;
   if (sp > min_steps / 8) sp = min_steps / 8;
   if (sp < 1) sp = 1;
   for (int i = 0; i < n; ++i) splits[i] = trim_splits(args[i].K, 64, (int)sp);
+  if (bm_out) *bm_out = bm;
   return 1;
 }
 }  // namespace
@@ -1025,7 +1037,7 @@ int group_plan(const dl_gemm_args* args, int n, int* splits) {
 extern "C" int dl_gemm_group_plan(const dl_gemm_args* args, int32_t n, int32_t* splits_out) {
   DL_CHECK_ARG(splits_out, DL_ERR_ARG, "dl_gemm_group_plan: null splits_out");
   int sp[DL_GROUP_MAX];
-  if (!group_plan(args, n, sp)) {
+  if (!group_plan(args, n, sp, nullptr)) {
     dl_set_error("dl_gemm_group_plan: not a group of at most %d bf16 weight-gradient products (x_kslow, w_kslow, f32 plain output, split_k = 0, "
                  "M, N multiples of 8, K >= 64, 16-byte aligned operands)", DL_GROUP_MAX);
     return DL_ERR_UNSUPPORTED;
@@ -1036,8 +1048,8 @@ extern "C" int dl_gemm_group_plan(const dl_gemm_args* args, int32_t n, int32_t* 
 
 extern "C" int dl_gemm_group(const dl_gemm_args* args, int32_t n, dl_stream stream) {
   hipStream_t s = (hipStream_t)stream;
-  int sp[DL_GROUP_MAX];
-  DL_CHECK_ARG(group_plan(args, n, sp), DL_ERR_UNSUPPORTED, "dl_gemm_group: the group is not eligible (see dl_gemm_group_plan)");
+  int sp[DL_GROUP_MAX], bm = 128;
+  DL_CHECK_ARG(group_plan(args, n, sp, &bm), DL_ERR_UNSUPPORTED, "dl_gemm_group: the group is not eligible (see dl_gemm_group_plan)");
   GemmGroupP gp;
   gp.n = n; gp.dbg = dl_study_env("DL_GEMM_DBG", 0);
   uint32_t end = 0;
@@ -1050,7 +1062,7 @@ extern "C" int dl_gemm_group(const dl_gemm_args* args, int32_t n, dl_stream stre
     GroupProb& q = gp.q[i];
     q.X = (const char*)a->X; q.W = (const char*)a->W; q.ldx = a->ldx; q.ldw = a->ldw;
     q.M = (int)a->M; q.N = (int)a->N; q.K = (int)a->K;
-    q.mt = (int)((a->M + 127) / 128); q.nt = (int)((a->N + 255) / 256);
+    q.mt = (int)((a->M + bm - 1) / bm); q.nt = (int)((a->N + 255) / 256);
     const int64_t ksteps = (a->K + 63) / 64;
     q.k_per_split = (int)(((ksteps + sp[i] - 1) / sp[i]) * 64);
     q.slabs = (float*)a->workspace;
@@ -1063,7 +1075,8 @@ extern "C" int dl_gemm_group(const dl_gemm_args* args, int32_t n, dl_stream stre
   for (int i = n; i < DL_GROUP_MAX; ++i) { gp.q[i] = gp.q[n - 1]; }
   const uint32_t nblocks = end < 256u ? end : 256u;
   dl_prof_before(0, s);
-  hipLaunchKernelGGL((gemm_big_tt2_kernel<4, 2, 4, true, 64, 3, false, true>), dim3(nblocks), dim3(512), 0, s, gp);
+  if (bm == 256) hipLaunchKernelGGL((gemm_big_tt2_kernel<8, 2, 4, true, 32, 4, false, true>), dim3(nblocks), dim3(512), 0, s, gp);
+  else hipLaunchKernelGGL((gemm_big_tt2_kernel<4, 2, 4, true, 64, 3, false, true>), dim3(nblocks), dim3(512), 0, s, gp);
   DL_CHECK_LAUNCH("dl_gemm_group");
   dl_prof_after(0, s, flops, bytes);
   for (int i = 0; i < n; ++i) {

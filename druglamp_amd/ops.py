@@ -154,10 +154,10 @@ def _gemm_launch(a, out, x, accumulate, x_colsum) -> None:
 # pairs per GPU each of them alone is a few tiles over 8192-16384 rows behind a 16- to 32-way split; together they fill the
 # chip with 1-4 slabs each.  The rule of deferred_reductions() covers it: nothing inside the block reads these outputs,
 # and their operands (saved activations, fresh gradient tensors) are not written again before the block ends.
-# Measured (bench.py, same box): batch 32 4.71 -> 4.23 ms, 64 6.22 -> 5.77, 128 9.32 -> 8.87, 256 15.53 -> 15.09.  At 65536 rows the
-# large outputs (2048 x 512 ...) stay on their own 256 x 256-tile launches (grouping them too: 15.26).
-group_wgrad_max_k = int(os.environ.get("DL_GROUP_WGRAD_MAX_K", "32768"))         # 0 (and small_mn 0): off
+# Measured (bench.py, same box, off -> on): batch 32 4.71 -> 4.23 ms, 64 6.22 -> 5.75, 128 9.32 -> 8.77, 256 15.53 -> 15.0.
+group_wgrad_max_k = int(os.environ.get("DL_GROUP_WGRAD_MAX_K", "65536"))         # 0 (and small_mn 0): off
 group_wgrad_small_mn = int(os.environ.get("DL_GROUP_WGRAD_SMALL_MN", "655360"))  # products with fewer outputs are grouped at any K
+group_wgrad_min_n = 2          # a single queued product takes its usual dl_gemm path
 _wgroup = None
 
 
@@ -172,7 +172,7 @@ def flush_wgrads() -> None:
         n = len(part)
         arr = (GemmArgs * n)(*[t[0] for t in part])
         splits = (C.c_int32 * n)()
-        if n < 2 or L.dl_gemm_group_plan(arr, n, splits) != 0:
+        if n < group_wgrad_min_n or L.dl_gemm_group_plan(arr, n, splits) != 0:
             for a, out, x_colsum, x, _w in part:             # not a group the library takes: one by one, as before
                 _gemm_launch(a, out, x, False, x_colsum)
             continue

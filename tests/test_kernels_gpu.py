@@ -441,7 +441,8 @@ def test_grouped_weight_gradients_match_single_launches():
     dt = torch.bfloat16
     probs = [(1024, 256, 8192), (256, 1024, 8192), (256, 256, 8192), (256, 512, 8192), (768, 256, 8192), (512, 2048, 8192),
              (1000, 648, 4160), (8, 1024, 8192), (128, 128, 16384), (136, 264, 8192), (2048, 512, 4096), (1536, 512, 8192)]
-    probs = probs + probs[:6]                                   # 18 products: two group launches
+    probs = probs + probs[:6]                                   # 18 products: two group launches (128-row tiles)
+    probs += [(2048, 512, 16384), (512, 2048, 16384), (512, 512, 16384), (1536, 512, 16384), (520, 1032, 16448)]   # third launch: 256-row tiles
     data = [((torch.randn(K, M, generator=g) * 0.5).to(dt).cuda(), (torch.randn(K, N, generator=g) * 0.5).to(dt).cuda()) for M, N, K in probs]
     big = ((torch.randn(32768, 256, generator=g) * 0.5).to(dt).cuda(), (torch.randn(32768, 512, generator=g) * 0.5).to(dt).cuda())
 
@@ -453,6 +454,8 @@ def test_grouped_weight_gradients_match_single_launches():
             dw = ops.gemm(a, b, M=M, N=N, K=K, x_kslow=True, w_kslow=True, ldx=M, ldw=N, out_dtype=torch.float32, split_k=0, x_colsum=db,
                           out=None if whole is None else whole[8:8 + M])
             outs += [dw] + ([db] if db is not None else [])
+            if i == 17:
+                ops.flush_wgrads()                               # (no-op outside a deferring block) the 18 products above leave now
         outs.append(ops.gemm(big[0], big[1], M=256, N=512, K=32768, x_kslow=True, w_kslow=True, ldx=256, ldw=512, out_dtype=torch.float32, split_k=0))
         return outs
 
@@ -460,10 +463,10 @@ def test_grouped_weight_gradients_match_single_launches():
     try:
         ops.group_wgrad_max_k, ops.group_wgrad_small_mn = 0, 0
         ref = [t.clone() for t in run()]
-        ops.group_wgrad_max_k = 16384
+        ops.group_wgrad_max_k = 20000
         with ops.deferred_reductions():
             got = run()
-            assert len(ops._wgroup) == len(probs) and len(ops._pending) == 1     # queued; only the K = 32768 product has been launched (its reduction waits)
+            assert len(ops._wgroup) == 5 and len(ops._pending) == 18 + 1       # the last five are queued; the K = 32768 product went out alone (its reduction waits)
         torch.cuda.synchronize()
         # run-to-run: the grouped launch is deterministic
         with ops.deferred_reductions():
