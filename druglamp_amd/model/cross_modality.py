@@ -72,11 +72,26 @@ class CMLabels:
     them)."""
 
     def __init__(self, rows: int, device):
-        self.rows = rows
-        self.idx = torch.zeros(2, rows, dtype=torch.int64, device=device)
-        self.mask = torch.zeros(2, rows, 1, dtype=torch.float32, device=device)
-        self.n = torch.ones(2, dtype=torch.float32, device=device)
-        self.gt = torch.full((rows, rows), -1, dtype=torch.int8, device=device)
+        self.rows = B = rows
+        # one device buffer, four views: a batch's labels arrive with ONE host-to-device copy from pinned memory that
+        # nothing waits for (a pageable copy would make the host wait for every launch queued before it)
+        o_mask, o_n, o_gt = 16 * B, 16 * B + 8 * B, 16 * B + 8 * B + 16
+        self.nbytes = o_gt + B * B
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.idx = self.buf[:o_mask].view(torch.int64).view(2, B)
+        self.mask = self.buf[o_mask:o_n].view(torch.float32).view(2, B, 1)
+        self.n = self.buf[o_n:o_n + 8].view(torch.float32)
+        self.gt = self.buf[o_gt:].view(torch.int8).view(B, B)
+        self._off = (o_mask, o_n, o_gt)
+        self.n.fill_(1.0)
+        self.gt.fill_(-1)
+        # pinned staging ring (allocated once: a pinned allocation per step costs milliseconds and synchronises the device);
+        # a slot is rewritten only after the copy that read it has run (event per slot)
+        on_gpu = torch.device(device).type == "cuda"
+        self._pins = [torch.zeros(self.nbytes, dtype=torch.uint8).pin_memory() if on_gpu else torch.zeros(self.nbytes, dtype=torch.uint8)
+                      for _ in range(4)]
+        self._events = [None] * len(self._pins)
+        self._slot = 0
 
     def fill(self, meta, use_cm=True):
         pidx, didx, gt = label_matrix(meta, use_cm)
@@ -84,16 +99,25 @@ class CMLabels:
         if len(meta) != B:
             raise ValueError("CMLabels: %d meta rows for a %d-row label block" % (len(meta), B))
         n_p, n_d = len(pidx), len(didx)
-        idx = np.zeros((2, B), dtype=np.int64)
+        o_mask, o_n, o_gt = self._off
+        k = self._slot
+        self._slot = (k + 1) % len(self._pins)
+        if self._events[k] is not None:
+            self._events[k].synchronize()
+        host = self._pins[k].numpy()
+        host[:] = 0
+        idx = host[:o_mask].view(np.int64).reshape(2, B)
         idx[0, :n_p], idx[1, :n_d] = pidx, didx
-        mask = np.zeros((2, B, 1), dtype=np.float32)
+        mask = host[o_mask:o_n].view(np.float32).reshape(2, B)
         mask[0, :n_p], mask[1, :n_d] = 1.0, 1.0
-        g = np.full((B, B), -1, dtype=np.int8)
+        host[o_n:o_n + 8].view(np.float32)[:] = (float(n_p), float(n_d))
+        g = host[o_gt:].view(np.int8).reshape(B, B)
+        g[:] = -1
         g[:n_p, :n_d] = gt
-        self.idx.copy_(torch.from_numpy(idx))
-        self.mask.copy_(torch.from_numpy(mask))
-        self.n.copy_(torch.tensor([float(n_p), float(n_d)]))
-        self.gt.copy_(torch.from_numpy(g))
+        self.buf.copy_(self._pins[k], non_blocking=True)
+        if self.buf.is_cuda:
+            self._events[k] = torch.cuda.Event()
+            self._events[k].record()
         return self
 
 
@@ -131,6 +155,7 @@ class CrossModality(nn.Module):
         self.to_drug_latent = nn.Linear(hidden_size * 2, hidden_size * 2, bias=False)
         self.m_sch_loss_fn = MarginSchedule(m_ori=max_margin, n_re=n_re)
         self.global_batch = bool(kwargs.get("global_batch", False))
+        self._label_blocks = {}
 
     def step(self):
         self.m_sch_loss_fn.step()
@@ -159,6 +184,12 @@ class CrossModality(nn.Module):
             meta = dist_ops.all_gather_meta(meta)
             labels = None
         if labels is None:
-            labels = CMLabels(len(meta), means[0].device).fill(meta, self.use_cm)
+            # one label block per batch size, refilled per step (stream order keeps the previous step's backward ahead of
+            # the refill; a captured step brings its own block)
+            key = (len(meta), means[0].device)
+            labels = self._label_blocks.get(key)
+            if labels is None:
+                labels = self._label_blocks[key] = CMLabels(*key)
+            labels.fill(meta, self.use_cm)
         p_lats, d_lats = self.latents_from_means(*means, labels)
         return Fn.TripletSigCosFn.apply(p_lats.float(), d_lats.float(), labels.gt, float(self.m_sch_loss_fn.margin))

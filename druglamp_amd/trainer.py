@@ -297,7 +297,7 @@ class GraphedStep:
         ts += [b for b in tr.model.buffers()] + [p_ for p_ in tr.model.parameters()]
         ts += [t for b in self.static for t in (b if isinstance(b, (tuple, list)) else (b,))]
         if self.labels is not None:
-            ts += [self.labels.idx, self.labels.mask, self.labels.n, self.labels.gt]
+            ts += [self.labels.buf]
         ts += list(ops._seed_offsets.values()) + list(ops._tickets.values())
         ts += [e.image for e in Fn._lowp_cache.values() if torch.is_tensor(e.image)]
         for tab in list(Fn._lowp_tables.values()) + [t for t in Fn._lowp_retired if isinstance(t, tuple) and len(t) == 4]:

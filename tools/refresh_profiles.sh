@@ -10,6 +10,15 @@ for b in 128 64 32; do python3 "$ROOT/bench.py" --batch $b --steps 100 --no-cpu-
 # step kinds of configs C3 / C4 (SSL + CM heads active: epoch 5 of DrugLAMP2C2P; SSL epoch of DrugLAMP)
 python3 "$ROOT/bench.py" --model DrugLAMP2C2P --epoch 5 --steps 50 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_line_2c2p_epoch5.json"
 python3 "$ROOT/bench.py" --model DrugLAMP --epoch 5 --steps 50 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_line_druglamp_epoch5.json"
+# CM steps as hipGraph replays (DrugLAMP2C2P after RS.INIT_EPOCH; epoch 10 is an SSL epoch as well), SSL-epoch step of DrugLAMP, batch 32
+python3 "$ROOT/bench.py" --model DrugLAMP2C2P --epoch 6 --batch 32 --steps 100 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_line_2c2p_epoch6_cm_batch32.json"
+python3 "$ROOT/bench.py" --model DrugLAMP2C2P --epoch 10 --batch 32 --steps 100 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_line_2c2p_epoch10_ssl_cm_batch32.json"
+python3 "$ROOT/bench.py" --model DrugLAMP --epoch 5 --batch 32 --steps 100 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_line_druglamp_epoch5_ssl_batch32.json"
+# kernel trace of replayed batch-32 steps (launch count per step = launches / steps in the window)
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace32" -o t -- python3 "$ROOT/bench.py" --batch 32 --steps 100 --no-cpu-baseline --no-kernel-timing > "$OUT/b32_under_rocprof.log" 2>&1
+T32=$(find "$OUT/trace32" -name '*kernel_trace.csv' | head -1)
+python3 "$ROOT/tools/prof_summary.py" "$T32" 0.25 > "$OUT/batch32_graph_kernel_summary.txt" 2>&1
+rm -rf "$OUT/trace32"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 > "$OUT/under_rocprof.log" 2>&1
 grep '"metric"' "$OUT/under_rocprof.log" | tail -1 > "$OUT/bench_line_under_rocprof.json"
 T=$(find "$OUT/trace" -name '*kernel_trace.csv' | head -1); S=$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)
