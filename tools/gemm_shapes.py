@@ -32,9 +32,13 @@ orig = ops.gemm
 
 def timed(x, w, **kw):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    queued = len(ops._wgroup) if ops._wgroup is not None else -1
     a.record()
     out = orig(x, w, **kw)
     b.record()
+    if queued >= 0 and len(ops._wgroup) > queued:        # left to the block's grouped launch (dl_gemm_group): timed there
+        recs.append(((kw["M"], kw["N"], kw["K"], "TT", "grp", str(out.dtype)[6:]), None, None))
+        return out
     epi = ("b" if kw.get("bias") is not None else "") + ("r" if kw.get("residual") is not None else "") + \
           ("g" if kw.get("act") else "") + ("p" if kw.get("pre_out") is not None else "") + \
           ("G" if kw.get("dact_pre") is not None else "") + ("d" if kw.get("dropout_p", 0) > 0 else "") + \
@@ -56,6 +60,24 @@ def wrap_attn(name):
     setattr(ops, name, g)
 wrap_attn("attn_fwd"); wrap_attn("attn_bwd")
 ops.gemm = timed
+orig_flush = ops.flush_wgrads
+
+
+def timed_flush():
+    if not ops._wgroup:
+        return orig_flush()
+    members = [(t[0].M, t[0].N, t[0].K) for t in ops._wgroup]
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    orig_flush()
+    b.record()
+    # one row per grouped launch: M column = number of members, N = their outputs / 1024, K = rows
+    recs.append(((len(members), sum(m * n for m, n, _ in members) // 1024, members[0][2], "TT", "GROUP", "float32"), a, b))
+    grecs.append((members, a, b))
+
+
+grecs = []
+ops.flush_wgrads = timed_flush
 import druglamp_amd.functional as Fn  # noqa: E402
 if hasattr(Fn, "ops"):
     Fn.arecs = []
@@ -74,14 +96,18 @@ trainer.training_step(batch, meta=meta, cur_epoch=1)
 torch.cuda.synchronize()
 agg = defaultdict(lambda: [0.0, 0])
 for key, a, b in recs:
-    agg[key][0] += a.elapsed_time(b)
+    agg[key][0] += a.elapsed_time(b) if a is not None else 0.0
     agg[key][1] += 1
 tot = sum(v[0] for v in agg.values())
-print("total gemm %.2f ms in %d calls" % (tot, len(recs)))
+print("total gemm %.2f ms in %d calls (%d of them members of %d grouped launches: rows 'grp' carry no time, rows 'GROUP' = one launch each, "
+      "M = members, N = outputs / 1024)" % (tot, len(recs) - len(grecs), sum(len(g[0]) for g in grecs), len(grecs)))
 print("%9s %6s %8s %3s %-6s %-8s %4s %9s %8s %7s" % ("M", "N", "K", "lay", "epi", "out", "n", "us/call", "TF/s", "ms"))
 for key, (ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     M, N, K, lay, epi, od = key
-    tf = 2.0 * M * N * K * n / (ms * 1e-3) / 1e12
+    if epi == "GROUP":
+        tf = 2.0 * N * 1024 * K * n / (ms * 1e-3) / 1e12
+    else:
+        tf = 2.0 * M * N * K * n / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     print("%9d %6d %8d %3s %-6s %-8s %4d %9.1f %8.1f %7.3f" % (M, N, K, lay, epi, od, n, ms / n * 1e3, tf, ms))
 
 agg = defaultdict(lambda: [0.0, 0])
