@@ -480,7 +480,11 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const dl_wprep_item* _
       if (vec && c + 4 <= it.cols) v = *reinterpret_cast<const f32x4*>(it.src + (int64_t)r * it.cols + c);
       else for (int e = 0; e < 4; ++e) if (c + e < it.cols) v[e] = it.src[(int64_t)r * it.cols + c + e];
     }
-    if (!it.transpose) {
+    if (it.transpose == 2) {                        // strided scatter (conv layouts: tiny tensors, scalar stores)
+      if (r < it.rows)
+        for (int e = 0; e < 4; ++e)
+          if (c + e < it.cols) dst[(int64_t)it.row0 + (int64_t)r * it.ld + (int64_t)(c + e) * it.cs] = from_f32<TD>(v[e]);
+    } else if (!it.transpose) {
       if (r < it.rows) {
         TD* d = dst + (int64_t)(it.row0 + r) * it.ld + c;
         if (c + 4 <= it.cols && (it.ld & 3) == 0 && (((uintptr_t)dst) & 15) == 0) store4<TD>(d, v);
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const dl_wprep_item* _
       for (int e = 0; e < 4; ++e) tile[tr + 16 * i][tc4 + e] = v[e];
     }
   }
-  if (!it.transpose) return;
+  if (it.transpose != 1) return;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

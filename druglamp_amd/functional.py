@@ -61,17 +61,26 @@ def planned_image_count() -> int:
 
 
 class _LowpEntry:
-    __slots__ = ("refs", "transpose", "dtype", "image", "versions", "epoch", "planned", "pad")
+    __slots__ = ("refs", "transpose", "dtype", "image", "versions", "epoch", "planned", "pad", "conv")
 
-    def __init__(self, params, transpose, dtype, image, planned, pad=None):
+    def __init__(self, params, transpose, dtype, image, planned, pad=None, conv=None):
         self.refs = tuple(weakref.ref(p) for p in params)
         self.transpose, self.dtype, self.image, self.planned, self.pad = transpose, dtype, image, planned, pad
+        self.conv = conv            # None, "f" or "b": GEMM layout of a Conv1d weight (see _conv_weight)
         self.versions = tuple(p._version for p in params)
         self.epoch = _param_epoch
 
     def params(self):
         ps = tuple(r() for r in self.refs)
         return None if any(p is None for p in ps) else ps
+
+
+def _build_conv_image(w, dtype, backward):
+    with torch.no_grad():
+        co, ci, k = w.shape
+        g = w.detach().flip(2).permute(1, 2, 0).reshape(ci, k * co) if backward else w.detach().permute(0, 2, 1).reshape(co, k * ci)
+        g = g.contiguous()
+        return ops.cast(g, dtype) if g.dtype != dtype else g
 
 
 def _build_image(params, dtype, transpose, pad=None):
@@ -101,23 +110,35 @@ def _refresh_all_images() -> None:
             del _lowp_cache[key]
             continue
         if not e.planned:
-            e.image = _build_image(ps, e.dtype, e.transpose, e.pad)
+            e.image = _build_conv_image(ps[0], e.dtype, e.conv == "b") if e.conv else _build_image(ps, e.dtype, e.transpose, e.pad)
             e.versions, e.epoch = tuple(p._version for p in ps), _param_epoch
             continue
         groups.setdefault((ps[0].device, e.dtype), []).append((e, ps))
     item_t = np.dtype([("src", "<u8"), ("dst", "<u8"), ("ld", "<i8"), ("rows", "<i4"), ("cols", "<i4"),
-                       ("row0", "<i4"), ("transpose", "<i4")])
+                       ("row0", "<i4"), ("transpose", "<i4"), ("cs", "<i8")])
     for gkey, lst in groups.items():
         tab = _lowp_tables.get(gkey)
         sig = tuple(id(e) for e, _ in lst) + tuple(p.data_ptr() for _, ps in lst for p in ps)
         if tab is None or tab[0] != sig:
             items, bmap = [], []
             for e, ps in lst:
+                if e.conv:
+                    # Conv1d weight [co][ci][k]: one strided item per output channel o, source [ci][k] at w[o]
+                    co, ci, k = ps[0].shape
+                    for o in range(co):
+                        src = ps[0].data_ptr() + o * ci * k * 4
+                        if e.conv == "f":       # Wg[o][j*ci + c] = w[o][c][j]
+                            items.append((src, e.image.data_ptr(), 1, ci, k, o * k * ci, 2, ci))
+                        else:                   # Wd[c][(k-1-j)*co + o] = w[o][c][j]
+                            items.append((src, e.image.data_ptr(), k * co, ci, k, (k - 1) * co + o, 2, -co))
+                        ntile = ((ci + 63) // 64) * ((k + 63) // 64)
+                        bmap.extend((len(items) - 1, t) for t in range(ntile))
+                    continue
                 row0 = 0
                 for p_ in ps:
                     r, c = p_.shape if p_.dim() == 2 else (1, p_.shape[0])     # a 1-D parameter is one row of the image
                     ld = e.image.shape[1] if e.image.dim() == 2 else c       # [rows][cols] image, or [cols][rows] when transposed
-                    items.append((p_.data_ptr(), e.image.data_ptr(), ld, r, c, row0, 1 if e.transpose else 0))
+                    items.append((p_.data_ptr(), e.image.data_ptr(), ld, r, c, row0, 1 if e.transpose else 0, 0))
                     ntile = ((r + 63) // 64) * ((c + 63) // 64)
                     bmap.extend((len(items) - 1, t) for t in range(ntile))
                     row0 += r
@@ -735,25 +756,20 @@ _CNN_HALO = 4          # zero rows kept on each side of every sample (max 'same'
 def _conv_weight(w: torch.Tensor, dtype: torch.dtype, backward: bool) -> torch.Tensor:
     """Conv1d weight [co][ci][k] as the GEMM operand of the overlapping-row formulation.
     forward : Wg[co][j*ci + c]  = w[co][c][j]
-    backward: Wd[ci][j'*co + o] = w[o][ci][k-1-j']   (data gradient = correlation with the flipped kernel)"""
+    backward: Wd[ci][j'*co + o] = w[o][ci][k-1-j']   (data gradient = correlation with the flipped kernel)
+    Round 3: the two layouts are weight IMAGES like every other compute-dtype copy (fixed address, refreshed by the one
+    dl_weight_prep launch through strided items) — torch's flip / permute / contiguous / cast per layer and direction
+    were ~20 launches per step (and per graph replay)."""
     key = ((id(w), "convb" if backward else "convf"), dtype)
-    ver = (_param_epoch, w._version)
-    hit = _derived_cache.get(key)
-    if hit is not None and hit[0] == ver and hit[2][0]() is w:
-        return hit[1]
-    with torch.no_grad():
-        co, ci, k = w.shape
-        if backward:
-            g = w.detach().flip(2).permute(1, 2, 0).reshape(ci, k * co)
-        else:
-            g = w.detach().permute(0, 2, 1).reshape(co, k * ci)
-        g = g.contiguous()
-        if g.dtype != dtype:
-            g = ops.cast(g, dtype)
-    if len(_derived_cache) > 1024:
-        _derived_cache.clear()
-    _derived_cache[key] = (ver, g, (weakref.ref(w),))
-    return g
+    e = _lowp_cache.get(key)
+    if e is not None and e.refs[0]() is w:
+        if e.epoch != _param_epoch or e.versions != (w._version,):
+            _refresh_all_images()
+        return e.image
+    planned = w.dim() == 3 and w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda
+    image = _build_conv_image(w, dtype, backward)
+    _lowp_cache[key] = _LowpEntry((w,), False, dtype, image, planned, None, "b" if backward else "f")
+    return image
 
 
 class ProteinCNNFn(torch.autograd.Function):

@@ -352,14 +352,18 @@ int dl_cnn_sitepool_bwd(const void* dpooled, void* dz, int64_t B, int64_t L, int
  * parameters after an optimiser step — the per-parameter `.to(dtype)` / `.t().contiguous()` / `cat(q,k,v)` copies
  * a torch implementation of the reference's modules makes implicitly, batched.  items / block_map are DEVICE
  * arrays built once by the host: block_map[2b] = item index, block_map[2b+1] = 64x64 tile index in that item.
- * plain item : dst[(row0 + r) * ld + c] = src[r][c];   transposed item : dst[c * ld + row0 + r] = src[r][c]. */
+ * plain item (transpose = 0): dst[(row0 + r) * ld + c] = src[r][c];   transposed item (1): dst[c * ld + row0 + r] = src[r][c];
+ * strided item (2, round 3): dst[row0 + r * ld + c * cs] = src[r][c] with any (also negative) column stride — the GEMM
+ * layouts of a Conv1d weight [co][ci][k] (one item per output channel: forward Wg[co][j*ci + c] = w[co][c][j], data
+ * gradient Wd[ci][j'*co + o] = w[o][ci][k-1-j']), which torch derived with flip / permute / contiguous / cast launches. */
 typedef struct dl_wprep_item {
   const float* src;        /* fp32 master parameter, [rows][cols] contiguous */
   void* dst;               /* image base (out_dtype) */
-  int64_t ld;              /* image leading dimension in elements */
+  int64_t ld;              /* image leading dimension in elements (strided items: row stride) */
   int32_t rows, cols;
-  int32_t row0;            /* offset of this parameter inside a concatenated image */
-  int32_t transpose;
+  int32_t row0;            /* offset of this parameter inside a concatenated image (strided items: element offset) */
+  int32_t transpose;       /* 0 plain, 1 transposed, 2 strided */
+  int64_t cs;              /* strided items: column stride in elements */
 } dl_wprep_item;
 int dl_weight_prep(const dl_wprep_item* items_dev, const int32_t* block_map_dev, int32_t n_blocks,
                    int32_t out_dtype, dl_stream s);

@@ -520,3 +520,26 @@ def test_gemm_pair_is_bitwise_equal_to_two_calls(M, N, K):
             if outs["pair"][1] is not None:
                 assert torch.equal(outs["pair"][1][i], outs["two"][1][i]), (name, i)
     assert not torch.equal(outs["pair"][0][0], outs["pair"][0][1])
+
+
+@pytest.mark.gpu
+def test_conv_weight_images_follow_the_masters_through_weight_prep():
+    """Round 3: the two GEMM layouts of a Conv1d weight (forward Wg[co][j*ci + c] = w[co][c][j]; data gradient
+    Wd[ci][j'*co + o] = w[o][ci][k-1-j']) are weight images refreshed by dl_weight_prep's strided items.  After the master
+    changes through a raw pointer (what the fused AdamW does) + bump_param_epoch, the SAME image tensors hold the new
+    layouts, bit-equal to torch's permute / flip of the bf16-rounded master."""
+    from druglamp_amd import functional as Fn
+    g = torch.Generator().manual_seed(3)
+    for (co, ci, k) in [(128, 128, 3), (128, 128, 6), (128, 128, 9), (72, 40, 5)]:
+        w = torch.nn.Parameter(torch.randn(co, ci, k, generator=g).cuda())
+        for dt in (torch.bfloat16, torch.float32):
+            f0, b0 = Fn._conv_weight(w, dt, False), Fn._conv_weight(w, dt, True)
+            for rep in range(2):
+                ref_f = w.detach().permute(0, 2, 1).reshape(co, k * ci).to(dt)
+                ref_b = w.detach().flip(2).permute(1, 2, 0).reshape(ci, k * co).to(dt)
+                f1, b1 = Fn._conv_weight(w, dt, False), Fn._conv_weight(w, dt, True)
+                assert f1.data_ptr() == f0.data_ptr() and b1.data_ptr() == b0.data_ptr()      # fixed addresses (graph replays)
+                assert torch.equal(f1, ref_f) and torch.equal(b1, ref_b), (co, ci, k, dt, rep)
+                with torch.no_grad():
+                    w.data.view(-1).mul_(1.5).add_(0.25)          # a raw update of the master
+                Fn.bump_param_epoch()
