@@ -157,6 +157,11 @@ class CrossModality(nn.Module):
         self.global_batch = bool(kwargs.get("global_batch", False))
         self._label_blocks = {}
 
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_label_blocks"] = {}            # device / pinned staging state (CUDA events): rebuilt on demand, never copied or pickled
+        return d
+
     def step(self):
         self.m_sch_loss_fn.step()
 
