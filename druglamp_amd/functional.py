@@ -15,6 +15,7 @@ Reference semantics restated here (see oracle/druglamp_oracle.py for the plain-t
 from __future__ import annotations
 
 import functools
+import contextlib
 import os
 import math
 import weakref
@@ -28,6 +29,11 @@ from . import ops
 # compute-dtype copies of fp32 master parameters, cached per optimiser epoch
 # ------------------------------------------------------------------------------------------------
 _param_epoch = 0
+def _maybe_deferring():
+    """ops.deferred_reductions() unless the A/B switch turned it off."""
+    return contextlib.nullcontext() if os.environ.get("DL_DEFER_REDUCTIONS", "1") == "0" else ops.deferred_reductions()
+
+
 def _deferring(fn):
     """Backward passes whose split-K / LayerNorm second-stage reductions leave in one dl_reduce_batch launch at the end
     (ops.deferred_reductions): legal because these passes never read the gradients they produce, they only return them."""
@@ -839,29 +845,32 @@ class ProteinCNNFn(torch.autograd.Function):
             dz[:, _CNN_HALO:_CNN_HALO + Lv] = dout
             dz = dz.reshape(R, C)
         grads = [None] * 18
-        for i in (2, 1, 0):
-            xin, y, mean, rstd, gamma = sv[i * 5:(i + 1) * 5]
-            w = ctx.weights[i]
-            k = w.shape[2]
-            pl = (k - 1) // 2
-            pr = k - 1 - pl
-            Mg = R - (k - 1)
-            sums = ops.bn_bwd_reduce(dz, y, mean, rstd, LP, _CNN_HALO, Lv)
-            dpre = ops.bn_bwd_apply(dz, y, mean, rstd, gamma, sums, 1.0 / n, True, LP, _CNN_HALO, Lv)
-            # rows outside [pl, pl + Mg) are halo rows (zero in dpre), so the bias gradient can ride along
-            dWg, dbias = _wgrad(dpre[pl:pl + Mg], xin, C, k * C, Mg, C, C)
-            grads[i * 6 + 0] = dWg.reshape(C, k, C).permute(0, 2, 1).contiguous()
-            grads[i * 6 + 1] = dbias
-            grads[i * 6 + 2] = sums[C:]
-            grads[i * 6 + 3] = sums[:C]
-            if i > 0 or ctx.needs_input_grad[0]:
-                Wd = _conv_weight(w, cdt, True)
-                dprev = torch.empty((R, C), dtype=cdt, device=dout.device)
-                ops.gemm(dpre, Wd, M=Mg, N=C, K=k * C, ldx=C, out=dprev[pr:pr + Mg])
-                if i == 0 and raw_dx:                       # rows the GEMM does not write must be finite for the consumer
-                    dprev[:pr].zero_()
-                    dprev[pr + Mg:].zero_()
-                dz = dprev
+        dWgs = {}
+        with _maybe_deferring():            # the three weight gradients leave as one grouped launch (nothing below reads them
+          for i in (2, 1, 0):               #  before the block ends; their re-layout follows the block)
+              xin, y, mean, rstd, gamma = sv[i * 5:(i + 1) * 5]
+              w = ctx.weights[i]
+              k = w.shape[2]
+              pl = (k - 1) // 2
+              pr = k - 1 - pl
+              Mg = R - (k - 1)
+              sums = ops.bn_bwd_reduce(dz, y, mean, rstd, LP, _CNN_HALO, Lv)
+              dpre = ops.bn_bwd_apply(dz, y, mean, rstd, gamma, sums, 1.0 / n, True, LP, _CNN_HALO, Lv)
+              # rows outside [pl, pl + Mg) are halo rows (zero in dpre), so the bias gradient can ride along
+              dWgs[i], dbias = _wgrad(dpre[pl:pl + Mg], xin, C, k * C, Mg, C, C)
+              grads[i * 6 + 1] = dbias
+              grads[i * 6 + 2] = sums[C:]
+              grads[i * 6 + 3] = sums[:C]
+              if i > 0 or ctx.needs_input_grad[0]:
+                  Wd = _conv_weight(w, cdt, True)
+                  dprev = torch.empty((R, C), dtype=cdt, device=dout.device)
+                  ops.gemm(dpre, Wd, M=Mg, N=C, K=k * C, ldx=C, out=dprev[pr:pr + Mg])
+                  if i == 0 and raw_dx:                       # rows the GEMM does not write must be finite for the consumer
+                      dprev[:pr].zero_()
+                      dprev[pr + Mg:].zero_()
+                  dz = dprev
+        for i, dWg in dWgs.items():
+            grads[i * 6 + 0] = dWg.reshape(C, ctx.weights[i].shape[2], C).permute(0, 2, 1).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
             if raw_dx:
