@@ -9,7 +9,7 @@
 #include <stdint.h>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(512) void store_tiles(char* __restrict__ out, int tiles, int tiles_per_row, int64_t pitch, int busy, int do_store,
+__global__ __launch_bounds__(512) void store_tiles(char* __restrict__ out, int tiles, int tiles_per_row, int64_t pitch, int busy, int do_store, int wait_ack,
                                                    float* __restrict__ sink) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float f = (float)tid;
@@ -27,6 +27,7 @@ if (do_store)
       const int row = wm * 128 + it * 8 + (lane >> 3);
       *reinterpret_cast<u32x4*>(out + (m0 + row) * pitch + n0b + wn * 128 + (lane & 7) * 16) = v;
     }
+    if (wait_ack) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // what the GEMM's next tile does before its first k-step
   }
   if (f == 12345.f) sink[0] = f;
 }
@@ -38,20 +39,21 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int total_tiles = (int)(M / 256) * 8;           // 2048 tiles of 128 KB = 268 MB
   printf("%6s %6s %8s %10s %10s %10s %12s\n", "G", "tiles", "busy", "us no st", "us", "TB/s", "GB/s per WG");
-  for (int busy : {0, 2000, 8000}) {
-    for (int G : {16, 32, 64, 128, 256, 512}) {
+  for (int wait_ack : {0, 1})
+  for (int busy : {0, 500}) {
+    for (int G : {16, 64, 256}) {
       const int tiles = total_tiles / G;
       float best[2] = {1e9f, 1e9f};
       for (int st = 0; st < 2; ++st)
         for (int rep = 0; rep < 5; ++rep) {
           hipEventRecord(e0);
-          hipLaunchKernelGGL(store_tiles, dim3(G), dim3(512), 0, 0, out, tiles, 8, pitch, busy, st, sink);
+          hipLaunchKernelGGL(store_tiles, dim3(G), dim3(512), 0, 0, out, tiles, 8, pitch, busy, st, wait_ack, sink);
           hipEventRecord(e1); hipEventSynchronize(e1);
           float ms; hipEventElapsedTime(&ms, e0, e1);
           if (ms < best[st]) best[st] = ms;
         }
       const double bytes = (double)G * tiles * 131072.0;
-      printf("%6d %6d %8d %10.1f %10.1f %10.2f %12.1f\n", G, tiles, busy, best[0] * 1e3, best[1] * 1e3, bytes / best[1] / 1e9, bytes / best[1] / 1e6 / G);
+      printf("ack %d %6d %6d %8d %10.1f %10.1f %10.2f %12.1f  exposed %.2f us/tile\n", wait_ack, G, tiles, busy, best[0] * 1e3, best[1] * 1e3, bytes / best[1] / 1e9, bytes / best[1] / 1e6 / G, (best[1] - best[0]) * 1e3 / tiles);
     }
   }
   return 0;
