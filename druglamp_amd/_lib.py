@@ -13,7 +13,8 @@ import torch  # noqa: F401  (must be imported BEFORE the dlopen below: the libra
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DL_USE_STUDY_LIB=1 (tools/ only) loads the -DDL_STUDY build, the only one that reads study switches from the environment
-LIB_PATH = os.path.join(_HERE, "lib", "libdruglamp_hip_study.so" if os.environ.get("DL_USE_STUDY_LIB") == "1"
+_study = os.environ.get("DL_USE_STUDY_LIB", "")
+LIB_PATH = os.path.join(_HERE, "lib", "libdruglamp_hip_study.so" if _study == "1" else _study if _study.endswith(".so")   # (a named variant build: same-box A/B of compile-time choices, tools only)
                         else "libdruglamp_hip.so")
 
 DL_F32, DL_BF16 = 0, 1

@@ -63,10 +63,14 @@ def _compile(src, force, objdir=OBJDIR, extra=()):
     return obj
 
 
-def build(force: bool = False, verbose: bool = True, study: bool = False) -> str:
-    objdir = OBJDIR + ("_study" if study else "")
+def build(force: bool = False, verbose: bool = True, study: bool = False, variant: str = "", defines=()) -> str:
+    """variant (tools only): a product-flavoured library under another name built with extra -D flags, loaded with
+    DL_USE_STUDY_LIB=libdruglamp_hip_<variant>.so — same-box A/B of compile-time choices."""
+    objdir = OBJDIR + ("_study" if study else "") + ("_" + variant if variant else "")
     lib = LIB.replace(".so", "_study.so") if study else LIB
-    extra = ("-DDL_STUDY",) if study else ()
+    if variant:
+        lib = LIB.replace(".so", "_%s.so" % variant)
+    extra = (("-DDL_STUDY",) if study else ()) + tuple(defines)
     os.makedirs(objdir, exist_ok=True)
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
@@ -88,6 +92,9 @@ def _link(LIB, objs, force, verbose):
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:              # python -m druglamp_amd.build --variant nt7 -DDL_NT_MASK=7
+        build(force="-f" in sys.argv, variant=sys.argv[sys.argv.index("--variant") + 1], defines=[a for a in sys.argv if a.startswith("-D")])
+        sys.exit(0)
     build(force="-f" in sys.argv)
     if "--study" in sys.argv:
         build(force="-f" in sys.argv, study=True)

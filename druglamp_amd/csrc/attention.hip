@@ -211,7 +211,7 @@ __global__ __launch_bounds__(ATT_THREADS, OCC) void attn_fwd_kernel(const AttnP 
     const float inv = 1.0f / l;
     if (q < p.Lq) {
 #pragma unroll
-      for (int d = 0; d < NDT; ++d) store4<T>(Ob + (int64_t)q * p.o_rs + d * 16 + 4 * g, o[d][qt] * inv);
+      for (int d = 0; d < NDT; ++d) store4_fam<4, T>(Ob + (int64_t)q * p.o_rs + d * 16 + 4 * g, o[d][qt] * inv);
       if (p.LSE && g == 0)
         p.LSE[(((int64_t)seg * p.P + pr) * p.H + h) * p.Lq + q] = m_run[qt] * p.scale + logf(l);
     }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_res_kernel(const AttnP p)
       const float inv = 1.0f / l;
       if (q < p.Lq) {
 #pragma unroll
-        for (int d = 0; d < NDT; ++d) store4<T>(Ob + (int64_t)q * p.o_rs + d * 16 + 4 * g, o[d][qt] * inv);
+        for (int d = 0; d < NDT; ++d) store4_fam<4, T>(Ob + (int64_t)q * p.o_rs + d * 16 + 4 * g, o[d][qt] * inv);
         if (p.LSE && g == 0)
           p.LSE[(((int64_t)seg * p.P + pr) * p.H + h) * p.Lq + q] = m_run[qt] * p.scale + logf(l);
       }
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(ATT_THREADS, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k
     if (q < p.Lq) {
 #pragma unroll
       for (int d = 0; d < NDT; ++d)
-        store4<T>(dQb + (int64_t)q * p.dq_rs + d * 16 + 4 * g, dq[d][qt] * p.scale);
+        store4_fam<4, T>(dQb + (int64_t)q * p.dq_rs + d * 16 + 4 * g, dq[d][qt] * p.scale);
     }
   }
 }
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_ring_kernel(const 
     if (q < p.Lq) {
 #pragma unroll
       for (int d = 0; d < NDT; ++d)
-        store4<T>(dQb + (int64_t)q * p.dq_rs + d * 16 + 4 * g, dq[d][qt] * p.scale);
+        store4_fam<4, T>(dQb + (int64_t)q * p.dq_rs + d * 16 + 4 * g, dq[d][qt] * p.scale);
     }
   }
 }
@@ -838,8 +838,8 @@ __global__ __launch_bounds__(ATT_THREADS, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_
     if (key < p.Lk) {
 #pragma unroll
       for (int d = 0; d < NDT; ++d) {
-        store4<T>(dKb + (int64_t)key * p.dk_rs + d * 16 + 4 * g, dk[d][kt] * p.scale);
-        store4<T>(dVb + (int64_t)key * p.dv_rs + d * 16 + 4 * g, dv[d][kt]);
+        store4_fam<4, T>(dKb + (int64_t)key * p.dk_rs + d * 16 + 4 * g, dk[d][kt] * p.scale);
+        store4_fam<4, T>(dVb + (int64_t)key * p.dv_rs + d * 16 + 4 * g, dv[d][kt]);
       }
     }
   }
@@ -977,8 +977,8 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void attn_bwd_dkv_ring_kernel(const
     if (key < p.Lk) {
 #pragma unroll
       for (int d = 0; d < NDT; ++d) {
-        store4<T>(dKb + (int64_t)key * p.dk_rs + d * 16 + 4 * g, dk[d][kt] * p.scale);
-        store4<T>(dVb + (int64_t)key * p.dv_rs + d * 16 + 4 * g, dv[d][kt]);
+        store4_fam<4, T>(dKb + (int64_t)key * p.dk_rs + d * 16 + 4 * g, dk[d][kt] * p.scale);
+        store4_fam<4, T>(dVb + (int64_t)key * p.dv_rs + d * 16 + 4 * g, dv[d][kt]);
       }
     }
   }

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_wide_kernel(const bf16_t* __
         for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], a[e], b[e]);
         o = pack8(f);
       }
-      *reinterpret_cast<u32x4*>(z + (int64_t)r * C + c) = o;
+      store16_fam<2>(z + (int64_t)r * C + c, o);
     }
   }
 }
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_wide_kernel(const bf16_t* __
         }
         o = pack8(d);
       }
-      *reinterpret_cast<u32x4*>(dy + (int64_t)r * C + c) = o;
+      store16_fam<2>(dy + (int64_t)r * C + c, o);
     }
   }
 }

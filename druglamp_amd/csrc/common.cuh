@@ -230,6 +230,37 @@ __device__ __forceinline__ float group4_max(float v) {
   return v;
 }
 
+// Output stores of the large tiles carry the `nt` (streaming) policy, as inline assembly: 65536x2048x512 plain 190 -> 153 us,
+// 65536x1536x512 111 -> 100, 65536x512x2048 127 -> 115 (tools/store_policy_study.py; sc1 / sc0 sc1 write-through forms are
+// slower than plain).  The store phases of the persistent grid arrive as 33 MB bursts (one 128 KB tile per CU); with the
+// default policy the lines are allocated in the XCD's 4 MB L2 and evict the operand panels the next main loops re-read.
+// (__builtin_nontemporal_store, tried in round 2, made no difference — it does not emit this policy bit for these stores.)
+__device__ __forceinline__ void store16_nt(void* dst, u32x4 v) {
+  // (s_nop: the compiler's hazard recogniser cannot see into the asm — a VALU write of the data registers directly behind a
+  //  store of more than 8 bytes needs wait states it would otherwise insert itself)
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 2" ::"v"(dst), "v"(v) : "memory");
+}
+// The same policy per kernel family where a same-box A/B of the training step says it pays (DL_NT_MASK: 1 LayerNorm, 2 BatchNorm
+// apply passes, 4 attention outputs and gradients).
+#ifndef DL_NT_MASK
+#define DL_NT_MASK 0
+#endif
+__device__ __forceinline__ void store8_nt(void* dst, u32x2 v) {
+  asm volatile("global_store_dwordx2 %0, %1, off nt\n\ts_nop 2" ::"v"(dst), "v"(v) : "memory");
+}
+template <int FAM> __device__ __forceinline__ void store16_fam(void* dst, u32x4 v) {
+  if constexpr ((DL_NT_MASK & FAM) != 0) store16_nt(dst, v);
+  else *reinterpret_cast<u32x4*>(dst) = v;
+}
+template <int FAM, typename T> __device__ __forceinline__ void store4_fam(T* p, f32x4 v) {
+  if constexpr ((DL_NT_MASK & FAM) != 0 && sizeof(T) == 2) {
+    store8_nt(p, u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])});
+  } else {
+    store4<T>(p, v);
+  }
+}
+
+
 // ---- math ---------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));

@@ -27,7 +27,8 @@ __device__ __forceinline__ void big_epilogue8(const GemmP& p, int m, int n, f32x
   if constexpr (EPI == 2) {
     T* pd = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
     u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
-    *reinterpret_cast<u32x4*>(pd) = o;
+    if (p.nt_pre) store16_nt(pd, o);
+    else *reinterpret_cast<u32x4*>(pd) = o;
     a0 = gelu4<T>(a0); a1 = gelu4<T>(a1);
   } else if constexpr (EPI == 5) {
 #pragma unroll
@@ -45,7 +46,9 @@ __device__ __forceinline__ void big_epilogue8(const GemmP& p, int m, int n, f32x
     a1 += f32x4{bf16lo(ext[2]), bf16hi(ext[2]), bf16lo(ext[3]), bf16hi(ext[3])};
   }
   u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
-  *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n) = o;
+  T* dstp = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n;
+  if (p.nt_c) store16_nt(dstp, o);
+  else *reinterpret_cast<u32x4*>(dstp) = o;
 }
 
 // own DMA of the awaited step has landed (counted: younger steps stay in flight) and own LDS reads retired

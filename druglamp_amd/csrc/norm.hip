@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(const bf16_t* __restrict_
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
-      *reinterpret_cast<u32x4*>(y + row * ldy + cl * 8) = pack8(o);
+      store16_fam<1>(y + row * ldy + cl * 8, pack8(o));
       if (cl == 0) {
         if (mean_out) mean_out[row] = mean;
         if (rstd_out) rstd_out[row] = rstd;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void ln_bwd16_kernel(const bf16_t* __restrict_
         unpack8(wr[q], rv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rs[q] * (g[e] - c1 - xv[e] * c2) + rv[e];
-        *reinterpret_cast<u32x4*>(dx + row * lddx + cl * 8) = pack8(o);
+        store16_fam<1>(dx + row * lddx + cl * 8, pack8(o));
       }
     }
   }
