@@ -230,24 +230,28 @@ __device__ __forceinline__ float group4_max(float v) {
   return v;
 }
 
-// Output stores of the large tiles carry the `nt` (streaming) policy, as inline assembly: 65536x2048x512 plain 190 -> 153 us,
-// 65536x1536x512 111 -> 100, 65536x512x2048 127 -> 115 (tools/store_policy_study.py; sc1 / sc0 sc1 write-through forms are
-// slower than plain).  The store phases of the persistent grid arrive as 33 MB bursts (one 128 KB tile per CU); with the
-// default policy the lines are allocated in the XCD's 4 MB L2 and evict the operand panels the next main loops re-read.
-// (__builtin_nontemporal_store, tried in round 2, made no difference — it does not emit this policy bit for these stores.)
-__device__ __forceinline__ void store16_nt(void* dst, u32x4 v) {
-  // (s_nop: the compiler's hazard recogniser cannot see into the asm — a VALU write of the data registers directly behind a
-  //  store of more than 8 bytes needs wait states it would otherwise insert itself)
-  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 2" ::"v"(dst), "v"(v) : "memory");
+// Output stores of the GEMM epilogues carry the `nt` (streaming) policy: 65536x2048x512 plain 189 -> 153 us, 65536x1024x256
+// 52 -> 49, 65536x512x2048 131 -> 119 (tools/epi_bench.py with DL_NT_MODE; sc1 / sc0 sc1 write-through forms are slower
+// than plain).  The store phases of the persistent grid arrive as 33 MB bursts (one 128 KB tile per CU); with the default
+// policy the lines are allocated in the XCD's 4 MB L2 and evict the operand panels the next main loops re-read.
+// mode 1 (product): the compiler's non-temporal store; study modes: 2 = inline assembly with nt (within 1-3 % of the builtin;
+// needs s_nop — the hazard recogniser cannot see into the asm and a VALU write of the data registers directly behind a
+// store of more than 8 bytes corrupts single outputs), 3 = inline assembly with the default policy (as slow as the plain
+// store: it is the policy, not the compiler's bookkeeping of the store)
+__device__ __forceinline__ void store16_nt(void* dst, u32x4 v, int mode = 1) {
+#ifdef DL_STUDY
+  if (mode == 2) { asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 2" ::"v"(dst), "v"(v) : "memory"); return; }
+  if (mode == 3) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" ::"v"(dst), "v"(v) : "memory"); return; }
+#endif
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
 }
+__device__ __forceinline__ u32x4 load16_nt(const void* src) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src)); }
 // The same policy per kernel family where a same-box A/B of the training step says it pays (DL_NT_MASK: 1 LayerNorm, 2 BatchNorm
 // apply passes, 4 attention outputs and gradients).
 #ifndef DL_NT_MASK
 #define DL_NT_MASK 0
 #endif
-__device__ __forceinline__ void store8_nt(void* dst, u32x2 v) {
-  asm volatile("global_store_dwordx2 %0, %1, off nt\n\ts_nop 2" ::"v"(dst), "v"(v) : "memory");
-}
+__device__ __forceinline__ void store8_nt(void* dst, u32x2 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(dst)); }
 template <int FAM> __device__ __forceinline__ void store16_fam(void* dst, u32x4 v) {
   if constexpr ((DL_NT_MASK & FAM) != 0) store16_nt(dst, v);
   else *reinterpret_cast<u32x4*>(dst) = v;

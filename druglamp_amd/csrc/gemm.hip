@@ -49,7 +49,7 @@ struct GemmP {
   float* slabs;   // split mode: [splits][M][N] f32
   float* cs_slabs; // split mode, optional: [splits][M] partial column sums of the K-slow X operand
   int dbg;
-  int nt_c = 0, nt_pre = 0, nt_small = 0;   // large-tile kernels: streaming (`nt`) policy for the output / pre-activation stores
+  int nt_c = 0, nt_pre = 0, nt_small = 0, nt_ext = 0;   // large-tile kernels: streaming (`nt`) policy for the output / pre-activation stores
   // paired launch (gemm_kernel only): byte offsets from problem 0's pointers to problem 1's, and the seed difference
   int nprob = 1;
   int64_t dX = 0, dW = 0, dC = 0, dBias = 0, dRes = 0, dPre = 0, dDact = 0;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p0) {
       TO* dst = reinterpret_cast<TO*>(p.C) + (int64_t)m * p.ldc + n;
       if constexpr (sizeof(TO) == 2) {
         u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
-        if (p.nt_c && p.nt_small) store16_nt(dst, o);
+        if (p.nt_c && p.nt_small) store16_nt(dst, o, p.nt_c);
         else *reinterpret_cast<u32x4*>(dst) = o;
       } else {
         *reinterpret_cast<f32x4*>(dst) = a0;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p0) {
       TO* dst = reinterpret_cast<TO*>(p.C) + (int64_t)m * p.ldc + n;
       if constexpr (sizeof(TO) == 2) {
         u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
-        if (p.nt_c && p.nt_small) store16_nt(dst, o);
+        if (p.nt_c && p.nt_small) store16_nt(dst, o, p.nt_c);
         else *reinterpret_cast<u32x4*>(dst) = o;
       } else {
         *reinterpret_cast<f32x4*>(dst) = a0;
@@ -927,9 +927,10 @@ int gemm_run(const dl_gemm_args* a, const dl_gemm_args* b, dl_stream stream) {
   p.dbg = dl_study_env("DL_GEMM_DBG", 0);     // 0 in the product build (kernels compile the study branches out)
   {
     const double out_mb = (double)a->M * (double)a->N * oes / 1e6;
-    p.nt_c = out_mb >= (double)dl_study_env("DL_NT_MIN_MB", 0) ? 1 : 0;
-    p.nt_pre = dl_study_env("DL_NT_PRE", 1);
+    p.nt_c = out_mb >= (double)dl_study_env("DL_NT_MIN_MB", 0) ? dl_study_env("DL_NT_MODE", 1) : 0;
+    p.nt_pre = dl_study_env("DL_NT_PRE", 1) ? dl_study_env("DL_NT_MODE", 1) : 0;
     p.nt_small = dl_study_env("DL_NT_SMALL", 1);
+    p.nt_ext = dl_study_env("DL_NT_EXT", 0);       // residual / saved pre-activation reads of the large-tile epilogues
   }
 
   if (b) {

@@ -27,7 +27,7 @@ __device__ __forceinline__ void big_epilogue8(const GemmP& p, int m, int n, f32x
   if constexpr (EPI == 2) {
     T* pd = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
     u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
-    if (p.nt_pre) store16_nt(pd, o);
+    if (p.nt_pre) store16_nt(pd, o, p.nt_pre);
     else *reinterpret_cast<u32x4*>(pd) = o;
     a0 = gelu4<T>(a0); a1 = gelu4<T>(a1);
   } else if constexpr (EPI == 5) {
@@ -47,7 +47,7 @@ __device__ __forceinline__ void big_epilogue8(const GemmP& p, int m, int n, f32x
   }
   u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
   T* dstp = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n;
-  if (p.nt_c) store16_nt(dstp, o);
+  if (p.nt_c) store16_nt(dstp, o, p.nt_c);
   else *reinterpret_cast<u32x4*>(dstp) = o;
 }
 
@@ -246,7 +246,7 @@ void gemm_big_kernel(const GemmP p) {
         if (m < p.M && n_ok) {
           const T* src = EPI == 3 ? reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n_lane
                                   : reinterpret_cast<const T*>(p.dact_pre) + (int64_t)m * p.lddp + n_lane;
-          v = *reinterpret_cast<const u32x4*>(src);
+          v = p.nt_ext ? load16_nt(src) : *reinterpret_cast<const u32x4*>(src);
         }
       }
       return v;
