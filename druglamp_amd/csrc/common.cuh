@@ -247,7 +247,8 @@ __device__ __forceinline__ void store16_nt(void* dst, u32x4 v, int mode = 1) {
 }
 __device__ __forceinline__ u32x4 load16_nt(const void* src) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src)); }
 // The same policy per kernel family where a same-box A/B of the training step says it pays (DL_NT_MASK: 1 LayerNorm, 2 BatchNorm
-// apply passes, 4 attention outputs and gradients).
+// apply passes, 4 attention outputs and gradients, 8 split-K slabs of the weight-gradient tiles, 16 = non-temporal LOAD of the saved
+// activation in the LayerNorm backward).
 #ifndef DL_NT_MASK
 #define DL_NT_MASK 0
 #endif

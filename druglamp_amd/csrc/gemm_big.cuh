@@ -592,8 +592,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_big_tt2_kernel(const s
         const int m = cm0 + wm * 16 * XF + i * 16 + r, n = cn0 + wn * 16 * WF + c8 * 8;
         if (m < eM && n < eN && !(DL_DBG(p) & 1)) {
           float* dst = eslabs + ((int64_t)csplit * eM + m) * eN + n;
-          *reinterpret_cast<u32x4*>(dst) = a0;
-          *reinterpret_cast<u32x4*>(dst + 4) = a1;
+          store16_fam<8>(dst, a0);
+          store16_fam<8>(dst + 4, a1);
         }
       }
       wave_sync();

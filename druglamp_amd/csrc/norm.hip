@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void ln_bwd16_kernel(const bf16_t* __restrict_
       mu[q] = 0.f; rs[q] = 0.f;
       if (row < M) {
         const int64_t dr = dy_share == 1 ? row : row / dy_share;
-        wx[q] = *reinterpret_cast<const u32x4*>(x + row * ldx + cl * 8);
+        wx[q] = (DL_NT_MASK & 16) ? load16_nt(x + row * ldx + cl * 8) : *reinterpret_cast<const u32x4*>(x + row * ldx + cl * 8);   // (saved activation: last use)
         wd[q] = *reinterpret_cast<const u32x4*>(dy + dr * lddy + cl * 8);
         if (dres) wr[q] = *reinterpret_cast<const u32x4*>(dres + row * lddres + cl * 8);
         mu[q] = mean[row]; rs[q] = rstd[row];
