@@ -180,6 +180,52 @@ def test_c_abi_argument_validation_without_gpu():
     assert L.dl_adamw_step(p16, p16, p16, p16, 16, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0, 1.0, None, 0, None) == -1
 
 
+def test_gemm_group_plan_without_gpu():
+    """dl_gemm_group_plan is host logic: which groups of weight-gradient products the library takes, and the slab count per
+    member (one common count so that tiles x slabs is about one round of 256 workgroups, at least eight 64-row k-steps per
+    slab, trimmed so that no slab is empty)."""
+    import ctypes as C
+    from druglamp_amd import _lib
+    L = _lib.lib()
+    p16 = 1 << 20
+
+    def member(M, N, K, **kw):
+        a = _lib.GemmArgs()
+        a.X = a.W = a.C = p16
+        a.M, a.N, a.K = M, N, K
+        a.ldx, a.ldw, a.ldc = M, N, N
+        a.x_kslow = a.w_kslow = 1
+        a.in_dtype, a.out_dtype = _lib.DL_BF16, _lib.DL_F32
+        a.split_k = 0
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+
+    def plan(members):
+        arr = (_lib.GemmArgs * len(members))(*members)
+        sp = (C.c_int32 * len(members))()
+        rc = L.dl_gemm_group_plan(arr, len(members), sp)
+        return rc, list(sp)
+
+    # a paired d = 256 block at 8192 rows: 56 tiles of 128 x 256 -> 4 slabs each
+    block = [member(256, 1024, 8192), member(1024, 256, 8192), member(256, 256, 8192), member(256, 512, 8192), member(768, 256, 8192)] * 2
+    rc, sp = plan(block)
+    assert rc == 0 and sp == [4] * 10
+    # few k-steps: at least eight per slab (K = 1024 = 16 steps -> 2 slabs); 1000 rows = 16 steps (the last one partial)
+    assert plan([member(128, 128, 1024), member(128, 128, 1000)]) == (0, [2, 2])
+    # large members over >= 16384 rows take 256-row tiles: 2048 x 512 -> 16 tiles, 512 x 2048 -> 16, one slab count for both
+    rc, sp = plan([member(2048, 512, 65536), member(512, 2048, 65536)])
+    assert rc == 0 and sp == [8, 8]
+    # not a weight-gradient product / odd sizes / too many members: DL_ERR_UNSUPPORTED, the caller issues dl_gemm calls
+    assert plan([member(256, 256, 8192, x_kslow=0)])[0] == -6
+    assert plan([member(256, 252, 8192)])[0] == -6
+    assert plan([member(256, 256, 8192, accumulate=1)])[0] == -6
+    assert plan([member(256, 256, 8192)] * 17)[0] == -6 and b"dl_gemm_group_plan" in L.dl_last_error()
+    # dl_gemm_group validates the workspaces before it launches anything
+    arr = (_lib.GemmArgs * 2)(member(256, 256, 8192), member(256, 256, 8192))
+    assert L.dl_gemm_group(arr, 2, None) == -4 and b"workspace" in L.dl_last_error()
+
+
 def test_ops_reject_cpu_tensors():
     from druglamp_amd import ops
     x = torch.randn(8, 8)
