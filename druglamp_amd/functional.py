@@ -1107,6 +1107,59 @@ class BatchNormRowsFn(torch.autograd.Function):
         return dx, sums[C:], sums[:C], None, None, None, None, None
 
 
+class BatchNormWeightedTailFn(torch.autograd.Function):
+    """BatchNorm1d (training) over the rows of x [B * LP][C] where, inside every window of LP rows, the first `lead` rows
+    count once and the `tail` rows behind them stand for `w` identical rows each (MolecularGCN's compact form: the virtual
+    padding nodes of a molecule are computed once).  Statistics and gradients are those of the expanded matrix with
+    B * (lead + w * tail) rows: sums = masked sums over the lead rows + w x masked sums over the tail rows; a tail row's
+    incoming gradient is the SUM over the rows it stands for (the expansion's backward), so its input gradient takes the
+    mean terms w times.  Returns (y, mean, var)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, eps, momentum, LP, lead, w):
+        R, C = x.shape
+        x = x.contiguous()
+        tail = LP - lead
+        n = (R // LP) * (lead + w * tail)
+        sums = ops.bn_stats(x, LP, 0, lead)
+        sums = sums.add_(ops.bn_stats(x, LP, lead, tail), alpha=float(w))
+        upd = momentum is not None and rmean is not None and rmean.dtype == torch.float32
+        mean, var, rstd = ops.bn_finalize(sums, n, eps, momentum if upd else 0.0, rmean.detach() if upd else None,
+                                          rvar.detach() if upd else None)
+        g = gamma.detach().float()
+        y = ops.bn_apply_fwd(x, mean, rstd, g, beta.detach().float(), 0, 0, 0)
+        ctx.save_for_backward(x, mean, rstd, g)
+        ctx.cfg = (LP, lead, w, n)
+        ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _m, _v):
+        x, mean, rstd, g = ctx.saved_tensors
+        LP, lead, w, n = ctx.cfg
+        R, C = x.shape
+        dy = dy.contiguous()
+        sums = ops.bn_bwd_reduce(dy, x, mean, rstd, 0, 0, 0)          # tail rows of dy already hold the sums over their copies
+        dx = ops.bn_bwd_apply(dy, x, mean, rstd, g, sums, 1.0 / n, False, 0, 0, 0)
+        # tail rows: dx = sum over the w copies of g rstd (dy_copy - mean_dy - xhat mean_dyxhat): the mean terms w times
+        xt = x.view(R // LP, LP, C)[:, lead:].float()
+        xhat = (xt - mean) * rstd
+        corr = (xhat * (sums[C:] / n) + sums[:C] / n) * (g * rstd * float(w - 1))
+        dx.view(R // LP, LP, C)[:, lead:] -= corr.to(dx.dtype)
+        return dx, sums[C:], sums[:C], None, None, None, None, None, None, None
+
+
+def batch_norm_rows_weighted_tail(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor, LP: int, lead: int, w: int) -> torch.Tensor:
+    """batch_norm_rows for the compact MolecularGCN layout (training mode; eval mode is row-wise and needs no weights)."""
+    if not bn.training:
+        return batch_norm_rows(bn, x2d)
+    y, _mean, _var = BatchNormWeightedTailFn.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                                                 LP, lead, w)
+    bn_tick(bn.num_batches_tracked)
+    return y
+
+
 # nn.BatchNorm1d's num_batches_tracked counters: one `+= 1` launch per BatchNorm layer (nine per DrugLAMP forward) or, inside
 # a `deferred_bn_ticks()` block (the model forwards), ONE multi-tensor add when the block ends.
 _tick_list = None

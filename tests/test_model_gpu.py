@@ -214,6 +214,7 @@ def test_gcn_dense_restatement_vs_plain_torch():
     from druglamp_amd.synthetic import make_batch
     torch.manual_seed(0)
     gcn = MolecularGCN(75, 128, True, [128] * 3).to(DEV).train()
+    gcn.compact_min_rows = 0                                   # the compact padding form also at this small batch
     (feat_d, *_), _ = make_batch(4, DEV, seed=5, with_graph=True)
     h, adj = feat_d
     out = gcn((h, adj))
@@ -249,6 +250,7 @@ def test_gcn_hip_path_vs_the_reference_gcn_classes_golden(dt, tol_o, tol_g):
     gcn = MolecularGCN(75, 128, True, [128] * 3).to(DEV).train()
     gcn.load_state_dict(sd, strict=True)
     gcn.compute_dtype = dt
+    gcn.compact_min_rows = 0                                   # (whenever the fixture has padding nodes beyond its adjacency block)
     h, adj = torch.from_numpy(g["h"]).to(DEV), torch.from_numpy(g["adj"]).to(DEV)
     out = gcn((h, adj))
     assert relerr(out.float(), g["out"]) <= tol_o
@@ -325,3 +327,46 @@ def test_odd_batch_sizes_match_the_oracle(B):
         with torch.no_grad():
             _, _, _, _, score = model(feat_d, vp, xd.to(cdt), xp.to(cdt))
         assert float((score.float().cpu() - ref).abs().max()) <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_gcn_compact_padding_equals_the_512_row_computation(dt, tol):
+    """Round 3: MolecularGCN computes the virtual padding nodes of a molecule (identical in every layer) as 8 rows that stand
+    for (512 - Nr) / 8 nodes each, weighted in the BatchNorm statistics and gradients.  Against the same module on all 512
+    rows per molecule: outputs, every parameter gradient and the BatchNorm running statistics (fp32: the sums associate
+    differently, nothing else).  DL_GCN_CHECK's padding check accepts the synthetic graphs and rejects a tampered one."""
+    import copy
+    from druglamp_amd.model.basic_model import MolecularGCN
+    from druglamp_amd.synthetic import make_batch
+    torch.manual_seed(1)
+    ref = MolecularGCN(75, 128, True, [128] * 3).to(DEV).train()
+    ref.compute_dtype = dt
+    cmp_ = copy.deepcopy(ref)
+    ref.compact_padding, cmp_.compact_padding = False, True
+    cmp_.check_padding, cmp_.compact_min_rows = True, 0
+    (feat_d, *_), _ = make_batch(6, DEV, seed=9, with_graph=True)
+    h, adj = feat_d
+    cot = torch.randn(6, 512, 128, device=DEV)
+    outs = []
+    for m in (ref, cmp_):
+        o = m((h, adj))
+        (o.float() * cot).sum().backward()
+        outs.append(o)
+    assert outs[1].shape == outs[0].shape
+    assert relerr(outs[1].float(), outs[0].float()) <= tol
+    for (n, a), (_, b) in zip(ref.named_parameters(), cmp_.named_parameters()):
+        if dt == torch.float32:
+            assert relerr(b.grad, a.grad) <= 20 * tol, n
+        else:
+            x, y = b.grad.double().flatten(), a.grad.double().flatten()
+            assert float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)) >= 0.99, n
+    for (n, a), (_, b) in zip(ref.named_buffers(), cmp_.named_buffers()):
+        assert relerr(b.float(), a.float()) <= max(tol, 1e-5), n
+    ref.eval(); cmp_.eval()
+    with torch.no_grad():
+        assert relerr(cmp_((h, adj)).float(), ref((h, adj)).float()) <= tol            # running statistics: row-wise, no weights
+    bad = h.clone()
+    bad[2, 300, 5] = 1.0
+    with pytest.raises(ValueError, match="virtual padding"):
+        cmp_((bad, adj))
