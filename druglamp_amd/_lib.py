@@ -121,6 +121,7 @@ SIGNATURES = {
     "dl_bn_stats": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "dl_bn_apply_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "dl_bn_bwd_reduce": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "dl_bn_tail_fix": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "dl_bn_bwd_apply": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64,
                                 c_i32, c_vp]),
     "dl_layernorm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_f32, c_i32, c_vp]),

@@ -363,6 +363,52 @@ extern "C" int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean,
   return DL_OK;
 }
 
+// ---- weighted tail rows (MolecularGCN's compact padding form) ------------------------------------------------------
+// Inside every window of `win` rows the rows [lead, win) stand for w identical rows each.  dl_bn_bwd_apply computed their
+// input gradient with the mean terms once; they count w times: dy[r] -= (w - 1) gamma rstd (S1 / n + xhat[r] S2 / n).
+namespace {
+template <typename T>
+__global__ void bn_tail_fix_kernel(T* __restrict__ dy, const T* __restrict__ y, const float* __restrict__ mean,
+                                   const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ sums,
+                                   float inv_n, float wm1, int64_t nwin, int win, int lead, int C) {
+  const int tail = win - lead;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (window, tail row, 4 columns)
+  const int c4 = C / 4;
+  if (i >= nwin * tail * c4) return;
+  const int c = (int)(i % c4) * 4;
+  const int64_t t = i / c4;
+  const int64_t r = (t / tail) * win + lead + (t % tail);
+  f32x4 d = load4<T>(dy + r * C + c);
+  const f32x4 x = load4<T>(y + r * C + c);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float rs = rstd[c + e];
+    const float xhat = (x[e] - mean[c + e]) * rs;
+    d[e] -= wm1 * gamma[c + e] * rs * (sums[c + e] * inv_n + xhat * sums[C + c + e] * inv_n);
+  }
+  store4<T>(dy + r * C + c, d);
+}
+}  // namespace
+
+extern "C" int dl_bn_tail_fix(void* dy, const void* y, const float* mean, const float* rstd, const float* gamma,
+                              const float* sums, float inv_n, int32_t w, int64_t R, int64_t C, int64_t win, int64_t lead,
+                              int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(dy && y && mean && rstd && gamma && sums && R > 0 && C > 0 && C % 4 == 0 && win > 0 && lead >= 0 && lead < win &&
+                   R % win == 0 && w >= 1, DL_ERR_ARG, "dl_bn_tail_fix: bad args");
+  DL_CHECK_ARG(dtype == DL_BF16 || dtype == DL_F32, DL_ERR_ARG, "dl_bn_tail_fix: bad dtype");
+  const int64_t n = (R / win) * (win - lead) * (C / 4);
+  const uint32_t blocks = (uint32_t)((n + 255) / 256);
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((bn_tail_fix_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (bf16_t*)dy, (const bf16_t*)y, mean, rstd, gamma,
+                       sums, inv_n, (float)(w - 1), R / win, (int)win, (int)lead, (int)C);
+  else
+    hipLaunchKernelGGL((bn_tail_fix_kernel<float>), dim3(blocks), dim3(256), 0, s, (float*)dy, (const float*)y, mean, rstd, gamma,
+                       sums, inv_n, (float)(w - 1), R / win, (int)win, (int)lead, (int)C);
+  DL_CHECK_LAUNCH("dl_bn_tail_fix");
+  return DL_OK;
+}
+
 // ---- finalize: sums -> mean / biased var / rstd, and the running-statistics update, in one tiny launch ---------
 namespace {
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, float inv_n, float unbias, float eps, float momentum,

@@ -1143,11 +1143,32 @@ class BatchNormWeightedTailFn(torch.autograd.Function):
         sums = ops.bn_bwd_reduce(dy, x, mean, rstd, 0, 0, 0)          # tail rows of dy already hold the sums over their copies
         dx = ops.bn_bwd_apply(dy, x, mean, rstd, g, sums, 1.0 / n, False, 0, 0, 0)
         # tail rows: dx = sum over the w copies of g rstd (dy_copy - mean_dy - xhat mean_dyxhat): the mean terms w times
-        xt = x.view(R // LP, LP, C)[:, lead:].float()
-        xhat = (xt - mean) * rstd
-        corr = (xhat * (sums[C:] / n) + sums[:C] / n) * (g * rstd * float(w - 1))
-        dx.view(R // LP, LP, C)[:, lead:] -= corr.to(dx.dtype)
+        ops.bn_tail_fix(dx, x, mean, rstd, g, sums, 1.0 / n, w, LP, lead)
         return dx, sums[C:], sums[:C], None, None, None, None, None, None, None
+
+
+class ExpandTailFn(torch.autograd.Function):
+    """(B, lead + tail, C) -> (B, lead + w * tail, C): row lead + j of the output is tail row j % tail.  Backward: the lead
+    rows' gradients as they are, a tail row's gradient = the sum over its w copies in a fixed order (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, y, lead, w):
+        B, LP, C = y.shape
+        tail = LP - lead
+        ctx.cfg = (lead, tail, w)
+        out = torch.empty((B, lead + w * tail, C), dtype=y.dtype, device=y.device)
+        out[:, :lead] = y[:, :lead]
+        out[:, lead:].view(B, w, tail, C).copy_(y[:, lead:].unsqueeze(1).expand(B, w, tail, C))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lead, tail, w = ctx.cfg
+        B, _, C = dout.shape
+        dy = torch.empty((B, lead + tail, C), dtype=dout.dtype, device=dout.device)
+        dy[:, :lead] = dout[:, :lead]
+        dy[:, lead:] = torch.sum(dout[:, lead:].reshape(B, w, tail, C), dim=1, dtype=torch.float32).to(dout.dtype)
+        return dy, None, None
 
 
 def batch_norm_rows_weighted_tail(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor, LP: int, lead: int, w: int) -> torch.Tensor:

@@ -620,6 +620,15 @@ def bn_bwd_apply(dz2d, y2d, mean, rstd, gamma, sums, inv_n, relu_mask, win, halo
     return dy
 
 
+def bn_tail_fix(dy2d, y2d, mean, rstd, gamma, sums, inv_n, w, win, lead):
+    """In place: the tail rows of every `win`-row window take the mean terms of the BatchNorm backward w times (dl_bn_tail_fix)."""
+    R, Cc = y2d.shape
+    check(_lib.lib().dl_bn_tail_fix(dy2d.data_ptr(), y2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                    sums.data_ptr(), float(inv_n), int(w), R, Cc, int(win), int(lead), _dt(y2d), _stream()),
+          "dl_bn_tail_fix")
+    return dy2d
+
+
 def gelu_bwd(dy2d, pre2d):
     dx = torch.empty_like(dy2d)
     check(_lib.lib().dl_gelu_bwd(dy2d.data_ptr(), pre2d.data_ptr(), dx.data_ptr(), dy2d.numel(), _dt(dy2d), _stream()),

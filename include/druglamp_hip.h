@@ -180,6 +180,13 @@ int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean, const floa
                     const float* gamma, const float* sums, float inv_n, int32_t relu_mask, void* dy,
                     int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid, int32_t dtype,
                     dl_stream s);
+/* Weighted tail rows (round 3: MolecularGCN's compact padding form, model/basic_model.py — the reference's virtual padding
+ * nodes, handler/dataset.py:216-221, are identical in every layer and computed once).  Inside every window of `win` rows
+ * the rows [lead, win) stand for w identical rows each; their incoming gradient is already the sum over those copies.
+ * dl_bn_bwd_apply (run first, inv_n = 1 / the expanded row count) gave them the mean terms once; this adds the other
+ * w - 1: dy[r] -= (w - 1) gamma rstd (S1 inv_n + xhat[r] S2 inv_n), in place, tail rows only. */
+int dl_bn_tail_fix(void* dy, const void* y, const float* mean, const float* rstd, const float* gamma, const float* sums,
+                   float inv_n, int32_t w, int64_t R, int64_t C, int64_t win, int64_t lead, int32_t dtype, dl_stream s);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps 1e-6 inside PMMA: model/PMMA/block.py:23-27,
