@@ -1147,6 +1147,32 @@ class BatchNormWeightedTailFn(torch.autograd.Function):
         return dx, sums[C:], sums[:C], None, None, None, None, None, None, None
 
 
+# Padding hints: host-side knowledge about the batch that the tensors themselves do not carry (the collate knows every
+# molecule's token count; the padded (B, 512, .) tensor does not say where the zero rows start).  Set by the trainer around
+# the model forward; a model that finds no hint computes every row.
+_pad_hints = {}
+
+
+class padding_hints:
+    def __init__(self, **hints):
+        self.hints = {k: v for k, v in hints.items() if v}
+
+    def __enter__(self):
+        global _pad_hints
+        self.prev = _pad_hints
+        _pad_hints = dict(self.prev, **self.hints)
+        return self
+
+    def __exit__(self, *exc):
+        global _pad_hints
+        _pad_hints = self.prev
+        return False
+
+
+def padding_hint(name: str):
+    return _pad_hints.get(name)
+
+
 class ExpandTailFn(torch.autograd.Function):
     """(B, lead + tail, C) -> (B, lead + w * tail, C): row lead + j of the output is tail row j % tail.  Backward: the lead
     rows' gradients as they are, a tail row's gradient = the sum over its w copies in a fixed order (no atomics)."""

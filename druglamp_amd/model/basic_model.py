@@ -245,6 +245,8 @@ class DrugLAMPBase(nn.Module):
         self.site_len = cfg["PROTEIN"]["SITE_LEN"]
         self.seq_len_q = cfg["PROTEIN"]["SEQ_LEN"]
         dec = cfg["DECODER"]
+        self.compact_padding = os.environ.get("DL_PAD_COMPACT", "1") != "0"      # A/B switch: compact padding rows of the drug LLM adaptor
+        self.check_padding = os.environ.get("DL_PAD_CHECK", "0") == "1"         # debug: verify the padding rows (host sync)
         self.drug_extractor = MolecularGCN(in_feats=cfg["DRUG"]["NODE_IN_FEATS"], dim_embedding=n_hidden,
                                            padding=cfg["DRUG"]["PADDING"], hidden_feats=[n_hidden] * 3)
         self.protein_extractor = ProteinCNN(n_hidden, [n_hidden] * 3, cfg["PROTEIN"]["KERNEL_SIZE"],
@@ -343,9 +345,20 @@ class DrugLAMPBase(nn.Module):
         h = Fn.layer_norm(h, self.p_norm.weight, self.p_norm.bias, self.p_norm.eps)
         xpf = Fn.dense(h, self.lin_p2.weight, self.lin_p2.bias)
         xd = xd_cat                                    # fill-augmented, padded (B, 512, 392)
+        # Compact form (round 3): the token rows beyond a molecule's tokens are zero (+ the fill bit) — identical rows, and the
+        # drug adaptor is row-wise (Linear, GELU, LayerNorm, Linear).  With the collate's hint `drug_tokens` (a block size that
+        # covers every molecule of the batch) the rows beyond it are computed as 8 rows standing for (512 - block) / 8 rows each
+        # and expanded; the expansion's backward sums the copies' gradients, which is all a row-wise layer needs.
+        blk, N, TAIL = Fn.padding_hint("drug_tokens"), xd.shape[1], 8
+        if blk and self.compact_padding and N - blk >= 2 * TAIL and (N - blk) % TAIL == 0 and blk % 8 == 0:
+            if self.check_padding and not bool((xd[:, blk:] == xd[:1, blk:blk + 1]).all()):
+                raise ValueError("drug LLM adaptor: the token rows beyond the hinted block of %d are not identical padding rows" % blk)
+            xd = xd[:, :blk + TAIL].contiguous()
         h = Fn.dense(xd, self.lin_d1.weight, self.lin_d1.bias, act=True)
         h = Fn.layer_norm(h, self.d_norm.weight, self.d_norm.bias, self.d_norm.eps)
         xdf = Fn.dense(h, self.lin_d2.weight, self.lin_d2.bias)
+        if xdf.shape[1] != N:
+            xdf = Fn.ExpandTailFn.apply(xdf, blk, (N - blk) // TAIL)
         return xpf, xdf                                # compute dtype
 
     def get_cross_attn_mat(self, modality="v"):

@@ -260,6 +260,7 @@ class GraphedStep:
         self.tr = trainer
         dev = trainer.device
         self.static = self._clone(batch)
+        self.hints = trainer.padding_hints_of(meta, batch)
         self.labels = None
         if "cm" in kind:
             from .model.cross_modality import CMLabels
@@ -349,7 +350,8 @@ class GraphedStep:
         tr, m = self.tr, self.tr.model
         ops.seed_offset_tensor(tr.device).add_(1)
         feat_d, feat_p, labels, llm_d, llm_p = self.static
-        _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p)
+        with Fn.padding_hints(**self.hints):           # (by-value knowledge of the capture: part of the graph key)
+            _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p)
         tr._zero_grad()
         _, cls_loss = binary_cross_entropy(score, labels) if tr.n_class == 1 else cross_entropy_logits(score, labels)
         out = {"cls": cls_loss.detach()}
@@ -568,6 +570,17 @@ class Trainer:
         if cm_lr is not None and self.opt_cm:
             self.opt_cm.lr = cm_lr
 
+    @staticmethod
+    def padding_hints_of(meta, batch) -> dict:
+        """Host-side knowledge about the batch for the model (functional.padding_hints).  drug_tokens: a block size (multiple
+        of 64, so that captured graphs are keyed by few values) that covers the token count of every molecule of the batch,
+        from the collate's `Drug_Tokens` records; absent records or a block that saves nothing: no hint."""
+        if not meta or any("Drug_Tokens" not in m_ for m_ in meta):
+            return {}
+        n_rows = int(batch[3].shape[1]) if torch.is_tensor(batch[3]) and batch[3].dim() == 3 else 0
+        blk = (max(int(m_["Drug_Tokens"]) for m_ in meta) + 63) // 64 * 64
+        return {"drug_tokens": blk} if 0 < blk <= n_rows - 64 else {}
+
     # -- the step ---------------------------------------------------------------------------------------
     def training_step(self, batch, meta=None, cur_epoch: int = 1, ssl_masks=None) -> Dict[str, float]:
         """batch = (feat_d, feat_p, labels, llm_d, llm_p) as the reference's collate yields them.
@@ -584,12 +597,14 @@ class Trainer:
         if self.graph_steps and cm_ok and not self.run_dead_backward and (not compute_ssl or ssl_masks is None):
             kind = (("ssl" if compute_ssl else "") + ("cm" if compute_cm else "")) or "cls"
             byval = (float(m.cm_model.m_sch_loss_fn.margin), float(self.cm_weight)) if compute_cm else ()
+            byval = tuple(sorted(self.padding_hints_of(meta, batch).items())) + byval
             sig = (kind,) + GraphedStep.signature(batch) + byval
             if sig in self._graphs or self._eager_seen.get(sig, 0) >= self.graph_warmup:
                 return self._graphed_step(batch, sig, kind, meta)
             self._eager_seen[sig] = self._eager_seen.get(sig, 0) + 1
         feat_d, feat_p, labels, llm_d, llm_p = batch
-        _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p)
+        with Fn.padding_hints(**self.padding_hints_of(meta, batch)):
+            _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p)
         self._zero_grad()
         _, cls_loss = binary_cross_entropy(score, labels) if self.n_class == 1 else cross_entropy_logits(score, labels)
         last = "cm" if compute_cm else "ssl" if compute_ssl else "cls"     # the backward the optimisers consume
@@ -640,8 +655,7 @@ class Trainer:
             if "cm" in kind:
                 # margin / cm_weight are by-value arguments of a capture: a graph of the same kind and shapes with older
                 # values (the margin moves once per epoch) will not be replayed again — release its pool first
-                n_shape = len(GraphedStep.signature(batch))
-                for old in [k for k in self._graphs if k[:1 + n_shape] == sig[:1 + n_shape]]:
+                for old in [k for k in self._graphs if k[:-2] == sig[:-2]]:       # same kind, shapes and hints
                     del self._graphs[old]
             g = self._graphs[sig] = GraphedStep(self, batch, kind, meta)     # records only; the replay below is the step
         out, idx = g.run(batch, meta)

@@ -370,3 +370,49 @@ def test_gcn_compact_padding_equals_the_512_row_computation(dt, tol):
     bad[2, 300, 5] = 1.0
     with pytest.raises(ValueError, match="virtual padding"):
         cmp_((bad, adj))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_drug_llm_adaptor_compact_padding_equals_the_full_computation(dt, tol):
+    """Round 3: with the collate's `drug_tokens` hint the drug LLM adaptor (Linear + GELU, LayerNorm, Linear: all row-wise)
+    computes the identical zero rows beyond the hinted block as 8 rows and expands them.  Whole-model check: scores,
+    every parameter gradient of a training forward/backward with and without the hint; DL_PAD_CHECK's check rejects a
+    hint that is too small."""
+    import copy
+    from druglamp_amd import functional as Fn
+    from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
+    from druglamp_amd.model import MInterface
+    from druglamp_amd.synthetic import make_batch
+    from druglamp_amd.trainer import Trainer
+    torch.manual_seed(3)
+    cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP")
+    ref = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(DEV).train()
+    ref.pmma.p_drop = 0.0
+    ref.pmma.embeddings.p_drop = 0.0
+    ref.set_compute_dtype(dt)
+    batch, meta = make_batch(4, DEV, seed=11, with_graph=True, llm_dtype=dt)
+    hints = Trainer.padding_hints_of(meta, batch)
+    assert hints == {"drug_tokens": 128}
+    cmp_ = copy.deepcopy(ref)
+    cmp_.check_padding = True
+    feat_d, feat_p, labels, llm_d, llm_p = batch
+    outs = []
+    for m, h in ((ref, {}), (cmp_, hints)):
+        with Fn.padding_hints(**h):
+            score = m(feat_d, feat_p, llm_d, llm_p)[-1]
+        score.float().sum().backward()
+        outs.append(score.float())
+    assert relerr(outs[1], outs[0]) <= tol
+    for (n, a), (_, b) in zip(ref.named_parameters(), cmp_.named_parameters()):
+        if a.grad is None:
+            assert b.grad is None, n
+            continue
+        if dt == torch.float32:
+            assert relerr(b.grad, a.grad) <= 50 * tol, n
+        else:
+            x, y = b.grad.double().flatten(), a.grad.double().flatten()
+            assert float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)) >= 0.98, n
+    with pytest.raises(ValueError, match="padding rows"):
+        with Fn.padding_hints(drug_tokens=64):
+            cmp_(feat_d, feat_p, llm_d, llm_p)
