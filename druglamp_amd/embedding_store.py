@@ -109,6 +109,10 @@ class EmbeddingStore:
     def nbytes(self) -> int:
         return self._rows * self.feat_dim * torch.empty((), dtype=self.dtype).element_size()
 
+    def length(self, key: Hashable) -> int:
+        """Rows stored under `key` (the collate's token count: what Trainer turns into a padding hint)."""
+        return int(self._index[key][1])
+
     def batch(self, keys: Sequence[Hashable], max_rows: int, repeat: bool) -> torch.Tensor:
         """(B, max_rows, feat_dim): repeat=True is the reference's repeat_pad, repeat=False its tail_pad."""
         if self._store is None or self._store.shape[0] != self._rows:

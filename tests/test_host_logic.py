@@ -226,6 +226,27 @@ def test_gemm_group_plan_without_gpu():
     assert L.dl_gemm_group(arr, 2, None) == -4 and b"workspace" in L.dl_last_error()
 
 
+def test_padding_hints_from_the_collate_records():
+    """Trainer.padding_hints_of: the batch maximum of the collate's Drug_Tokens records, rounded up to a multiple of 64 (few
+    graph keys); no hint without the records or when the block would save nothing; functional.padding_hints nests."""
+    from druglamp_amd import functional as Fn
+    from druglamp_amd.trainer import Trainer
+    llm_d = torch.zeros(3, 512, 8)
+    batch = (None, None, None, llm_d, None)
+    mk = lambda *n: [{"Drug_Tokens": k} for k in n]      # noqa: E731
+    assert Trainer.padding_hints_of(mk(12, 64, 40), batch) == {"drug_tokens": 64}
+    assert Trainer.padding_hints_of(mk(12, 65, 40), batch) == {"drug_tokens": 128}
+    assert Trainer.padding_hints_of(mk(449, 3, 3), batch) == {}                  # block 512: nothing to save
+    assert Trainer.padding_hints_of(mk(448, 3, 3), batch) == {"drug_tokens": 448}
+    assert Trainer.padding_hints_of([{"Drug_Tokens": 5}, {"Y": 1.0}], batch) == {} and Trainer.padding_hints_of(None, batch) == {}
+    assert Fn.padding_hint("drug_tokens") is None
+    with Fn.padding_hints(drug_tokens=128):
+        assert Fn.padding_hint("drug_tokens") == 128
+        with Fn.padding_hints():
+            assert Fn.padding_hint("drug_tokens") == 128
+    assert Fn.padding_hint("drug_tokens") is None
+
+
 def test_ops_reject_cpu_tensors():
     from druglamp_amd import ops
     x = torch.randn(8, 8)
