@@ -245,7 +245,12 @@ def main():
                                        ", PMMA attention forward in MXFP8" if args.attention == "fp8" else ""),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "step_kind": "+".join(kinds), "epoch": ep, "hip_graph": bool(graphed), "protein_seq_len": args.seq_len,
-                       "attention": args.attention},
+                       "attention": args.attention,
+                       # identical padding rows of the drug branch (virtual GCN nodes beyond the adjacency block, zero token rows
+                       # beyond the collate's Drug_Tokens) are computed once and expanded: same results as computing every row
+                       # (tests/test_model_gpu.py); DL_GCN_COMPACT=0 DL_PAD_COMPACT=0 computes every row
+                       "padding_rows": "computed once" if (os.environ.get("DL_GCN_COMPACT", "1") != "0" or
+                                                           os.environ.get("DL_PAD_COMPACT", "1") != "0") else "every row"},
             # (the per-pair flop count of BASELINE.md section 3 is for 256 sites; not applicable to other lengths)
             "hot_path_tflops_per_gpu": round(value * HOT_FLOPS_PER_PAIR_STEP / world / 1e12, 2) if args.seq_len == 2304 else None,
             "hot_path_frac_of_peak": round(value * HOT_FLOPS_PER_PAIR_STEP / world / 1e12 / peak, 4) if args.seq_len == 2304 else None,
