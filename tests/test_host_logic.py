@@ -226,6 +226,33 @@ def test_gemm_group_plan_without_gpu():
     assert L.dl_gemm_group(arr, 2, None) == -4 and b"workspace" in L.dl_last_error()
 
 
+def test_cm_labels_pack_the_label_matrix_into_static_shapes():
+    """CMLabels (model/cross_modality.py): label_matrix() of a batch padded to (B, B) with the padding marked ignored (-1),
+    unique-row indices padded with row 0, row masks and counts — one packed buffer, refilled in place (what a captured CM
+    step reads).  CPU build of the same code path (no pinned staging without a GPU)."""
+    from druglamp_amd.model.cross_modality import CMLabels, CrossModality, label_matrix
+    import copy, pickle
+    meta = [{"Prot_ID": "p%d" % (i % 3), "Drug_ID": "d%d" % (i % 5), "Y": float(i % 2)} for i in range(8)]
+    lab = CMLabels(8, "cpu")
+    ptrs = (lab.idx.data_ptr(), lab.mask.data_ptr(), lab.n.data_ptr(), lab.gt.data_ptr())
+    for use_cm in (True, False, True):
+        for _ in range(5):                                  # more fills than staging slots
+            lab.fill(meta, use_cm)
+        pi, di, gt = label_matrix(meta, use_cm)
+        assert lab.idx[0, :len(pi)].tolist() == pi and lab.idx[1, :len(di)].tolist() == di
+        assert lab.idx[0, len(pi):].sum() == 0 and lab.idx[1, len(di):].sum() == 0
+        assert lab.n.tolist() == [float(len(pi)), float(len(di))]
+        assert lab.mask[0, :, 0].tolist() == [1.0] * len(pi) + [0.0] * (8 - len(pi))
+        assert (lab.gt[:len(pi), :len(di)].numpy() == gt).all()
+        assert (lab.gt[len(pi):] == -1).all() and (lab.gt[:, len(di):] == -1).all()
+    assert ptrs == (lab.idx.data_ptr(), lab.mask.data_ptr(), lab.n.data_ptr(), lab.gt.data_ptr())      # refilled in place
+    with pytest.raises(ValueError):
+        lab.fill(meta[:5])
+    cm = CrossModality(hidden_size=128, max_margin=0.5, n_re=10)
+    cm._label_blocks[(8, "cpu")] = lab
+    assert copy.deepcopy(cm)._label_blocks == {} and pickle.loads(pickle.dumps(cm))._label_blocks == {}
+
+
 def test_padding_hints_from_the_collate_records():
     """Trainer.padding_hints_of: the batch maximum of the collate's Drug_Tokens records, rounded up to a multiple of 64 (few
     graph keys); no hint without the records or when the block would save nothing; functional.padding_hints nests."""
