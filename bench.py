@@ -196,6 +196,15 @@ def main():
                 L.dl_prof_totals(fam, C.byref(na), C.byref(fla), C.byref(bya))
                 # (timed launches, their ms / flops / bytes, all launches of the region, their flops / bytes)
                 stats[name] = (n.value, ms.value, fl.value, by.value, na.value, fla.value, bya.value)
+                if fam == 0:
+                    # sub-families of dl_gemm (dl_gemm_args.prof_tag): QKV / fc / out projections, FFN, ProteinCNN
+                    # convolutions (implicit im2col), weight gradients, everything else
+                    sub = {}
+                    for tag, tname in _lib.TAG_NAMES.items():
+                        L.dl_prof_collect_tag(0, tag, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by), C.byref(na), C.byref(fla), C.byref(bya))
+                        if na.value:
+                            sub[tname] = (n.value, ms.value, fl.value, by.value, na.value, fla.value, bya.value)
+                    stats["gemm_sub"] = sub
                 L.dl_prof_enable(fam, 0)
         if busy and float(t) < args.min_busy_seconds:
             # untimed, after the K timed steps and the event collection: keeps the GPU busy long enough for an external
@@ -261,7 +270,7 @@ def main():
             dt_ev, steps_ev = events_dt, events_steps
             ach = fl / (ms * 1e-3) / 1e12
             traffic, traffic_source = None, None
-            for pmc_name in ("r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json"):
+            for pmc_name in ("r4_pmc_summary.json",):
                 pmc = os.path.join(ROOT, "profiles", pmc_name)
                 if os.path.exists(pmc) and args.batch == 256 and args.dtype == "bf16" and args.model == "DrugLAMP" and kinds == ["cls"] \
                         and args.seq_len == 2304 and args.attention == "native":
@@ -290,6 +299,29 @@ def main():
                 "floor_ms_per_step": {"hbm": round(t_hbm * 1e3 / steps_ev, 3), "mfma": round(t_mfma * 1e3 / steps_ev, 3),
                                       "measured": round(ms_all / steps_ev, 3)},
                 "mfma": mfma_obj, "hbm": hbm_obj})
+            # per sub-family: which roofline binds it (its algorithmic bytes at the HBM peak vs its flops at the MFMA peak) and
+            # how far from it the launches run; `furthest` names the sub-family with the most time above its floor
+            subs, worst, worst_gap = {}, None, -1.0
+            for tname, (sn, sms, sfl, sby, sn_all, sfl_all, sby_all) in fam_stats.get("gemm_sub", {}).items():
+                if not sn:
+                    subs[tname] = {"launches": sn_all, "timed_launches": 0}
+                    continue
+                s_ms_all = sms * sn_all / sn
+                s_hbm, s_mfma = sby_all / (HBM_PEAK_GBPS * 1e9) * 1e3, sfl_all / (peak * 1e12) * 1e3     # ms over the region
+                s_bound = "hbm" if s_hbm >= s_mfma else "mfma"
+                s_gbps, s_tf = sby / (sms * 1e-3) / 1e9, sfl / (sms * 1e-3) / 1e12
+                subs[tname] = {"bound": s_bound, "frac": round((s_gbps / HBM_PEAK_GBPS) if s_bound == "hbm" else (s_tf / peak), 4),
+                               "hbm_GBps": round(s_gbps, 1), "hbm_frac": round(s_gbps / HBM_PEAK_GBPS, 4),
+                               "mfma_TFLOPs": round(s_tf, 2), "mfma_frac": round(s_tf / peak, 4),
+                               "launches": sn_all, "timed_launches": sn, "avg_launch_us": round(sms * 1e3 / sn, 2),
+                               "algorithmic_bytes_per_launch": round(sby_all / sn_all),
+                               "ms_per_step": round(s_ms_all / steps_ev, 3),
+                               "floor_ms_per_step": round(max(s_hbm, s_mfma) / steps_ev, 3)}
+                gap = (s_ms_all - max(s_hbm, s_mfma)) / steps_ev
+                if gap > worst_gap:
+                    worst, worst_gap = tname, gap
+            out["roofline"]["sub_families"] = subs
+            out["roofline"]["furthest"] = {"sub_family": worst, "ms_per_step_above_floor": round(worst_gap, 3)}
             for name in ("attn_fwd", "attn_bwd"):
                 n2, ms2, fl2, by2, n2_all, _, _ = fam_stats[name]
                 if n2:

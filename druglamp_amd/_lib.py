@@ -59,7 +59,12 @@ class GemmArgs(C.Structure):
         ("algo", c_i32),
         ("tile_tickets", c_vp),
         ("deferred", C.POINTER(ReduceItem)),
+        ("prof_tag", c_i32),
     ]
+
+
+TAG_OTHER, TAG_QKV_OUT, TAG_FFN, TAG_CONV, TAG_WGRAD, TAG_ADAPTOR = 0, 1, 2, 3, 4, 5
+TAG_NAMES = {0: "other", 1: "qkv_out", 2: "ffn", 3: "conv", 4: "wgrad", 5: "adaptor"}
 
 
 class AttnFwdArgs(C.Structure):
@@ -166,6 +171,8 @@ SIGNATURES = {
     "dl_prof_collect": (c_i32, [c_i32, C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),
     "dl_prof_totals": (c_i32, [c_i32, C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dl_prof_collect_tag": (c_i32, [c_i32, c_i32, C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -8,11 +8,14 @@
 namespace {
 thread_local char g_err[512] = "";
 
-struct ProfRec { hipEvent_t a, b; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; double flops, bytes; int tag; };
+constexpr int NTAG = 8;           // sub-family tags of a family (dl_gemm_args.prof_tag; 0 = untagged)
 struct ProfFamily {
   int period = 0;                 // 0 = off; N >= 1: HIP events around every N-th launch of the family
   int64_t seen = 0;               // launches since dl_prof_enable (timed or not), with their algorithmic work
   double all_flops = 0, all_bytes = 0;
+  int64_t tag_seen[NTAG] = {};    // the same per sub-family tag
+  double tag_flops[NTAG] = {}, tag_bytes[NTAG] = {};
   std::vector<ProfRec> recs;
   hipEvent_t pending = nullptr;
 };
@@ -44,18 +47,22 @@ void dl_prof_before(int family, hipStream_t s) {
   f.pending = e;
 }
 
-void dl_prof_after(int family, hipStream_t s, double flops, double bytes) {
+void dl_prof_after(int family, hipStream_t s, double flops, double bytes, int tag) {
   if (family < 0 || family >= NFAM || !g_prof[family].period) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfFamily& f = g_prof[family];
+  if (tag < 0 || tag >= NTAG) tag = 0;
   ++f.seen;
   f.all_flops += flops;
   f.all_bytes += bytes;
+  ++f.tag_seen[tag];
+  f.tag_flops[tag] += flops;
+  f.tag_bytes[tag] += bytes;
   if (!f.pending) return;
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return;
   (void)hipEventRecord(e, s);
-  f.recs.push_back(ProfRec{f.pending, e, flops, bytes});
+  f.recs.push_back(ProfRec{f.pending, e, flops, bytes, tag});
   f.pending = nullptr;
 }
 
@@ -69,6 +76,7 @@ extern "C" int dl_prof_enable(int32_t family, int32_t on) {
   f.period = on > 0 ? on : 0;
   f.seen = 0;
   f.all_flops = f.all_bytes = 0;
+  for (int t = 0; t < NTAG; ++t) { f.tag_seen[t] = 0; f.tag_flops[t] = f.tag_bytes[t] = 0; }
   return DL_OK;
 }
 
@@ -99,6 +107,30 @@ extern "C" int dl_prof_collect(int32_t family, int64_t* launches, double* total_
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
   if (total_bytes) *total_bytes = by;
+  return DL_OK;
+}
+
+extern "C" int dl_prof_collect_tag(int32_t family, int32_t tag, int64_t* timed_launches, double* timed_ms, double* timed_flops,
+                                   double* timed_bytes, int64_t* all_launches, double* all_flops, double* all_bytes) {
+  DL_CHECK_ARG(family >= 0 && family < NFAM && tag >= 0 && tag < NTAG, DL_ERR_ARG, "dl_prof_collect_tag: bad family %d / tag %d", family, tag);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfFamily& f = g_prof[family];
+  double ms = 0, fl = 0, by = 0;
+  int64_t n = 0;
+  for (auto& r : f.recs) {
+    if (r.tag != tag) continue;
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    ms += t; fl += r.flops; by += r.bytes; ++n;
+  }
+  if (timed_launches) *timed_launches = n;
+  if (timed_ms) *timed_ms = ms;
+  if (timed_flops) *timed_flops = fl;
+  if (timed_bytes) *timed_bytes = by;
+  if (all_launches) *all_launches = f.tag_seen[tag];
+  if (all_flops) *all_flops = f.tag_flops[tag];
+  if (all_bytes) *all_bytes = f.tag_bytes[tag];
   return DL_OK;
 }
 

@@ -52,7 +52,7 @@ static constexpr int dl_study_env(const char*, int dflt) { return dflt; }
 extern "C" void dl_set_error(const char* fmt, ...);
 // profiling hooks (api.hip)
 void dl_prof_before(int family, hipStream_t s);
-void dl_prof_after(int family, hipStream_t s, double flops, double bytes);
+void dl_prof_after(int family, hipStream_t s, double flops, double bytes, int tag = 0);
 
 #define DL_CHECK_ARG(cond, code, ...)                 \
   do {                                                \

@@ -815,6 +815,24 @@ extern "C" size_t dl_gemm_workspace_bytes(const dl_gemm_args* a) {
 }
 
 namespace {
+// Algorithmic HBM bytes of one product: every DISTINCT operand byte once + the output + the epilogue's extra operands.
+// An operand whose row pitch is smaller than its row length (the implicit-im2col A operand of the ProteinCNN
+// convolutions, reference model/basic_model.py:155-180: pitch C, K = k * C; the K-slow W operand of their weight
+// gradients) overlaps its own rows: it spans (rows - 1) * pitch + row_length elements, not rows * row_length.
+static double gemm_algorithmic_bytes(const dl_gemm_args* a) {
+  const double es = (double)dl_dtype_size(a->in_dtype), oes = (double)dl_dtype_size(a->out_dtype);
+  auto span = [](double rows, double len, double pitch) { return pitch < len ? (rows - 1.0) * pitch + len : rows * len; };
+  const double x = a->x_kslow ? span((double)a->K, (double)a->M, (double)a->ldx) : span((double)a->M, (double)a->K, (double)a->ldx);
+  const double w = a->w_kslow ? span((double)a->K, (double)a->N, (double)a->ldw) : span((double)a->N, (double)a->K, (double)a->ldw);
+  const double mn = (double)a->M * (double)a->N;
+  double bytes = (x + w) * es + mn * oes;
+  if (a->pre_out) bytes += mn * es;                                   // pre-activation copy (written)
+  if (a->dact_pre) bytes += mn * es;                                  // saved pre-activation (read)
+  if (a->residual) bytes += (a->res_row_mod > 0 ? (double)a->res_row_mod * (double)a->N : mn) * es;
+  if (a->accumulate) bytes += mn * oes;                               // C read back
+  if (a->bias) bytes += (double)a->N * 4.0;
+  return bytes;
+}
 constexpr int DL_PAIR_FALLBACK = 1;       // gemm_run: the pair is not on the gemm_kernel path, nothing was launched
 // b: nullptr, or a second problem of identical shape / layout / epilogue (checked by dl_gemm_pair) that shares the launch.
 int gemm_run(const dl_gemm_args* a, const dl_gemm_args* b, dl_stream stream);
@@ -973,8 +991,7 @@ int gemm_run(const dl_gemm_args* a, const dl_gemm_args* b, dl_stream stream) {
   {
     // the timing bracket covers the MFMA kernel only (the split-K slab reduction is a separate, HBM-bound launch)
     const double flops = 2.0 * (double)a->M * (double)a->N * (double)a->K * (b ? 2 : 1);
-    const double bytes = (((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * oes) * (b ? 2 : 1);
-    dl_prof_after(0, s, flops, bytes);
+    dl_prof_after(0, s, flops, gemm_algorithmic_bytes(a) * (b ? 2 : 1), a->prof_tag);
   }
   if (slab_path) {
     const int64_t mn = a->M * a->N;
@@ -1080,7 +1097,7 @@ extern "C" int dl_gemm_group(const dl_gemm_args* args, int32_t n, dl_stream stre
     end += (uint32_t)q.mt * q.nt * sp[i];
     q.end = end; q.pad = 0;
     flops += 2.0 * (double)a->M * (double)a->N * (double)a->K;
-    bytes += ((double)a->M * a->K + (double)a->N * a->K) * 2.0 + (double)a->M * a->N * 4.0;
+    bytes += gemm_algorithmic_bytes(a);
   }
   for (int i = n; i < DL_GROUP_MAX; ++i) { gp.q[i] = gp.q[n - 1]; }
   const uint32_t nblocks = end < 256u ? end : 256u;
@@ -1088,7 +1105,7 @@ extern "C" int dl_gemm_group(const dl_gemm_args* args, int32_t n, dl_stream stre
   if (bm == 256) hipLaunchKernelGGL((gemm_big_tt2_kernel<8, 2, 4, true, 32, 4, false, true>), dim3(nblocks), dim3(512), 0, s, gp);
   else hipLaunchKernelGGL((gemm_big_tt2_kernel<4, 2, 4, true, 64, 3, false, true>), dim3(nblocks), dim3(512), 0, s, gp);
   DL_CHECK_LAUNCH("dl_gemm_group");
-  dl_prof_after(0, s, flops, bytes);
+  dl_prof_after(0, s, flops, bytes, args[0].prof_tag);
   for (int i = 0; i < n; ++i) {
     const dl_gemm_args* a = &args[i];
     const int64_t mn = a->M * a->N;

@@ -232,6 +232,8 @@ class _Stream:
         self.w1T, self.w2T = lowp((w1,), cdt, True), lowp((w2,), cdt, True)
 
 
+from ._lib import TAG_QKV_OUT as _TAG_QKV_OUT, TAG_FFN as _TAG_FFN, TAG_CONV as _TAG_CONV, TAG_ADAPTOR as _TAG_ADAPTOR  # noqa: E402
+
 PAIR_GEMMS = os.environ.get("DL_PAIR_GEMMS", "1") != "0"     # A/B switch for tools: 0 = one launch per stream
 
 
@@ -269,8 +271,9 @@ class TransformerBlockFn(torch.autograd.Function):
             xn.append(y)
             stats1.append((mean, rstd))
         # the same layer of both streams leaves as one launch where the shapes allow it (_gemm_s -> dl_gemm_pair)
-        _gemm_s(xn, [st.qkv_w for st in streams], M=M, N=3 * d, K=d, bias=[st.qkv_b for st in streams],
-                out=[qkv[s] for s in range(S)])
+        with ops.prof_tag(_TAG_QKV_OUT):
+            _gemm_s(xn, [st.qkv_w for st in streams], M=M, N=3 * d, K=d, bias=[st.qkv_b for st in streams],
+                    out=[qkv[s] for s in range(S)])
         a = torch.empty((S, M, nseg * d), dtype=cdt, device=x.device)
         qs = (L * 3 * d, hd, 3 * d)
         os_ = (L * nseg * d, hd, nseg * d)
@@ -281,18 +284,20 @@ class TransformerBlockFn(torch.autograd.Function):
         out = torch.empty_like(x)
         saved: List[torch.Tensor] = [x, qkv, a, lse]
         seeds = [((ops.next_seed(), ops.next_seed()) if p_eff > 0 else (0, 0)) for _ in range(S)]
-        if paired:
-            f = _gemm_s([a[s] for s in range(S)], [st.fc_w for st in streams], M=M, N=d, K=2 * d, bias=[st.fc_b for st in streams])
-        else:
-            f = [a[s] for s in range(S)]
-        x1 = _gemm_s(f, [st.out_w for st in streams], M=M, N=d, K=d, bias=[st.out_b for st in streams], residual=xs)
+        with ops.prof_tag(_TAG_QKV_OUT):
+            if paired:
+                f = _gemm_s([a[s] for s in range(S)], [st.fc_w for st in streams], M=M, N=d, K=2 * d, bias=[st.fc_b for st in streams])
+            else:
+                f = [a[s] for s in range(S)]
+            x1 = _gemm_s(f, [st.out_w for st in streams], M=M, N=d, K=d, bias=[st.out_b for st in streams], residual=xs)
         ln2 = [ops.layernorm_fwd(x1[s], st.ln2w.detach(), st.ln2b.detach(), eps) for s, st in enumerate(streams)]
         hn = [t[0] for t in ln2]
         pre = [torch.empty((M, 4 * d), dtype=cdt, device=x.device) for _ in range(S)]
-        act = _gemm_s(hn, [st.w1 for st in streams], M=M, N=4 * d, K=d, bias=[st.b1 for st in streams], act=1, pre_out=pre,
-                      dropout_p=p_eff, seed=[sd[0] for sd in seeds])
-        _gemm_s(act, [st.w2 for st in streams], M=M, N=d, K=4 * d, bias=[st.b2 for st in streams], dropout_p=p_eff,
-                seed=[sd[1] for sd in seeds], residual=x1, out=[out[s].reshape(M, d) for s in range(S)])
+        with ops.prof_tag(_TAG_FFN):
+            act = _gemm_s(hn, [st.w1 for st in streams], M=M, N=4 * d, K=d, bias=[st.b1 for st in streams], act=1, pre_out=pre,
+                          dropout_p=p_eff, seed=[sd[0] for sd in seeds])
+            _gemm_s(act, [st.w2 for st in streams], M=M, N=d, K=4 * d, bias=[st.b2 for st in streams], dropout_p=p_eff,
+                    seed=[sd[1] for sd in seeds], residual=x1, out=[out[s].reshape(M, d) for s in range(S)])
         for s, st in enumerate(streams):
             saved += [xn[s], stats1[s][0], stats1[s][1], f[s], x1[s], hn[s], ln2[s][1], ln2[s][2], pre[s], act[s],
                       st.qkv_wT, st.out_wT, st.w1T, st.w2T, st.fc_wT if paired else st.out_wT,
@@ -320,13 +325,16 @@ class TransformerBlockFn(torch.autograd.Function):
         dys = [dout[s].reshape(M, d) for s in range(S)]
         g2 = [ops.dropout_apply(dys[s], p_eff, seeds[s][1]) if p_eff > 0 else dys[s] for s in range(S)]
         wg2 = [_wgrad(g2[s], act_[s], d, 4 * d, M, d, 4 * d) for s in range(S)]
-        g1 = _gemm_s(g2, w2_, M=M, N=4 * d, K=d, dact_pre=pre_, dropout_p=p_eff, seed=[seeds[s][0] for s in range(S)])
-        wg1 = [_wgrad(g1[s], hn_[s], 4 * d, d, M, 4 * d, d) for s in range(S)]
-        dhn = _gemm_s(g1, w1_, M=M, N=d, K=4 * d)
+        with ops.prof_tag(_TAG_FFN):
+            g1 = _gemm_s(g2, w2_, M=M, N=4 * d, K=d, dact_pre=pre_, dropout_p=p_eff, seed=[seeds[s][0] for s in range(S)])
+            wg1 = [_wgrad(g1[s], hn_[s], 4 * d, d, M, 4 * d, d) for s in range(S)]
+            dhn = _gemm_s(g1, w1_, M=M, N=d, K=4 * d)
         lnb = [ops.layernorm_bwd(dhn[s], x1_[s], mean2_[s], rstd2_[s], ln2w_[s], dres=dys[s]) for s in range(S)]
         dx1_all = [t[0] for t in lnb]
         wgo = [_wgrad(dx1_all[s], f_[s], d, d, M, d, d) for s in range(S)]
         grads_tail = []     # per stream: param grads produced after attention (fc/out/ln2/mlp)
+        _tag_qo = ops.prof_tag(_TAG_QKV_OUT)
+        _tag_qo.__enter__()
         if paired:
             df = _gemm_s(dx1_all, outw_, M=M, N=d, K=d)
             wgf = [_wgrad(df[s], a[s], d, 2 * d, M, d, 2 * d) for s in range(S)]
@@ -338,6 +346,7 @@ class TransformerBlockFn(torch.autograd.Function):
             _gemm_s(dx1_all, outw_, M=M, N=d, K=d, out=[da[s] for s in range(S)])
             for s in range(S):
                 grads_tail.append((wgo[s][0], wgo[s][1], lnb[s][1], lnb[s][2], wg1[s][0], wg1[s][1], wg2[s][0], wg2[s][1]))
+        _tag_qo.__exit__(None, None, None)
         # attention backward: dqkv [S, M, 3d]
         dqkv = torch.empty_like(qkv)
         qs = (L * 3 * d, hd, 3 * d)
@@ -349,7 +358,8 @@ class TransformerBlockFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         out_grads: List[Optional[torch.Tensor]] = []
         wgq = [_wgrad(dqkv[s], xn_[s], 3 * d, d, M, 3 * d, d) for s in range(S)]
-        dxn = _gemm_s([dqkv[s] for s in range(S)], qkvw_, M=M, N=d, K=3 * d)
+        with ops.prof_tag(_TAG_QKV_OUT):
+            dxn = _gemm_s([dqkv[s] for s in range(S)], qkvw_, M=M, N=d, K=3 * d)
         for s in range(S):
             dwqkv, dbqkv = wgq[s]
             _, dg1, dbt1 = ops.layernorm_bwd(dxn[s], x[s].reshape(M, d), SV[s][1], SV[s][2], SV[s][15], dres=dx1_all[s],
@@ -802,7 +812,8 @@ class ProteinCNNFn(torch.autograd.Function):
             Wg = _conv_weight(w, cdt, False)
             y = torch.empty((R, C), dtype=cdt, device=x.device)
             Mg = R - (k - 1)
-            ops.gemm(cur, Wg, M=Mg, N=C, K=k * C, ldx=C, bias=_f32(b), act=2, out=y[pl:pl + Mg])
+            with ops.prof_tag(_TAG_CONV):
+                ops.gemm(cur, Wg, M=Mg, N=C, K=k * C, ldx=C, bias=_f32(b), act=2, out=y[pl:pl + Mg])
             if training:
                 # batch statistics + nn.BatchNorm1d's running-stat update (momentum given) in one tiny launch
                 sums = ops.bn_stats(y, LP, _CNN_HALO, Lv)
@@ -846,8 +857,8 @@ class ProteinCNNFn(torch.autograd.Function):
             dz = dz.reshape(R, C)
         grads = [None] * 18
         dWgs = {}
-        with _maybe_deferring():            # the three weight gradients leave as one grouped launch (nothing below reads them
-          for i in (2, 1, 0):               #  before the block ends; their re-layout follows the block)
+        with _maybe_deferring(), ops.prof_tag(_TAG_CONV):   # the three weight gradients leave as one grouped launch (nothing below
+          for i in (2, 1, 0):                               #  reads them before the block ends; their re-layout follows the block)
               xin, y, mean, rstd, gamma = sv[i * 5:(i + 1) * 5]
               w = ctx.weights[i]
               k = w.shape[2]

@@ -76,6 +76,29 @@ _ws2 = _Workspace()  # second buffer so that two scratch users can be live insid
 # ------------------------------------------------------------------------------------------------
 # raw ops
 # ------------------------------------------------------------------------------------------------
+# Sub-family tag of the dl_gemm launches issued inside a `with prof_tag(T):` block (dl_gemm_args.prof_tag; timing hooks
+# only).  Weight-gradient products outside the ProteinCNN are tagged TAG_WGRAD whatever the block says.
+_prof_tag = 0
+
+
+class prof_tag:
+    __slots__ = ("tag", "prev")
+
+    def __init__(self, tag: int):
+        self.tag = tag
+
+    def __enter__(self):
+        global _prof_tag
+        self.prev = _prof_tag
+        _prof_tag = self.tag
+        return self
+
+    def __exit__(self, *exc):
+        global _prof_tag
+        _prof_tag = self.prev
+        return False
+
+
 def _gemm_args(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_kslow=False, w_kslow=False,
                ldx: Optional[int] = None, ldw: Optional[int] = None, bias=None, residual=None, res_row_mod=0,
                res_before_dropout=False, act=0, pre_out=None, dact_pre=None, dropout_p=0.0, seed=0, out=None,
@@ -111,6 +134,7 @@ def _gemm_args(x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, K: int, x_ks
     a.dropout_seed_offset = _seed_offset_ptr(x.device) if dropout_p > 0 else None
     a.algo = algo
     a.tile_tickets = _tickets_ptr(x.device)
+    a.prof_tag = _lib.TAG_WGRAD if (x_kslow and w_kslow and _prof_tag != _lib.TAG_CONV) else _prof_tag
     return a, out
 
 

@@ -119,7 +119,10 @@ typedef struct {
   dl_reduce_item* deferred;          /* NULL, or HOST pointer: a split-K call writes its slabs, describes the pending
                                         reduction here and does NOT launch it (kind = DL_REDUCE_NONE when the call took no
                                         split); the caller owns the workspace until dl_reduce_batch has run */
+  int32_t prof_tag;                  /* sub-family of this product for the timing hooks (dl_prof_collect_tag): DL_TAG_*;
+                                        no effect on the computation */
 } dl_gemm_args;
+enum { DL_TAG_OTHER = 0, DL_TAG_QKV_OUT = 1, DL_TAG_FFN = 2, DL_TAG_CONV = 3, DL_TAG_WGRAD = 4, DL_TAG_ADAPTOR = 5 };
 enum { DL_GEMM_ALGO_AUTO = 0, DL_GEMM_ALGO_TILE128 = 1 };
 
 size_t dl_gemm_workspace_bytes(const dl_gemm_args* a);
@@ -463,11 +466,18 @@ int dl_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * launches / total ms / total algorithmic flops / total algorithmic bytes since dl_prof_enable.
  * dl_prof_totals returns the count and algorithmic work of ALL launches of the family since
  * dl_prof_enable, timed or not.
+ * Algorithmic bytes of a dl_gemm launch: every DISTINCT operand byte once (an operand whose row pitch is smaller than
+ * its row length — the implicit-im2col convolutions — spans (rows - 1) * pitch + length elements), the output, and
+ * the epilogue's extra operands (pre_out, dact_pre, residual, bias, the read-back of an accumulating output).
  * ------------------------------------------------------------------------------------------ */
 int dl_prof_enable(int32_t family, int32_t on);
 int dl_prof_collect(int32_t family, int64_t* launches, double* total_ms, double* total_flops,
                     double* total_bytes);
 int dl_prof_totals(int32_t family, int64_t* launches, double* total_flops, double* total_bytes);
+/* The same per sub-family tag (dl_gemm_args.prof_tag) of a family: the timed launches' count / ms / algorithmic flops /
+ * algorithmic bytes, and the count / flops / bytes of ALL the tag's launches since dl_prof_enable. */
+int dl_prof_collect_tag(int32_t family, int32_t tag, int64_t* timed_launches, double* timed_ms, double* timed_flops,
+                        double* timed_bytes, int64_t* all_launches, double* all_flops, double* all_bytes);
 
 #ifdef __cplusplus
 }
