@@ -161,7 +161,7 @@ def main():
         (["cm"] if trainer.use_cm and ep >= trainer.cm_init_epoch else [])
     # cls, SSL-epoch and CM steps replay a hipGraph; eager: the epoch the CM head starts in (its loss weight is scaled on
     # the host there) and the global-batch CM form at N > 1 (object collectives)
-    graphed = use_graph and ("cm" not in kinds or (ep > trainer.cm_init_epoch and not (args.global_batch_cm and world > 1)))
+    graphed = use_graph and ("cm" not in kinds or ep > trainer.cm_init_epoch) and trainer.graphed_kind_ok("ssl" in kinds, "cm" in kinds)
 
     def sync():
         if world > 1:
@@ -184,6 +184,7 @@ def main():
             trainer.training_step(batch, meta=meta, cur_epoch=ep)
         sync()
         dt = time.perf_counter() - t0
+        trainer.check_device_flags()              # the padding guards of the compact forms (raises if one tripped)
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -259,7 +260,10 @@ def main():
                        # beyond the collate's Drug_Tokens) are computed once and expanded: same results as computing every row
                        # (tests/test_model_gpu.py); DL_GCN_COMPACT=0 DL_PAD_COMPACT=0 computes every row
                        "padding_rows": "computed once" if (os.environ.get("DL_GCN_COMPACT", "1") != "0" or
-                                                           os.environ.get("DL_PAD_COMPACT", "1") != "0") else "every row"},
+                                                           os.environ.get("DL_PAD_COMPACT", "1") != "0") else "every row",
+                       # the tiled protein sequences (period L + 2, utils.py:392-412) carry ~L + 31 distinct ProteinCNN rows of
+                       # 2304: the CNN runs on those (weighted BatchNorm, device-side periodicity guard); DL_CNN_COMPACT=0 = all
+                       "protein_cnn_rows": "distinct rows" if os.environ.get("DL_CNN_COMPACT", "1") != "0" else "every position"},
             # (the per-pair flop count of BASELINE.md section 3 is for 256 sites; not applicable to other lengths)
             "hot_path_tflops_per_gpu": round(value * HOT_FLOPS_PER_PAIR_STEP / world / 1e12, 2) if args.seq_len == 2304 else None,
             "hot_path_frac_of_peak": round(value * HOT_FLOPS_PER_PAIR_STEP / world / 1e12 / peak, 4) if args.seq_len == 2304 else None,

@@ -63,6 +63,7 @@ class GemmArgs(C.Structure):
     ]
 
 
+FLAG_PROT_PERIOD, FLAG_DRUG_TOKEN_PAD, FLAG_GCN_NODE_PAD = 1, 2, 4
 TAG_OTHER, TAG_QKV_OUT, TAG_FFN, TAG_CONV, TAG_WGRAD, TAG_ADAPTOR = 0, 1, 2, 3, 4, 5
 TAG_NAMES = {0: "other", 1: "qkv_out", 2: "ffn", 3: "conv", 4: "wgrad", 5: "adaptor"}
 
@@ -167,6 +168,14 @@ SIGNATURES = {
     "dl_triplet_sigcos_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_vp, c_f32, c_vp, c_vp, c_vp]),
     "dl_adamw_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32, c_vp,
                               c_i32, c_vp]),
+    "dl_bn_stats_rw": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "dl_bn_apply_fwd_rw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp]),
+    "dl_bn_bwd_reduce_rw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "dl_bn_bwd_apply_rw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp]),
+    "dl_embed_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp]),
+    "dl_rows_gather": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "dl_rows_sum_strided": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp]),
+    "dl_rows_equal_check": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i64, C.c_uint32, c_vp, c_vp]),
     "dl_prof_enable": (c_i32, [c_i32, c_i32]),
     "dl_prof_collect": (c_i32, [c_i32, C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),

@@ -49,7 +49,10 @@ def _stale(out, deps):
 # launches per hundred WHEN ANOTHER PROCESS LOADS THE GPU (tools/contention_repeat.py: 8-27 mismatching launches of 80,
 # always pass 1, lanes 48-63, even elements; 0 of 80 without the packed forms) — a timing-dependent forwarding hazard the
 # compiler does not pad.  Found through the two-rank graph-vs-eager bit-identity test.
-FILE_FLAGS = {"norm.hip": ["-fno-slp-vectorize"]}
+# bn.hip / elementwise.hip carry the same unpack-then-fp32 pattern (v_pk_*_f32 behind a bf16 unpack: 361 / 251 packed ops with
+# the vectoriser on) and are HBM-bound, so they get the flag too; gemm / attention keep the vectoriser
+# (their epilogues rely on the packed forms: 15.70 -> 16.36 ms without) and are covered by tests/test_contention_gpu.py.
+FILE_FLAGS = {"norm.hip": ["-fno-slp-vectorize"], "bn.hip": ["-fno-slp-vectorize"], "elementwise.hip": ["-fno-slp-vectorize"]}
 
 
 def _compile(src, force, objdir=OBJDIR, extra=()):

@@ -18,11 +18,19 @@ __device__ __forceinline__ bool row_valid(int64_t r, int64_t win, int64_t halo, 
   return q >= (uint32_t)halo && q < (uint32_t)(halo + valid);
 }
 
-// grid (ceil(C/256), chunks); lane -> 4 columns; MODE 0: (y, y^2); MODE 1: (dz, dz*yhat)
+// Row rule of every kernel below: rw == nullptr -> the window rule above (weight 1 for valid rows); else rw[r] is the row's
+// weight: < 0 halo row (excluded, written as zeros), 0 context row (computed, not part of the statistics), m >= 1 a row that
+// stands for m identical rows (the ProteinCNN compact layout, druglamp_amd/protein_plan.py).  -1 = excluded.
+__device__ __forceinline__ float row_weight(const float* __restrict__ rw, int64_t r, int64_t win, int64_t halo, int64_t valid) {
+  if (rw) return rw[r];
+  return row_valid(r, win, halo, valid) ? 1.f : -1.f;
+}
+
+// grid (ceil(C/256), chunks); lane -> 4 columns; MODE 0: (w y, w y^2); MODE 1: (dz, dz*yhat) over the rows with w >= 0
 template <typename T, int MODE>
 __global__ void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const float* __restrict__ mean,
                                   const float* __restrict__ rstd, int64_t R, int C, int64_t win, int64_t halo,
-                                  int64_t valid, float* __restrict__ partial, int rows_per_block) {
+                                  int64_t valid, const float* __restrict__ rw, float* __restrict__ partial, int rows_per_block) {
   __shared__ f32x4 red[2][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 256 + lane * 4;
@@ -33,9 +41,10 @@ __global__ void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__
     f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f};
     if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + c); rs = *reinterpret_cast<const f32x4*>(rstd + c); }
     for (int64_t r = r0 + wave; r < r1; r += 4) {
-      if (!row_valid(r, win, halo, valid)) continue;
+      const float wr = row_weight(rw, r, win, halo, valid);
+      if (MODE == 0 ? wr <= 0.f : wr < 0.f) continue;
       const f32x4 v = load4<T>(a + r * C + c);
-      if (MODE == 0) { s0 += v; s1 += v * v; }
+      if (MODE == 0) { const f32x4 t = v * wr; s0 += t; s1 += t * v; }      // (wr = 1: the plain sums, bit for bit)
       else {
         const f32x4 yv = load4<T>(y + r * C + c);
         s0 += v; s1 += v * ((yv - mu) * rs);
@@ -59,7 +68,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_wide_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ y,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               int64_t R, int C, int64_t win, int64_t halo, int64_t valid,
-                                                              float* __restrict__ partial, int rows_per_block) {
+                                                              const float* __restrict__ rw, float* __restrict__ partial, int rows_per_block) {
   __shared__ float red[2][256][8];
   const int tid = threadIdx.x;
   const int cpr = C >> 3, rpp = 256 / cpr;                  // chunks per row, rows per pass
@@ -76,10 +85,12 @@ __global__ __launch_bounds__(256) void bn_partial_wide_kernel(const bf16_t* __re
   for (int64_t r = r0 + rsub; r < r1; r += 4 * rpp) {
     u32x4 va[4], vy[4];
     bool ok[4];
+    float wr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t rr = r + (int64_t)u * rpp;
-      ok[u] = rr < r1 && row_valid(rr, win, halo, valid);
+      wr[u] = rr < r1 ? row_weight(rw, rr, win, halo, valid) : -1.f;
+      ok[u] = MODE == 0 ? wr[u] > 0.f : wr[u] >= 0.f;
       va[u] = u32x4{0u, 0u, 0u, 0u}; vy[u] = va[u];
       if (ok[u]) {
         va[u] = *reinterpret_cast<const u32x4*>(a + rr * C + c);
@@ -94,8 +105,8 @@ __global__ __launch_bounds__(256) void bn_partial_wide_kernel(const bf16_t* __re
       if (MODE == 1) unpack(vy[u], w);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        s0[e] += v[e];
-        s1[e] += MODE == 0 ? v[e] * v[e] : v[e] * ((w[e] - mu[e]) * rs[e]);
+        if (MODE == 0) { const float t = v[e] * wr[u]; s0[e] += t; s1[e] += t * v[e]; }     // (wr = 1: the plain sums, bit for bit)
+        else { s0[e] += v[e]; s1[e] += v[e] * ((w[e] - mu[e]) * rs[e]); }
       }
     }
   }
@@ -115,14 +126,14 @@ template <typename T>
 __global__ void bn_apply_fwd_kernel(const T* __restrict__ y, T* __restrict__ z, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, int64_t R, int C, int64_t win, int64_t halo,
-                                    int64_t valid) {
+                                    int64_t valid, const float* __restrict__ rw) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;          // R * C / 4 < 2^32 is checked by the host
   const uint32_t c4 = (uint32_t)C >> 2;
   if (i >= (uint32_t)R * c4) return;
   const int64_t r = i / c4;
   const int c = (int)(i - (uint32_t)r * c4) * 4;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
-  if (row_valid(r, win, halo, valid)) {
+  if (row_weight(rw, r, win, halo, valid) >= 0.f) {
     const f32x4 v = load4<T>(y + r * C + c);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
@@ -135,20 +146,23 @@ template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ sums, float inv_n, int relu_mask, T* __restrict__ dy,
-                                    int64_t R, int C, int64_t win, int64_t halo, int64_t valid) {
+                                    int64_t R, int C, int64_t win, int64_t halo, int64_t valid, const float* __restrict__ rw) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;          // R * C / 4 < 2^32 is checked by the host
   const uint32_t c4 = (uint32_t)C >> 2;
   if (i >= (uint32_t)R * c4) return;
   const int64_t r = i / c4;
   const int c = (int)(i - (uint32_t)r * c4) * 4;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
-  if (row_valid(r, win, halo, valid)) {
+  const float wr = row_weight(rw, r, win, halo, valid);
+  if (wr >= 0.f) {
     const f32x4 d = load4<T>(dz + r * C + c), yv = load4<T>(y + r * C + c);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
     const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c), s1 = *reinterpret_cast<const f32x4*>(sums + C + c);
     const f32x4 yh = (yv - mu) * rs;
-    o = g * rs * (d - s0 * inv_n - yh * (s1 * inv_n));
+    // a row that stands for wr identical rows takes the mean terms wr times (its dz is the sum over those rows)
+    if (rw) o = g * rs * (d - (s0 * inv_n + yh * (s1 * inv_n)) * wr);
+    else o = g * rs * (d - s0 * inv_n - yh * (s1 * inv_n));
     if (relu_mask) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = yv[e] > 0.f ? o[e] : 0.f;
@@ -175,7 +189,7 @@ template <int C>
 __global__ __launch_bounds__(256) void bn_apply_fwd_wide_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ z,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                int R, int win, int halo, int valid) {
+                                                                int R, int win, int halo, int valid, const float* __restrict__ rw) {
   constexpr int TPR = C / 8, RPB = 256 / TPR;              // threads per row, rows per block and pass
   const int c = (threadIdx.x % TPR) * 8, rsub = threadIdx.x / TPR;
   float a[8], b[8];
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_wide_kernel(const bf16_t* __
 #pragma unroll
     for (int u = 0; u < BN_WIDE_U; ++u) {
       const int r = r0 + u * stride;
-      ok[u] = r < R && row_valid(r, win, halo, valid);
+      ok[u] = r < R && row_weight(rw, r, win, halo, valid) >= 0.f;
       w[u] = u32x4{0u, 0u, 0u, 0u};
       if (ok[u]) w[u] = *reinterpret_cast<const u32x4*>(y + (int64_t)r * C + c);
     }
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_wide_kernel(const bf16_t* __
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ sums,
                                                                 float inv_n, int relu_mask, bf16_t* __restrict__ dy, int R, int win,
-                                                                int halo, int valid) {
+                                                                int halo, int valid, const float* __restrict__ rw) {
   constexpr int TPR = C / 8, RPB = 256 / TPR;
   const int c = (threadIdx.x % TPR) * 8, rsub = threadIdx.x / TPR;
   // dy = g*rs*(d - s0/n - yhat*s1/n), yhat = (y - mu)*rs   ->   dy = k0*d + k1*y + k2 per column
@@ -228,10 +242,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_wide_kernel(const bf16_t* __
   for (int r0 = blockIdx.x * RPB + rsub; r0 < R; r0 += stride * BN_WIDE_U) {
     u32x4 wd[BN_WIDE_U], wy[BN_WIDE_U];
     bool ok[BN_WIDE_U];
+    float wr[BN_WIDE_U];
 #pragma unroll
     for (int u = 0; u < BN_WIDE_U; ++u) {
       const int r = r0 + u * stride;
-      ok[u] = r < R && row_valid(r, win, halo, valid);
+      wr[u] = r < R ? row_weight(rw, r, win, halo, valid) : -1.f;
+      ok[u] = wr[u] >= 0.f;
       wd[u] = u32x4{0u, 0u, 0u, 0u}; wy[u] = wd[u];
       if (ok[u]) {
         wd[u] = *reinterpret_cast<const u32x4*>(dz + (int64_t)r * C + c);
@@ -250,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_wide_kernel(const bf16_t* __
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float yh = (yv[e] - mu[e]) * rs[e];                  // same operation order as bn_bwd_apply_kernel
-          float v = gr[e] * (d[e] - m0[e] - yh * m1[e]);
+          float v = rw ? gr[e] * (d[e] - (m0[e] + yh * m1[e]) * wr[u]) : gr[e] * (d[e] - m0[e] - yh * m1[e]);
           if (relu_mask) v = yv[e] > 0.f ? v : 0.f;
           d[e] = v;
         }
@@ -276,7 +292,7 @@ extern "C" size_t dl_bn_workspace_bytes(int64_t R, int64_t C) {
 
 template <int MODE>
 static int bn_reduce(const char* who, const void* a, const void* y, const float* mean, const float* rstd, int64_t R,
-                     int64_t C, int64_t win, int64_t halo, int64_t valid, int32_t dtype, float* sums, void* ws,
+                     int64_t C, int64_t win, int64_t halo, int64_t valid, const float* rw, int32_t dtype, float* sums, void* ws,
                      size_t ws_bytes, hipStream_t s) {
   DL_CHECK_ARG(a && sums && R > 0 && C > 0 && C % 4 == 0, DL_ERR_ARG, "%s: bad args", who);
   DL_CHECK_ARG(R < (1ll << 31), DL_ERR_SHAPE, "%s: R must fit 31 bits", who);
@@ -286,13 +302,13 @@ static int bn_reduce(const char* who, const void* a, const void* y, const float*
   dim3 grid((uint32_t)((C + 255) / 256), (uint32_t)chunks);
   if (dtype == DL_BF16 && (C == 64 || C == 128 || C == 256) && ((uintptr_t)a & 15) == 0 && (!y || ((uintptr_t)y & 15) == 0))
     hipLaunchKernelGGL((bn_partial_wide_kernel<MODE>), dim3(1, (uint32_t)chunks), dim3(256), 0, s, (const bf16_t*)a,
-                       (const bf16_t*)y, mean, rstd, R, (int)C, win, halo, valid, (float*)ws, rpb);
+                       (const bf16_t*)y, mean, rstd, R, (int)C, win, halo, valid, rw, (float*)ws, rpb);
   else if (dtype == DL_BF16)
     hipLaunchKernelGGL((bn_partial_kernel<bf16_t, MODE>), grid, dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)y,
-                       mean, rstd, R, (int)C, win, halo, valid, (float*)ws, rpb);
+                       mean, rstd, R, (int)C, win, halo, valid, rw, (float*)ws, rpb);
   else
     hipLaunchKernelGGL((bn_partial_kernel<float, MODE>), grid, dim3(256), 0, s, (const float*)a, (const float*)y, mean,
-                       rstd, R, (int)C, win, halo, valid, (float*)ws, rpb);
+                       rstd, R, (int)C, win, halo, valid, rw, (float*)ws, rpb);
   hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((2 * C + DL_REDUCE_COLS - 1) / DL_REDUCE_COLS)), dim3(1024), 0, s, (const float*)ws,
                      chunks, (int64_t)(2 * C), (int)(2 * C), sums, 0);
   DL_CHECK_LAUNCH(who);
@@ -301,7 +317,14 @@ static int bn_reduce(const char* who, const void* a, const void* y, const float*
 
 extern "C" int dl_bn_stats(const void* y, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid, int32_t dtype,
                            float* sums, void* workspace, size_t workspace_bytes, dl_stream stream) {
-  return bn_reduce<0>("dl_bn_stats", y, nullptr, nullptr, nullptr, R, C, win, halo, valid, dtype, sums, workspace,
+  return bn_reduce<0>("dl_bn_stats", y, nullptr, nullptr, nullptr, R, C, win, halo, valid, nullptr, dtype, sums, workspace,
+                      workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int dl_bn_stats_rw(const void* y, int64_t R, int64_t C, const float* row_w, int32_t dtype, float* sums,
+                              void* workspace, size_t workspace_bytes, dl_stream stream) {
+  DL_CHECK_ARG(row_w, DL_ERR_ARG, "dl_bn_stats_rw: null row weights");
+  return bn_reduce<0>("dl_bn_stats_rw", y, nullptr, nullptr, nullptr, R, C, 0, 0, 0, row_w, dtype, sums, workspace,
                       workspace_bytes, (hipStream_t)stream);
 }
 
@@ -309,13 +332,21 @@ extern "C" int dl_bn_bwd_reduce(const void* dz, const void* y, const float* mean
                                 int64_t win, int64_t halo, int64_t valid, int32_t dtype, float* sums, void* workspace,
                                 size_t workspace_bytes, dl_stream stream) {
   DL_CHECK_ARG(y && mean && rstd, DL_ERR_ARG, "dl_bn_bwd_reduce: null pointer");
-  return bn_reduce<1>("dl_bn_bwd_reduce", dz, y, mean, rstd, R, C, win, halo, valid, dtype, sums, workspace,
+  return bn_reduce<1>("dl_bn_bwd_reduce", dz, y, mean, rstd, R, C, win, halo, valid, nullptr, dtype, sums, workspace,
                       workspace_bytes, (hipStream_t)stream);
 }
 
-extern "C" int dl_bn_apply_fwd(const void* y, void* z, const float* mean, const float* rstd, const float* gamma,
-                               const float* beta, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid,
-                               int32_t dtype, dl_stream stream) {
+extern "C" int dl_bn_bwd_reduce_rw(const void* dz, const void* y, const float* mean, const float* rstd, int64_t R, int64_t C,
+                                   const float* row_w, int32_t dtype, float* sums, void* workspace, size_t workspace_bytes,
+                                   dl_stream stream) {
+  DL_CHECK_ARG(y && mean && rstd && row_w, DL_ERR_ARG, "dl_bn_bwd_reduce_rw: null pointer");
+  return bn_reduce<1>("dl_bn_bwd_reduce_rw", dz, y, mean, rstd, R, C, 0, 0, 0, row_w, dtype, sums, workspace,
+                      workspace_bytes, (hipStream_t)stream);
+}
+
+static int bn_apply_fwd_run(const void* y, void* z, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid,
+                            const float* rw, int32_t dtype, dl_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   DL_CHECK_ARG(R < (1ll << 31) && R * (C / 4) < (1ll << 32), DL_ERR_SHAPE, "dl_bn_apply_fwd: R * C / 4 must fit 32 bits");
   DL_CHECK_ARG(y && z && mean && rstd && gamma && beta && R > 0 && C > 0 && C % 4 == 0, DL_ERR_ARG,
@@ -325,22 +356,34 @@ extern "C" int dl_bn_apply_fwd(const void* y, void* z, const float* mean, const 
   const bool wide = dtype == DL_BF16 && (C == 64 || C == 128 || C == 256) && (((uintptr_t)y | (uintptr_t)z) & 15) == 0;
   if (wide) {
     const uint32_t wb = bn_wide_blocks(R, (int)C);
-    if (C == 64) hipLaunchKernelGGL((bn_apply_fwd_wide_kernel<64>), dim3(wb), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean, rstd, gamma, beta, (int)R, (int)win, (int)halo, (int)valid);
-    else if (C == 128) hipLaunchKernelGGL((bn_apply_fwd_wide_kernel<128>), dim3(wb), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean, rstd, gamma, beta, (int)R, (int)win, (int)halo, (int)valid);
-    else hipLaunchKernelGGL((bn_apply_fwd_wide_kernel<256>), dim3(wb), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean, rstd, gamma, beta, (int)R, (int)win, (int)halo, (int)valid);
+    if (C == 64) hipLaunchKernelGGL((bn_apply_fwd_wide_kernel<64>), dim3(wb), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean, rstd, gamma, beta, (int)R, (int)win, (int)halo, (int)valid, rw);
+    else if (C == 128) hipLaunchKernelGGL((bn_apply_fwd_wide_kernel<128>), dim3(wb), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean, rstd, gamma, beta, (int)R, (int)win, (int)halo, (int)valid, rw);
+    else hipLaunchKernelGGL((bn_apply_fwd_wide_kernel<256>), dim3(wb), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean, rstd, gamma, beta, (int)R, (int)win, (int)halo, (int)valid, rw);
   } else if (dtype == DL_BF16)
     hipLaunchKernelGGL((bn_apply_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean,
-                       rstd, gamma, beta, R, (int)C, win, halo, valid);
+                       rstd, gamma, beta, R, (int)C, win, halo, valid, rw);
   else
     hipLaunchKernelGGL((bn_apply_fwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)y, (float*)z, mean,
-                       rstd, gamma, beta, R, (int)C, win, halo, valid);
+                       rstd, gamma, beta, R, (int)C, win, halo, valid, rw);
   DL_CHECK_LAUNCH("dl_bn_apply_fwd");
   return DL_OK;
 }
 
-extern "C" int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean, const float* rstd, const float* gamma,
-                               const float* sums, float inv_n, int32_t relu_mask, void* dy, int64_t R, int64_t C,
-                               int64_t win, int64_t halo, int64_t valid, int32_t dtype, dl_stream stream) {
+extern "C" int dl_bn_apply_fwd(const void* y, void* z, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid,
+                               int32_t dtype, dl_stream stream) {
+  return bn_apply_fwd_run(y, z, mean, rstd, gamma, beta, R, C, win, halo, valid, nullptr, dtype, stream);
+}
+
+extern "C" int dl_bn_apply_fwd_rw(const void* y, void* z, const float* mean, const float* rstd, const float* gamma,
+                                  const float* beta, int64_t R, int64_t C, const float* row_w, int32_t dtype, dl_stream stream) {
+  DL_CHECK_ARG(row_w, DL_ERR_ARG, "dl_bn_apply_fwd_rw: null row weights");
+  return bn_apply_fwd_run(y, z, mean, rstd, gamma, beta, R, C, 0, 0, 0, row_w, dtype, stream);
+}
+
+static int bn_bwd_apply_run(const void* dz, const void* y, const float* mean, const float* rstd, const float* gamma,
+                            const float* sums, float inv_n, int32_t relu_mask, void* dy, int64_t R, int64_t C,
+                            int64_t win, int64_t halo, int64_t valid, const float* rw, int32_t dtype, dl_stream stream) {
   hipStream_t s = (hipStream_t)stream;
   DL_CHECK_ARG(R < (1ll << 31) && R * (C / 4) < (1ll << 32), DL_ERR_SHAPE, "dl_bn_bwd_apply: R * C / 4 must fit 32 bits");
   DL_CHECK_ARG(dz && y && mean && rstd && gamma && sums && dy && R > 0 && C > 0 && C % 4 == 0, DL_ERR_ARG,
@@ -350,17 +393,30 @@ extern "C" int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean,
   const bool wide = dtype == DL_BF16 && (C == 64 || C == 128 || C == 256) && (((uintptr_t)y | (uintptr_t)dz | (uintptr_t)dy) & 15) == 0;
   if (wide) {
     const uint32_t wb = bn_wide_blocks(R, (int)C);
-    if (C == 64) hipLaunchKernelGGL((bn_bwd_apply_wide_kernel<64>), dim3(wb), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, (int)R, (int)win, (int)halo, (int)valid);
-    else if (C == 128) hipLaunchKernelGGL((bn_bwd_apply_wide_kernel<128>), dim3(wb), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, (int)R, (int)win, (int)halo, (int)valid);
-    else hipLaunchKernelGGL((bn_bwd_apply_wide_kernel<256>), dim3(wb), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, (int)R, (int)win, (int)halo, (int)valid);
+    if (C == 64) hipLaunchKernelGGL((bn_bwd_apply_wide_kernel<64>), dim3(wb), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, (int)R, (int)win, (int)halo, (int)valid, rw);
+    else if (C == 128) hipLaunchKernelGGL((bn_bwd_apply_wide_kernel<128>), dim3(wb), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, (int)R, (int)win, (int)halo, (int)valid, rw);
+    else hipLaunchKernelGGL((bn_bwd_apply_wide_kernel<256>), dim3(wb), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, (int)R, (int)win, (int)halo, (int)valid, rw);
   } else if (dtype == DL_BF16)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y,
-                       mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, R, (int)C, win, halo, valid);
+                       mean, rstd, gamma, sums, inv_n, relu_mask, (bf16_t*)dy, R, (int)C, win, halo, valid, rw);
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)dz, (const float*)y,
-                       mean, rstd, gamma, sums, inv_n, relu_mask, (float*)dy, R, (int)C, win, halo, valid);
+                       mean, rstd, gamma, sums, inv_n, relu_mask, (float*)dy, R, (int)C, win, halo, valid, rw);
   DL_CHECK_LAUNCH("dl_bn_bwd_apply");
   return DL_OK;
+}
+
+extern "C" int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean, const float* rstd, const float* gamma,
+                               const float* sums, float inv_n, int32_t relu_mask, void* dy, int64_t R, int64_t C,
+                               int64_t win, int64_t halo, int64_t valid, int32_t dtype, dl_stream stream) {
+  return bn_bwd_apply_run(dz, y, mean, rstd, gamma, sums, inv_n, relu_mask, dy, R, C, win, halo, valid, nullptr, dtype, stream);
+}
+
+extern "C" int dl_bn_bwd_apply_rw(const void* dz, const void* y, const float* mean, const float* rstd, const float* gamma,
+                                  const float* sums, float inv_n, int32_t relu_mask, void* dy, int64_t R, int64_t C,
+                                  const float* row_w, int32_t dtype, dl_stream stream) {
+  DL_CHECK_ARG(row_w, DL_ERR_ARG, "dl_bn_bwd_apply_rw: null row weights");
+  return bn_bwd_apply_run(dz, y, mean, rstd, gamma, sums, inv_n, relu_mask, dy, R, C, 0, 0, 0, row_w, dtype, stream);
 }
 
 // ---- weighted tail rows (MolecularGCN's compact padding form) ------------------------------------------------------

@@ -114,8 +114,8 @@ class RowTable:
             y = r[:, 2].to(self.device, dtype=torch.float32)
             llm_d = self.drug_store.batch(r[:, 0].tolist(), 512, repeat=False)
             llm_p = self.prot_store.batch(r[:, 1].tolist(), self.seq_len, repeat=True)
-            meta = [{"Drug_ID": int(a), "Prot_ID": int(b), "Y": float(c), "Drug_Tokens": self.drug_store.length(int(a))}
-                    for a, b, c in r.tolist()]
+            meta = [{"Drug_ID": int(a), "Prot_ID": int(b), "Y": float(c), "Drug_Tokens": self.drug_store.length(int(a)),
+                     "Prot_Len": int(self.prot_len[int(b)])} for a, b, c in r.tolist()]
             yield (feat_d, vp, y, llm_d, llm_p), meta
 
     def batches_only(self, split: str, batch_size: int, **kw):

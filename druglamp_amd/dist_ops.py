@@ -53,9 +53,39 @@ def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
 
 
 def all_gather_meta(meta: List[dict]) -> List[dict]:
-    """Rank-ordered concatenation of the per-sample meta dicts (ids may be strings)."""
+    """Rank-ordered concatenation of the per-sample meta dicts (ids may be strings).  A host pickle collective: NOT on the
+    training step since round 4 (the global-batch CM head gathers integer id codes as a tensor, id_codes / all_gather_codes);
+    kept for tools and tests that want the records themselves."""
     if world_size() == 1:
         return list(meta)
     out = [None] * world_size()
     dist.all_gather_object(out, list(meta))
     return [m for part in out for m in part]
+
+
+def id_code(v) -> int:
+    """A stable 63-bit integer for an entity id (ints map to themselves; strings through blake2b — equal ids give equal
+    codes on every rank and in every process, unlike Python's salted hash())."""
+    if isinstance(v, (int,)) and not isinstance(v, bool) and 0 <= int(v) < (1 << 62):
+        return int(v)
+    import hashlib
+    h = hashlib.blake2b(repr(v).encode() if not isinstance(v, str) else v.encode(), digest_size=8).digest()
+    return (int.from_bytes(h, "little") & ((1 << 62) - 1)) | (1 << 62)       # disjoint from the small-int range
+
+
+def id_codes(meta: List[dict]):
+    """(n, 3) int64 numpy array: prot code, drug code, label (0 / 1) per sample — what the global-batch CM head gathers."""
+    import numpy as np
+    out = np.empty((len(meta), 3), dtype=np.int64)
+    for t, m in enumerate(meta):
+        out[t, 0], out[t, 1], out[t, 2] = id_code(m["Prot_ID"]), id_code(m["Drug_ID"]), int(m["Y"])
+    return out
+
+
+def all_gather_codes(codes: torch.Tensor) -> torch.Tensor:
+    """(n, 3) int64 on every rank -> (world * n, 3), rank-ordered: ONE tensor collective (capturable on RCCL)."""
+    if world_size() == 1:
+        return codes
+    out = torch.empty((world_size() * codes.shape[0], codes.shape[1]), dtype=codes.dtype, device=codes.device)
+    dist.all_gather_into_tensor(out, codes.contiguous())
+    return out

@@ -796,13 +796,23 @@ class ProteinCNNFn(torch.autograd.Function):
     elementwise pass that also re-zeroes the halo rows.  Returns (z [B, L, C] view, batch mean/var x3)."""
 
     @staticmethod
-    def forward(ctx, x, training, eps, pool_site_len, momenta, raw_dx, *params):
-        B, LP, C = x.shape
-        Lv = LP - 2 * _CNN_HALO
-        R = B * LP
+    def forward(ctx, x, training, eps, pool_site_len, momenta, raw_dx, rw, n_stat, *params):
+        """rw (R,) fp32 row weights + n_stat (round 4, the compact layout of protein_plan.py): x is then (R, C) — segments of
+        distinct positions with their own halo rows; rw < 0 marks the halo rows, rw = m >= 1 a row that stands for m
+        positions of the reference's layout (BatchNorm multiplicity), n_stat the BatchNorm row count (B * L).  The
+        convolutions are the same GEMMs over overlapping rows; pool_site_len must be 0 (the caller expands the rows)."""
+        if rw is not None:
+            if x.dim() != 2 or pool_site_len:
+                raise ValueError("ProteinCNNFn: the compact layout takes a (R, C) input and no fused pooling")
+            (R, C), B, LP, Lv = x.shape, 1, x.shape[0], 0
+            n = int(n_stat)
+        else:
+            B, LP, C = x.shape
+            Lv = LP - 2 * _CNN_HALO
+            R = B * LP
+            n = B * Lv
         cdt = x.dtype
         x2 = x.reshape(R, C)
-        n = B * Lv
         saved, stats_out, meta = [], [], []
         cur = x2
         for i in range(3):
@@ -816,22 +826,25 @@ class ProteinCNNFn(torch.autograd.Function):
                 ops.gemm(cur, Wg, M=Mg, N=C, K=k * C, ldx=C, bias=_f32(b), act=2, out=y[pl:pl + Mg])
             if training:
                 # batch statistics + nn.BatchNorm1d's running-stat update (momentum given) in one tiny launch
-                sums = ops.bn_stats(y, LP, _CNN_HALO, Lv)
+                sums = ops.bn_stats(y, LP, _CNN_HALO, Lv, rw)
                 upd = momenta is not None and rmean.dtype == torch.float32
                 mean, var, rstd = ops.bn_finalize(sums, n, eps, momenta[i] if upd else 0.0,
                                                   rmean.detach() if upd else None, rvar.detach() if upd else None)
             else:
                 mean, var = rmean.detach().float(), rvar.detach().float()
                 rstd = torch.rsqrt(var + eps)
-            z = ops.bn_apply_fwd(y, mean, rstd, gamma.detach().float(), beta.detach().float(), LP, _CNN_HALO, Lv)
+            z = ops.bn_apply_fwd(y, mean, rstd, gamma.detach().float(), beta.detach().float(), LP, _CNN_HALO, Lv, rw)
             saved += [cur, y, mean, rstd, gamma.detach().float()]
             stats_out += [mean, var]
             meta.append((k, pl, w))
             cur = z
         ctx.save_for_backward(*saved)
-        ctx.cfg = (B, LP, C, Lv, training, pool_site_len, raw_dx)
+        ctx.cfg = (B, LP, C, Lv, training, pool_site_len, raw_dx, n)
         ctx.weights = [m[2] for m in meta]
-        if pool_site_len:
+        ctx.rw = rw
+        if rw is not None:
+            out = cur                                  # (R, C) compact rows; ExpandRowsFn maps them to positions
+        elif pool_site_len:
             # the reference's (B,C,L).view(B,L,C) reinterpretation + site pooling, straight from the padded buffer
             out = ops.cnn_sitepool_fwd(cur.reshape(B, LP, C), Lv, _CNN_HALO, pool_site_len)
         else:
@@ -842,14 +855,16 @@ class ProteinCNNFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, *_):
-        B, LP, C, Lv, training, pool_site_len, raw_dx = ctx.cfg
+        B, LP, C, Lv, training, pool_site_len, raw_dx, n = ctx.cfg
         if not training:
             raise RuntimeError("ProteinCNNFn.backward is only implemented for training-mode BatchNorm")
         sv = ctx.saved_tensors
         R = B * LP
-        n = B * Lv
+        rw = ctx.rw
         cdt = sv[0].dtype
-        if pool_site_len:
+        if rw is not None:
+            dz = dout.contiguous()                     # (R, C): a representative's gradient is the sum over its positions
+        elif pool_site_len:
             dz = ops.cnn_sitepool_bwd(dout, Lv, _CNN_HALO, pool_site_len).reshape(R, C)
         else:
             dz = torch.zeros((B, LP, C), dtype=cdt, device=dout.device)
@@ -865,8 +880,8 @@ class ProteinCNNFn(torch.autograd.Function):
               pl = (k - 1) // 2
               pr = k - 1 - pl
               Mg = R - (k - 1)
-              sums = ops.bn_bwd_reduce(dz, y, mean, rstd, LP, _CNN_HALO, Lv)
-              dpre = ops.bn_bwd_apply(dz, y, mean, rstd, gamma, sums, 1.0 / n, True, LP, _CNN_HALO, Lv)
+              sums = ops.bn_bwd_reduce(dz, y, mean, rstd, LP, _CNN_HALO, Lv, rw)
+              dpre = ops.bn_bwd_apply(dz, y, mean, rstd, gamma, sums, 1.0 / n, True, LP, _CNN_HALO, Lv, rw)
               # rows outside [pl, pl + Mg) are halo rows (zero in dpre), so the bias gradient can ride along
               dWgs[i], dbias = _wgrad(dpre[pl:pl + Mg], xin, C, k * C, Mg, C, C)
               grads[i * 6 + 1] = dbias
@@ -884,12 +899,14 @@ class ProteinCNNFn(torch.autograd.Function):
             grads[i * 6 + 0] = dWg.reshape(C, ctx.weights[i].shape[2], C).permute(0, 2, 1).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            if raw_dx:
+            if rw is not None:
+                dx = dz                          # (R, C); halo rows hold finite junk; EmbedRowsFn ignores them
+            elif raw_dx:
                 dx = dz.reshape(B, LP, C)        # halo rows hold finite junk; EmbedPadFn ignores them
             else:
                 dx = torch.zeros((B, LP, C), dtype=cdt, device=dout.device)
                 dx[:, _CNN_HALO:_CNN_HALO + Lv] = dz.reshape(B, LP, C)[:, _CNN_HALO:_CNN_HALO + Lv]
-        return (dx, None, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None, None, None) + tuple(grads)
 
 
 
@@ -1082,6 +1099,69 @@ class EmbedPadFn(torch.autograd.Function):
         return None, dw, None, None
 
 
+class EmbedRowsFn(torch.autograd.Function):
+    """ProteinCNN input on distinct rows (round 4): compact rows [embedding | fill bit] through the plan's `src` table, zero
+    halo rows; the same launch checks the batch's periodic structure on the device (plan.period).  Backward: the one-hot
+    GEMM of EmbedPadFn over the compact rows (a representative's gradient already is the sum over its positions)."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, fill, padding_idx, src, period):
+        ctx.save_for_backward(ids, src)
+        ctx.wshape = tuple(weight.shape)
+        ctx.padding_idx = padding_idx
+        return ops.embed_rows(ids, weight.detach(), fill, src, period)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, src = ctx.saved_tensors
+        V, D = ctx.wshape
+        R, C = dy.shape
+        Vp = (V + 7) // 8 * 8
+        cdt = dy.dtype
+        srcl = src.long()
+        tok = ids.reshape(-1)[srcl.clamp(min=0)]
+        onehot = torch.zeros((R, Vp), dtype=cdt, device=dy.device)
+        onehot.scatter_(1, tok.unsqueeze(1), (srcl >= 0).to(cdt).unsqueeze(1))
+        g = dy.contiguous()
+        dw = ops.gemm(onehot, g, M=Vp, N=C, K=R, x_kslow=True, w_kslow=True, ldx=Vp, ldw=C, out_dtype=torch.float32, split_k=0)
+        dw = dw[:V, :D]
+        if ctx.padding_idx is not None:
+            dw[ctx.padding_idx].zero_()
+        return None, dw, None, None, None, None
+
+
+class ExpandRowsFn(torch.autograd.Function):
+    """(R, C) compact rows -> (N, C): out[i] = z[row_of[i]] (dl_rows_gather).  Backward: a compact row's gradient is the sum
+    over the positions it stands for — arithmetic progressions recorded in the plan's `rep` table (dl_rows_sum_strided:
+    fixed order, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, z, row_of, rep):
+        ctx.save_for_backward(rep)
+        return ops.rows_gather(z, row_of)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (rep,) = ctx.saved_tensors
+        return ops.rows_sum_strided(dout.contiguous(), rep), None, None
+
+
+class SitePoolFn(torch.autograd.Function):
+    """The reference's (B, C, L).view(B, L, C) reinterpretation + site pooling (basic_model.py:179, DrugLAMP.py:35-40) of a
+    channel-last (B, L, C) activation without halo rows: dl_cnn_sitepool_fwd / _bwd with halo = 0."""
+
+    @staticmethod
+    def forward(ctx, z, site_len):
+        B, L, C = z.shape
+        ctx.cfg = (L, site_len)
+        return ops.cnn_sitepool_fwd(z.contiguous(), L, 0, site_len)
+
+    @staticmethod
+    def backward(ctx, dout):
+        L, site_len = ctx.cfg
+        return ops.cnn_sitepool_bwd(dout, L, 0, site_len), None
+
+
 class BatchNormRowsFn(torch.autograd.Function):
     """BatchNorm1d over the rows of a [R][C] matrix (training: batch statistics) on the dl_bn_* kernels.
     Returns (y, mean, var) with biased variance; running-stat bookkeeping stays with the caller."""
@@ -1156,32 +1236,6 @@ class BatchNormWeightedTailFn(torch.autograd.Function):
         # tail rows: dx = sum over the w copies of g rstd (dy_copy - mean_dy - xhat mean_dyxhat): the mean terms w times
         ops.bn_tail_fix(dx, x, mean, rstd, g, sums, 1.0 / n, w, LP, lead)
         return dx, sums[C:], sums[:C], None, None, None, None, None, None, None
-
-
-# Padding hints: host-side knowledge about the batch that the tensors themselves do not carry (the collate knows every
-# molecule's token count; the padded (B, 512, .) tensor does not say where the zero rows start).  Set by the trainer around
-# the model forward; a model that finds no hint computes every row.
-_pad_hints = {}
-
-
-class padding_hints:
-    def __init__(self, **hints):
-        self.hints = {k: v for k, v in hints.items() if v}
-
-    def __enter__(self):
-        global _pad_hints
-        self.prev = _pad_hints
-        _pad_hints = dict(self.prev, **self.hints)
-        return self
-
-    def __exit__(self, *exc):
-        global _pad_hints
-        _pad_hints = self.prev
-        return False
-
-
-def padding_hint(name: str):
-    return _pad_hints.get(name)
 
 
 class ExpandTailFn(torch.autograd.Function):

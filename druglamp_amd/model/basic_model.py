@@ -22,6 +22,8 @@ from .PGCA import GuidedCrossAttention
 from .PMMA import MultiHeadLinearAttention, PairedMultimodelAttention
 from .self_supervised_learning import SSL
 
+from .._lib import FLAG_DRUG_TOKEN_PAD as _FLAG_TOK, FLAG_GCN_NODE_PAD as _FLAG_GCN   # noqa: E402
+
 CONFIGS = {"LAMP": get_model_defaults}
 
 
@@ -120,7 +122,8 @@ class MolecularGCN(nn.Module):
         self.in_feats = in_feats
         self.compute_dtype = torch.float32
         self.compact_padding = os.environ.get("DL_GCN_COMPACT", "1") != "0"    # A/B switch for tools
-        self.check_padding = os.environ.get("DL_GCN_CHECK", "0") == "1"         # debug: verify the padding rows (host sync)
+        self.check_padding = os.environ.get("DL_GCN_CHECK", "0") == "1"         # debug: verify the padding rows on the host (sync)
+        self.guard_padding = os.environ.get("DL_PAD_GUARD", "1") != "0"         # device-side check of the padding rows (no sync)
         self.compact_min_rows = int(os.environ.get("DL_GCN_COMPACT_MIN_ROWS", "4096"))   # padding rows saved per batch
 
     def forward(self, batch_graph):
@@ -145,6 +148,10 @@ class MolecularGCN(nn.Module):
         # (measured down to 32 molecules per batch: 4.16 -> 4.10 ms; tiny batches keep the plain form)
         if (self.compact_padding and N - Nr >= 2 * TAIL and (N - Nr) % TAIL == 0 and node_feats.is_cuda and
                 B * (N - Nr - TAIL) >= self.compact_min_rows):
+            if self.guard_padding:
+                # device-side guard (round 4): one pass over the padding nodes; a node that differs sets a sticky flag
+                # word that the trainer polls (ops.check_guard_flags) — a malformed batch is an error, not silent garbage
+                ops.rows_equal_check(node_feats, Nr, _FLAG_GCN)
             if self.check_padding:
                 pad = node_feats[:, Nr:]
                 if not bool((pad == pad[:1, :1]).all()):
@@ -173,25 +180,45 @@ class ProteinCNN(nn.Module):
 
     compute_dtype = torch.float32
 
-    def forward(self, v, fill_mask, site_pool=0):
+    def forward(self, v, fill_mask, site_pool=0, plan=None):
         """Embedding lookup + fill bit are torch glue; the three Conv1d + ReLU + BatchNorm1d stages run as
         channel-last implicit GEMMs + BatchNorm kernels (functional.ProteinCNNFn).  The reference's final
         `.view(B, L, C)` of the channel-first (B, C, L) buffer is reproduced exactly.  site_pool = site_len (> 0)
         additionally applies the caller's site pooling (DrugLAMP.py:39-40) inside the same kernel and returns
-        (B, L // site_len, C)."""
-        from ..functional import EmbedPadFn, ProteinCNNFn, cast
+        (B, L // site_len, C).
+        plan (protein_plan.PlanDev, round 4): the batch's distinct-row tables — the sequences are tiled with period L + 2
+        (utils.py:392-412), so only ~L + 31 of the 2304 positions of a sample have distinct outputs; the network runs on
+        those rows (BatchNorm weighted by the multiplicities) and the result is expanded: same values, ~3.5x fewer rows.
+        The tiling is verified on the device (ops.guard_flags)."""
+        from ..functional import EmbedPadFn, EmbedRowsFn, ExpandRowsFn, ProteinCNNFn, SitePoolFn, cast
         ids = v.long()
         w = self.embedding.weight
         wc = cast(w, self.compute_dtype) if w.requires_grad else w.detach().to(self.compute_dtype)
-        x = EmbedPadFn.apply(ids, wc, fill_mask, self.embedding.padding_idx)        # (B, L + 2*HALO, C) channel-last
         B, L = ids.shape
-        C = x.shape[-1]
         params = []
         for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)):
             params += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        fused_pool = int(site_pool) if (site_pool and x.dtype == torch.bfloat16 and L % int(site_pool) == 0) else 0
         momenta = (self.bn1.momentum, self.bn2.momentum, self.bn3.momentum) if self.training else None
-        outs = ProteinCNNFn.apply(x, self.training, self.bn1.eps, fused_pool, momenta, True, *params)
+        if plan is not None:
+            if (plan.B, plan.S) != (B, L):
+                raise ValueError("ProteinCNN: the plan is for a (%d, %d) batch, the ids are (%d, %d)" % (plan.B, plan.S, B, L))
+            x = EmbedRowsFn.apply(ids, wc, fill_mask, self.embedding.padding_idx, plan.src, plan.period)     # (R, C) compact rows
+            C = x.shape[-1]
+            outs = ProteinCNNFn.apply(x, self.training, self.bn1.eps, 0, momenta, True, plan.w, plan.n, *params)
+            if self.training:
+                for bn in (self.bn1, self.bn2, self.bn3):
+                    Fn.bn_tick(bn.num_batches_tracked)
+            z = ExpandRowsFn.apply(outs[0], plan.row_of, plan.rep).view(B, L, C)      # channel-last, every position
+            if site_pool and z.dtype == torch.bfloat16 and L % int(site_pool) == 0:
+                return SitePoolFn.apply(z, int(site_pool))
+            z = z.transpose(1, 2).contiguous().view(B, L, C)
+            if site_pool:
+                z = z.view(B, int(site_pool), L // int(site_pool), C).mean(dim=1)
+            return z
+        x = EmbedPadFn.apply(ids, wc, fill_mask, self.embedding.padding_idx)        # (B, L + 2*HALO, C) channel-last
+        C = x.shape[-1]
+        fused_pool = int(site_pool) if (site_pool and x.dtype == torch.bfloat16 and L % int(site_pool) == 0) else 0
+        outs = ProteinCNNFn.apply(x, self.training, self.bn1.eps, fused_pool, momenta, True, None, 0, *params)
         z = outs[0]
         if self.training:
             for bn in (self.bn1, self.bn2, self.bn3):
@@ -246,7 +273,9 @@ class DrugLAMPBase(nn.Module):
         self.seq_len_q = cfg["PROTEIN"]["SEQ_LEN"]
         dec = cfg["DECODER"]
         self.compact_padding = os.environ.get("DL_PAD_COMPACT", "1") != "0"      # A/B switch: compact padding rows of the drug LLM adaptor
-        self.check_padding = os.environ.get("DL_PAD_CHECK", "0") == "1"         # debug: verify the padding rows (host sync)
+        self.check_padding = os.environ.get("DL_PAD_CHECK", "0") == "1"         # debug: verify the padding rows on the host (sync)
+        self.guard_padding = os.environ.get("DL_PAD_GUARD", "1") != "0"         # device-side check of the padding rows (no sync)
+        self.compact_cnn = os.environ.get("DL_CNN_COMPACT", "1") != "0"         # A/B switch: ProteinCNN on distinct rows
         self.drug_extractor = MolecularGCN(in_feats=cfg["DRUG"]["NODE_IN_FEATS"], dim_embedding=n_hidden,
                                            padding=cfg["DRUG"]["PADDING"], hidden_feats=[n_hidden] * 3)
         self.protein_extractor = ProteinCNN(n_hidden, [n_hidden] * 3, cfg["PROTEIN"]["KERNEL_SIZE"],
@@ -331,7 +360,7 @@ class DrugLAMPBase(nn.Module):
         m = Fn.layer_norm(m, norm.weight, norm.bias, norm.eps)
         return m, raw
 
-    def _llm_adaptors(self, xp_cat, xd_cat):
+    def _llm_adaptors(self, xp_cat, xd_cat, drug_tokens: int = 0):
         """xp_cat: site-pooled protein LLM features + fill bit, zero-padded (B, 256, 648); xd_cat: drug LLM
         features + fill bit, zero-padded (B, 512, 392) — both straight from ops.fill_pool, compute dtype.
         Protein / drug LLM adaptors (DrugLAMP.py:39-52) on the HIP GEMM path: 641- and 385-wide features
@@ -349,8 +378,10 @@ class DrugLAMPBase(nn.Module):
         # drug adaptor is row-wise (Linear, GELU, LayerNorm, Linear).  With the collate's hint `drug_tokens` (a block size that
         # covers every molecule of the batch) the rows beyond it are computed as 8 rows standing for (512 - block) / 8 rows each
         # and expanded; the expansion's backward sums the copies' gradients, which is all a row-wise layer needs.
-        blk, N, TAIL = Fn.padding_hint("drug_tokens"), xd.shape[1], 8
+        blk, N, TAIL = int(drug_tokens or 0), xd.shape[1], 8
         if blk and self.compact_padding and N - blk >= 2 * TAIL and (N - blk) % TAIL == 0 and blk % 8 == 0:
+            if self.guard_padding:
+                ops.rows_equal_check(xd, blk, _FLAG_TOK)       # device-side guard: a wrong token count is an error, not garbage
             if self.check_padding and not bool((xd[:, blk:] == xd[:1, blk:blk + 1]).all()):
                 raise ValueError("drug LLM adaptor: the token rows beyond the hinted block of %d are not identical padding rows" % blk)
             xd = xd[:, :blk + TAIL].contiguous()
@@ -371,5 +402,11 @@ class DrugLAMPBase(nn.Module):
     def get_inter_attn_mat(self):
         return self.attn, self.guide_attn
 
-    def forward(self, vd, vp, xd, xp, mode="train"):
+    def forward(self, vd, vp, xd, xp, mode="train", hints=None):
         pass
+
+    def _protein_plan(self, hints, vp):
+        """The compact-layout tables for this batch's ProteinCNN pass (None: every position is computed)."""
+        if hints is None or hints.protein_plan is None or not self.compact_cnn or not vp.is_cuda:
+            return None
+        return hints.protein_plan

@@ -121,6 +121,73 @@ class CMLabels:
         return self
 
 
+class CMCodes:
+    """A batch's (prot code, drug code, label) rows on the device: (rows, 3) int64, refilled in place from a pinned ring
+    (one non-blocking copy per step; a captured graph points at `dev`).  Input of the device-built label matrix."""
+
+    def __init__(self, rows: int, device):
+        self.rows = rows
+        self.dev = torch.zeros((rows, 3), dtype=torch.int64, device=device)
+        on_gpu = torch.device(device).type == "cuda"
+        self._pins = [torch.zeros((rows, 3), dtype=torch.int64).pin_memory() if on_gpu else torch.zeros((rows, 3), dtype=torch.int64)
+                      for _ in range(4)]
+        self._events = [None] * len(self._pins)
+        self._slot = 0
+
+    def fill(self, meta):
+        if len(meta) != self.rows:
+            raise ValueError("CMCodes: %d meta rows for a %d-row block" % (len(meta), self.rows))
+        k = self._slot
+        self._slot = (k + 1) % len(self._pins)
+        if self._events[k] is not None:
+            self._events[k].synchronize()
+        self._pins[k].numpy()[:] = dist_ops.id_codes(meta)
+        self.dev.copy_(self._pins[k], non_blocking=True)
+        if self.dev.is_cuda:
+            self._events[k] = torch.cuda.Event()
+            self._events[k].record()
+        return self
+
+
+class DeviceLabels:
+    """label_matrix() built ON THE DEVICE from (G, 3) integer codes with static shapes — the same fields as CMLabels
+    (idx, mask, n, gt), so the head below does not care which one it gets.  Reference semantics (cross_modality.py:138-150):
+    unique ids in first-seen order, each represented by the LAST sample that carries it; gt[p][d] = the label of the LAST
+    sample of that (protein, drug) pair; unobserved pairs 0 (use_cm) or -1; everything outside [n_p) x [n_d) is -1
+    (ignored).  G x G comparison matrices (G = global batch <= a few thousand); no host round trip, capturable."""
+
+    def __init__(self, codes: torch.Tensor, use_cm=True):
+        G = codes.shape[0]
+        dev = codes.device
+        ar = torch.arange(G, device=dev)
+
+        def uniq(c):
+            eq = c.unsqueeze(1) == c.unsqueeze(0)                                   # (G, G)
+            first = torch.where(eq, ar.unsqueeze(0), G).min(dim=1).values           # first sample with this id
+            last = torch.where(eq, ar.unsqueeze(0), -1).max(dim=1).values           # last sample with this id
+            is_first = first == ar
+            pos = torch.cumsum(is_first.to(torch.int64), 0) - 1                     # position in the unique list (at firsts)
+            n = is_first.sum()
+            upos = pos.gather(0, first)                                             # unique position of EVERY sample
+            idx = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+            idx.scatter_(0, torch.where(is_first, pos, torch.full_like(pos, G)), last)   # non-firsts write the spare slot
+            return eq, upos, idx[:G], n
+
+        eqp, up, pidx, n_p = uniq(codes[:, 0])
+        eqd, ud, didx, n_d = uniq(codes[:, 1])
+        last_pair = torch.where(eqp & eqd, ar.unsqueeze(0), -1).max(dim=1).values == ar     # one writer per (p, d) cell
+        inside = (ar.unsqueeze(1) < n_p) & (ar.unsqueeze(0) < n_d)
+        gt = torch.where(inside, torch.full((), 0 if use_cm else -1, dtype=torch.int8, device=dev),
+                         torch.full((), -1, dtype=torch.int8, device=dev)).reshape(-1)
+        gt = torch.cat([gt, gt.new_zeros(1)])
+        cell = torch.where(last_pair, up * G + ud, torch.full_like(up, G * G))
+        gt.scatter_(0, cell, codes[:, 2].to(torch.int8))
+        self.gt = gt[:G * G].view(G, G).contiguous()
+        self.idx = (pidx, didx)
+        self.mask = ((ar < n_p).float().unsqueeze(1), (ar < n_d).float().unsqueeze(1))
+        self.n = (n_p.float(), n_d.float())
+
+
 def _bn_rows(bn: nn.BatchNorm1d, x, mask, n):
     """nn.BatchNorm1d over the rows with mask == 1 (n of them, a device scalar) of a padded (rows, hidden) block:
     batch statistics (biased variance) for the normalisation, running statistics updated with the unbiased variance
@@ -176,18 +243,27 @@ class CrossModality(nn.Module):
                         _mean2embed(self.aug_drug2latent, adm.index_select(0, di), dk, n_d)], dim=-1)
         return F.normalize(self.to_prot_latent(pe), dim=-1), F.normalize(self.to_drug_latent(de), dim=-1)
 
-    def forward(self, prot, aug_prot, drug, aug_drug, meta=None, labels: CMLabels = None):
+    def forward(self, prot, aug_prot, drug, aug_drug, meta=None, labels=None):
         """meta: the batch's id / label records (the reference's argument); labels: the same thing already on the device
-        (CMLabels.fill — what a captured step hands over).  One of the two."""
+        (CMLabels.fill, or CMCodes.fill in the global-batch form — what a captured step hands over).  One of the two."""
         means = [t.float().mean(dim=1) for t in (prot, aug_prot, drug, aug_drug)]
         if self.global_batch and dist_ops.world_size() > 1:
             # NEW vs the reference (off by default): the label matrix and the triplets span the GLOBAL batch.
-            # Only the (n, hidden) token means and the ids travel: 4 x 128 floats per pair over xGMI.
-            if meta is None:
-                raise RuntimeError("CrossModality: the global-batch form needs the id records (meta); it is not capturable")
+            # Only the (n, hidden) token means and three integers per pair travel (4 x 128 floats + 24 bytes per pair over
+            # xGMI), all as TENSOR collectives: the ids go as 63-bit codes (dist_ops.id_codes), the label matrix of the
+            # gathered batch is built on the device (DeviceLabels) — no host pickle collective on the step (round 4).
+            if isinstance(labels, CMCodes):
+                codes = labels
+            else:
+                if meta is None:
+                    raise RuntimeError("CrossModality: the global-batch form needs the id records (meta) or a filled CMCodes block")
+                key = ("codes", len(meta), means[0].device)
+                codes = self._label_blocks.get(key)
+                if codes is None:
+                    codes = self._label_blocks[key] = CMCodes(len(meta), means[0].device)
+                codes.fill(meta)
             means = [dist_ops.all_gather_rows(m) for m in means]
-            meta = dist_ops.all_gather_meta(meta)
-            labels = None
+            labels = DeviceLabels(dist_ops.all_gather_codes(codes.dev), self.use_cm)
         if labels is None:
             # one label block per batch size, refilled per step (stream order keeps the previous step's backward ahead of
             # the refill; a captured step brings its own block)

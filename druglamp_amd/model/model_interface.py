@@ -25,15 +25,17 @@ class MInterface(object):
         return Model(**args1)
 
 
-def load_reference_checkpoint(model, checkpoint, strict: bool = False, allow_pickle: bool = False):
+def load_reference_checkpoint(model, checkpoint, strict: bool = True, allow_pickle: bool = False):
     """Load a checkpoint written by the reference's Lightning run (trainer.py:151-156 ModelCheckpoint on the ExpModule):
     a dict whose "state_dict" maps "exp_model.<key>" to tensors (ExpModule stores the model as self.exp_model,
     trainer.py:43) next to metric-object states.  `checkpoint` is a path or the loaded dict; a bare state_dict (with or
     without the prefix) is accepted too.  The lazily created SimSiam projectors are built first when the checkpoint holds
     them (the reference needs one SSL forward before it can load such a checkpoint).  Returns load_state_dict's result
-    (missing / unexpected keys); strict=False by default, as the reference itself reloads (trainer.py:134) — a Lightning
-    state_dict also holds metric states outside the `exp_model.` prefix.  Files are read with weights_only=True;
-    allow_pickle=True opts in to full unpickling when that fails."""
+    (missing / unexpected keys).  strict=True by default: the dict is already filtered to the `exp_model.` keys (Lightning's
+    metric states never reach load_state_dict), so a missing or renamed key is an error, not a silently random weight.
+    With strict=False (what the reference itself passes, trainer.py:134) anything missing besides the lazily built SimSiam
+    projector keys still raises.  Files are read with weights_only=True; allow_pickle=True opts in to full unpickling
+    when that fails."""
     import torch
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "read"):
         try:
@@ -61,4 +63,8 @@ def load_reference_checkpoint(model, checkpoint, strict: bool = False, allow_pic
                 dims[name] = int(w.shape[1])
         if len(dims) == 2:
             model.ssl_model.build_projectors(dims["net"], dims["llm_net"], device=next(model.parameters()).device)
-    return model.load_state_dict(sd, strict=strict)
+    res = model.load_state_dict(sd, strict=strict)
+    hard = [k for k in res.missing_keys if ".projector." not in k]
+    if hard:
+        raise RuntimeError("load_reference_checkpoint: %d parameters of the model are not in the checkpoint (first: %s)" % (len(hard), hard[:4]))
+    return res

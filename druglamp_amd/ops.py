@@ -598,11 +598,16 @@ def triplet_sigcos_bwd(p_lats, d_lats, gt_i8, margin: float, buf, ntri, grad_out
     return dp, dd
 
 
-def bn_stats(y2d, win, halo, valid):
+def bn_stats(y2d, win, halo, valid, rw=None):
+    """rw (R,) fp32 row weights (< 0 halo, 0 context, m >= 1 multiplicity) replace the window rule (dl_bn_stats_rw)."""
     R, Cc = y2d.shape
     L = _lib.lib()
     sums = torch.empty(2 * Cc, dtype=torch.float32, device=y2d.device)
     ws = _ws2.get(L.dl_bn_workspace_bytes(R, Cc), y2d.device)
+    if rw is not None:
+        check(L.dl_bn_stats_rw(y2d.data_ptr(), R, Cc, rw.data_ptr(), _dt(y2d), sums.data_ptr(), ws.data_ptr(), ws.numel(),
+                               _stream()), "dl_bn_stats_rw")
+        return sums
     check(L.dl_bn_stats(y2d.data_ptr(), R, Cc, win, halo, valid, _dt(y2d), sums.data_ptr(), ws.data_ptr(), ws.numel(),
                         _stream()), "dl_bn_stats")
     return sums
@@ -617,27 +622,40 @@ def bn_finalize(sums, n, eps, momentum=0.0, running_mean=None, running_var=None)
     return out[0], out[1], out[2]
 
 
-def bn_apply_fwd(y2d, mean, rstd, gamma, beta, win, halo, valid):
+def bn_apply_fwd(y2d, mean, rstd, gamma, beta, win, halo, valid, rw=None):
     R, Cc = y2d.shape
     z = torch.empty_like(y2d)
+    if rw is not None:
+        check(_lib.lib().dl_bn_apply_fwd_rw(y2d.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                            beta.data_ptr(), R, Cc, rw.data_ptr(), _dt(y2d), _stream()), "dl_bn_apply_fwd_rw")
+        return z
     check(_lib.lib().dl_bn_apply_fwd(y2d.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                      beta.data_ptr(), R, Cc, win, halo, valid, _dt(y2d), _stream()), "dl_bn_apply_fwd")
     return z
 
 
-def bn_bwd_reduce(dz2d, y2d, mean, rstd, win, halo, valid):
+def bn_bwd_reduce(dz2d, y2d, mean, rstd, win, halo, valid, rw=None):
     R, Cc = y2d.shape
     L = _lib.lib()
     sums = torch.empty(2 * Cc, dtype=torch.float32, device=y2d.device)
     ws = _ws2.get(L.dl_bn_workspace_bytes(R, Cc), y2d.device)
+    if rw is not None:
+        check(L.dl_bn_bwd_reduce_rw(dz2d.data_ptr(), y2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), R, Cc, rw.data_ptr(),
+                                    _dt(y2d), sums.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_bn_bwd_reduce_rw")
+        return sums
     check(L.dl_bn_bwd_reduce(dz2d.data_ptr(), y2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), R, Cc, win, halo, valid,
                              _dt(y2d), sums.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_bn_bwd_reduce")
     return sums
 
 
-def bn_bwd_apply(dz2d, y2d, mean, rstd, gamma, sums, inv_n, relu_mask, win, halo, valid):
+def bn_bwd_apply(dz2d, y2d, mean, rstd, gamma, sums, inv_n, relu_mask, win, halo, valid, rw=None):
     R, Cc = y2d.shape
     dy = torch.empty_like(y2d)
+    if rw is not None:
+        check(_lib.lib().dl_bn_bwd_apply_rw(dz2d.data_ptr(), y2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                            sums.data_ptr(), float(inv_n), int(relu_mask), dy.data_ptr(), R, Cc, rw.data_ptr(),
+                                            _dt(y2d), _stream()), "dl_bn_bwd_apply_rw")
+        return dy
     check(_lib.lib().dl_bn_bwd_apply(dz2d.data_ptr(), y2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                      sums.data_ptr(), float(inv_n), int(relu_mask), dy.data_ptr(), R, Cc, win, halo, valid,
                                      _dt(y2d), _stream()), "dl_bn_bwd_apply")
@@ -722,6 +740,88 @@ def embed_pad(ids: torch.Tensor, weight: torch.Tensor, fill: torch.Tensor, halo:
     check(_lib.lib().dl_embed_pad(ids.data_ptr(), weight.data_ptr(), fill.data_ptr(), out.data_ptr(), B, L, V, D, halo,
                                   _dt(weight), _stream()), "dl_embed_pad")
     return out
+
+
+# Device-side guard flags (dl_embed_rows / dl_rows_equal_check OR sticky bits into one int32 word per device): the compact
+# padding forms are only valid for inputs with the padding structure of the reference's collate; Trainer polls the word.
+_guard_flags = {}
+FLAG_TEXT = {_lib.FLAG_PROT_PERIOD: "a protein's residue codes / fill bits are not tiled with the period its length gives "
+                                    "(utils.py:392-412 repeat_integer_label_protein); disable with DL_CNN_COMPACT=0",
+             _lib.FLAG_DRUG_TOKEN_PAD: "drug LLM token rows beyond the hinted block (meta 'Drug_Tokens') are not identical padding rows; "
+                                       "disable with DL_PAD_COMPACT=0",
+             _lib.FLAG_GCN_NODE_PAD: "drug graph nodes beyond the adjacency block are not identical virtual padding nodes "
+                                     "(handler/dataset.py:216-221); disable with DL_GCN_COMPACT=0"}
+
+
+def guard_flags(device) -> torch.Tensor:
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0))
+    t = _guard_flags.get(key)
+    if t is None:
+        t = _guard_flags[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
+def guard_text(bits: int) -> str:
+    return "; ".join(v for k, v in FLAG_TEXT.items() if bits & k) or "unknown flag bits %#x" % bits
+
+
+def check_guard_flags(device) -> None:
+    """Synchronising check of the device guard word: raises (and clears the word) when a compact padding form ran on a batch
+    that does not have the structure it assumes."""
+    t = guard_flags(device)
+    bits = int(t.item())
+    if bits:
+        t.zero_()
+        raise RuntimeError("druglamp_amd: padding guard tripped — " + guard_text(bits))
+
+
+def embed_rows(ids: torch.Tensor, weight: torch.Tensor, fill: torch.Tensor, src: torch.Tensor, period: Optional[torch.Tensor]) -> torch.Tensor:
+    """Compact ProteinCNN input (dl_embed_rows): ids (B, L) int64, weight (V, D), fill (B, L), src (R,) int32 flat indices or -1
+    -> (R, D + 1).  period (B,) int32: also run the periodicity guard (sets the device guard word on a violation)."""
+    _need_gpu(ids, weight, fill, src)
+    B, L = ids.shape
+    V, D = weight.shape
+    ids = ids.contiguous()
+    weight = torch.nn.functional.pad(weight, (0, 1)).contiguous()
+    fill = fill.to(weight.dtype).contiguous()
+    R = src.numel()
+    out = torch.empty((R, D + 1), dtype=weight.dtype, device=weight.device)
+    flags = guard_flags(weight.device) if period is not None else None
+    check(_lib.lib().dl_embed_rows(ids.data_ptr(), weight.data_ptr(), fill.data_ptr(), src.data_ptr(), out.data_ptr(), R, V, D,
+                                   _ptr(period), B, L, _ptr(flags), _dt(weight), _stream()), "dl_embed_rows")
+    return out
+
+
+def rows_gather(src2d: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """out[i] = src2d[index[i]] (zeros where index[i] < 0); index int32 (dl_rows_gather)."""
+    _need_gpu(src2d, index)
+    src2d = src2d.contiguous()
+    N, Cc = index.numel(), src2d.shape[1]
+    out = torch.empty((N, Cc), dtype=src2d.dtype, device=src2d.device)
+    check(_lib.lib().dl_rows_gather(src2d.data_ptr(), index.data_ptr(), out.data_ptr(), N, Cc * src2d.element_size(), _stream()),
+          "dl_rows_gather")
+    return out
+
+
+def rows_sum_strided(x2d: torch.Tensor, rep: torch.Tensor) -> torch.Tensor:
+    """out[r] = sum_{k < rep[r, 2]} x2d[rep[r, 0] + k * rep[r, 1]]; rep (R, 3) int32 (dl_rows_sum_strided)."""
+    _need_gpu(x2d, rep)
+    x2d = x2d.contiguous()
+    R, Cc = rep.shape[0], x2d.shape[1]
+    out = torch.empty((R, Cc), dtype=x2d.dtype, device=x2d.device)
+    check(_lib.lib().dl_rows_sum_strided(x2d.data_ptr(), rep.data_ptr(), out.data_ptr(), R, Cc, _dt(x2d), _stream()),
+          "dl_rows_sum_strided")
+    return out
+
+
+def rows_equal_check(x3d: torch.Tensor, row0: int, code: int) -> None:
+    """Guard: rows row0.. of every sample of x3d (B, N, F) must equal row row0 of sample 0 (dl_rows_equal_check)."""
+    _need_gpu(x3d)
+    x3d = x3d.contiguous()
+    B, N, F_ = x3d.shape
+    check(_lib.lib().dl_rows_equal_check(x3d.data_ptr(), B, N, F_ * x3d.element_size(), int(row0), int(code),
+                                         guard_flags(x3d.device).data_ptr(), _stream()), "dl_rows_equal_check")
 
 
 def interleave_streams(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:

@@ -61,7 +61,8 @@ def make_batch(B: int, device, seed: int = 0, with_graph: bool = True, llm_dtype
     pid = torch.randint(0, n_prot, (B,), generator=g).tolist()
     did = torch.randint(0, n_drug, (B,), generator=g).tolist()
     # (Drug_Tokens: the molecule's token count, which a collate knows — Trainer turns the batch maximum into a padding hint)
-    meta = [{"Prot_ID": pid[t], "Drug_ID": did[t], "Y": float(y[t]), "Drug_Tokens": int(n_tok[t])} for t in range(B)]
+    # (Prot_Len: the protein's residue count, likewise collate knowledge — the ProteinCNN distinct-row plan is built from it)
+    meta = [{"Prot_ID": pid[t], "Drug_ID": did[t], "Y": float(y[t]), "Drug_Tokens": int(n_tok[t]), "Prot_Len": int(Lp[t])} for t in range(B)]
     batch = (feat_d, vp.to(device), y.to(device), xd.to(device=device, dtype=llm_dtype),
              xp.to(device=device, dtype=llm_dtype))
     return batch, meta

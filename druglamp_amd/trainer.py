@@ -260,11 +260,15 @@ class GraphedStep:
         self.tr = trainer
         dev = trainer.device
         self.static = self._clone(batch)
-        self.hints = trainer.padding_hints_of(meta, batch)
+        self.hints = trainer.hints_of(meta, batch, own_tables=True)       # (this graph's own device tables: refilled per replay)
         self.labels = None
         if "cm" in kind:
-            from .model.cross_modality import CMLabels
-            self.labels = CMLabels(int(batch[2].shape[0]), dev).fill(meta, trainer.model.cm_model.use_cm)
+            from .model.cross_modality import CMCodes, CMLabels
+            if trainer.model.cm_model.global_batch and trainer.world > 1:
+                # global-batch form: the step gathers integer id codes and builds the label matrix on the device
+                self.labels = CMCodes(int(batch[2].shape[0]), dev).fill(meta)
+            else:
+                self.labels = CMLabels(int(batch[2].shape[0]), dev).fill(meta, trainer.model.cm_model.use_cm)
         # The weight-image refresh (dl_weight_prep) must be a node of the graph whatever ran last: an eager forward with no
         # optimiser step behind it (evaluate() between the warm-up steps and this capture, a validate-every-N loop) leaves
         # the images current, lowp() would skip the refresh during capture, and every replay would then compute with the
@@ -298,7 +302,10 @@ class GraphedStep:
         ts += [b for b in tr.model.buffers()] + [p_ for p_ in tr.model.parameters()]
         ts += [t for b in self.static for t in (b if isinstance(b, (tuple, list)) else (b,))]
         if self.labels is not None:
-            ts += [self.labels.buf]
+            ts += [self.labels.buf if hasattr(self.labels, "buf") else self.labels.dev]
+        if self.hints.protein_plan is not None:
+            ts += [self.hints.protein_plan.buf]
+        ts += list(ops._guard_flags.values())
         ts += list(ops._seed_offsets.values()) + list(ops._tickets.values())
         ts += [e.image for e in Fn._lowp_cache.values() if torch.is_tensor(e.image)]
         for tab in list(Fn._lowp_tables.values()) + [t for t in Fn._lowp_retired if isinstance(t, tuple) and len(t) == 4]:
@@ -350,8 +357,8 @@ class GraphedStep:
         tr, m = self.tr, self.tr.model
         ops.seed_offset_tensor(tr.device).add_(1)
         feat_d, feat_p, labels, llm_d, llm_p = self.static
-        with Fn.padding_hints(**self.hints):           # (by-value knowledge of the capture: part of the graph key)
-            _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p)
+        # (hints: by-value knowledge of the capture — the block sizes are part of the graph key, the table CONTENTS are refilled)
+        _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p, hints=self.hints)
         tr._zero_grad()
         _, cls_loss = binary_cross_entropy(score, labels) if tr.n_class == 1 else cross_entropy_logits(score, labels)
         out = {"cls": cls_loss.detach()}
@@ -390,8 +397,16 @@ class GraphedStep:
         return "cm" if "cm" in self.kind else self.kind
 
     def run(self, batch, meta=None):
-        if self.labels is not None:
-            self.labels.fill(meta, self.tr.model.cm_model.use_cm)      # host label matrix -> the graph's static tensors
+        if self.hints.protein_plan is not None:    # this batch's distinct-row tables -> the graph's static tables
+            plan = self.tr.protein_plan_of(meta, batch)
+            if plan is None or plan.key != self.hints.protein_plan.key:
+                raise RuntimeError("GraphedStep: the batch's ProteinCNN row tables do not have the captured shape")
+            self.hints.protein_plan.fill(plan)
+        if self.labels is not None:                # host label matrix / id codes -> the graph's static tensors
+            if hasattr(self.labels, "buf"):
+                self.labels.fill(meta, self.tr.model.cm_model.use_cm)
+            else:
+                self.labels.fill(meta)
         if not self._is_static(batch):                  # copy into the static inputs (device-to-device)
             for dst, src in zip(self.static, batch):
                 if isinstance(dst, tuple):
@@ -480,6 +495,11 @@ class Trainer:
         self._agreed_sets: Dict[str, frozenset] = {}
         self._eager_seen: Dict[tuple, int] = {}
         self.graph_warmup = 2            # eager (real) steps of a batch shape before its graph is captured
+        self.graph_cache_max = max(1, int(os.environ.get("DL_GRAPH_CACHE_MAX", "6")))     # live GraphedSteps (LRU)
+        self._plan_devs: Dict[tuple, object] = {}           # ProteinCNN row tables of eager steps, one set per shape
+        on_gpu = torch.device(self.device).type == "cuda"
+        self._guard_pin = torch.zeros(1, dtype=torch.int32).pin_memory() if on_gpu else None
+        self._guard_event = None
         if self.graph_steps:
             ops.use_seed_offset(True)    # one dropout-seed regime for eager and replayed steps
 
@@ -570,6 +590,74 @@ class Trainer:
         if cm_lr is not None and self.opt_cm:
             self.opt_cm.lr = cm_lr
 
+    def model_has_global_ntxent(self) -> bool:
+        ssl = getattr(self.model, "ssl_model", None)
+        return bool(ssl is not None and getattr(ssl, "global_batch", False) and getattr(ssl, "drug_ssl_type", "") == "simclr")
+
+    def graphed_kind_ok(self, compute_ssl: bool, compute_cm: bool) -> bool:
+        """Whether a step kind may replay a graph at this world size (bench.py reports `hip_graph` from it)."""
+        coll_ok = self.world == 1 or (bool(self.graph_allreduce) and dist.get_backend() == "nccl")
+        cm = getattr(self.model, "cm_model", None)
+        return ((not compute_ssl) or coll_ok or not self.model_has_global_ntxent()) and \
+            ((not compute_cm) or coll_ok or not (cm is not None and cm.global_batch))
+
+    def protein_plan_of(self, meta, batch):
+        """The ProteinCNN distinct-row plan of a batch from the collate's `Prot_Len` records (residue counts after the
+        reference's truncation, handler/dataset.py:36,139), or None (no records / switched off / nothing to save)."""
+        if not meta or not getattr(self.model, "compact_cnn", False) or any("Prot_Len" not in m_ for m_ in meta):
+            return None
+        vp = batch[1]
+        if not (torch.is_tensor(vp) and vp.dim() == 2 and vp.shape[0] == len(meta)):
+            return None
+        from .protein_plan import plan_of
+        return plan_of([int(m_["Prot_Len"]) for m_ in meta], int(vp.shape[1]))
+
+    def hints_of(self, meta, batch, own_tables: bool = False):
+        """BatchHints for model(..., hints=...): the drug-token block (padding_hints_of) and the ProteinCNN plan's device
+        tables.  Eager steps share one table set per shape (refilled in place, stream-ordered); own_tables=True gives the
+        caller its own (a captured graph keeps pointing at them)."""
+        from .protein_plan import BatchHints, PlanDev
+        plan = self.protein_plan_of(meta, batch)
+        pd = None
+        if plan is not None:
+            if own_tables:
+                pd = PlanDev(plan, self.device)
+            else:
+                pd = self._plan_devs.pop(plan.key, None)
+                if pd is None:
+                    while len(self._plan_devs) >= 4:
+                        del self._plan_devs[next(iter(self._plan_devs))]
+                    pd = PlanDev(plan, self.device)
+                else:
+                    pd.fill(plan)
+                self._plan_devs[plan.key] = pd           # most recently used last
+        return BatchHints(self.padding_hints_of(meta, batch).get("drug_tokens", 0), pd)
+
+    # -- device-side padding guards (ops.guard_flags): polled without a host sync, checked with one on demand -------------
+    def _poll_guard(self):
+        """Raise if a guard tripped in an earlier step (reads the pinned copy the previous steps posted; never waits)."""
+        if self._guard_pin is None:
+            return
+        ev = self._guard_event
+        if ev is not None and ev.query():
+            bits = int(self._guard_pin[0])
+            self._guard_event = None
+            if bits:
+                ops.guard_flags(self.device).zero_()
+                raise RuntimeError("druglamp_amd: padding guard tripped in an earlier step — " + ops.guard_text(bits))
+
+    def _post_guard(self):
+        if self._guard_pin is None or self._guard_event is not None:
+            return                                        # one copy in flight at a time (the word is sticky)
+        self._guard_pin.copy_(ops.guard_flags(self.device), non_blocking=True)
+        self._guard_event = torch.cuda.Event()
+        self._guard_event.record()
+
+    def check_device_flags(self):
+        """Synchronising check of the padding guards (end of an epoch, of an evaluation, of a benchmark)."""
+        if torch.device(self.device).type == "cuda":
+            ops.check_guard_flags(self.device)
+
     @staticmethod
     def padding_hints_of(meta, batch) -> dict:
         """Host-side knowledge about the batch for the model (functional.padding_hints).  drug_tokens: a block size (multiple
@@ -578,33 +666,41 @@ class Trainer:
         if not meta or any("Drug_Tokens" not in m_ for m_ in meta):
             return {}
         n_rows = int(batch[3].shape[1]) if torch.is_tensor(batch[3]) and batch[3].dim() == 3 else 0
-        blk = (max(int(m_["Drug_Tokens"]) for m_ in meta) + 63) // 64 * 64
-        return {"drug_tokens": blk} if 0 < blk <= n_rows - 64 else {}
+        blk = (max(int(m_["Drug_Tokens"]) for m_ in meta) + 127) // 128 * 128      # 128 / 256 / 384: few graph keys
+        return {"drug_tokens": blk} if 0 < blk <= n_rows - 128 else {}
 
     # -- the step ---------------------------------------------------------------------------------------
     def training_step(self, batch, meta=None, cur_epoch: int = 1, ssl_masks=None) -> Dict[str, float]:
         """batch = (feat_d, feat_p, labels, llm_d, llm_p) as the reference's collate yields them.
         cur_epoch is 1-based (trainer.py:180).  Returns python floats of the losses (one host sync)."""
         m = self.model
+        self._poll_guard()
         if not m.training:
             m.train()                  # (walks every submodule: 0.7 ms per call)
         compute_ssl = self.use_ssl and (cur_epoch % self.ssl_epoch_step == 0)
         compute_cm = self.use_cm and (cur_epoch >= self.cm_init_epoch)
         # steps with the CM head replay a graph too (round 3) except: in the epoch the head starts (the cm_weight
         # auto-scale below reads losses on the host), without id records, and in the global-batch form (object collectives)
+        # Heads that see the GLOBAL batch issue collectives in their forward and backward (NT-Xent rows, CM token means and
+        # id codes: tensor collectives only since round 4).  A step with them is captured only where captured collectives
+        # are switched on (DL_GRAPH_ALLREDUCE) AND the backend is RCCL; on gloo (every two-rank test) it stays eager.
+        coll_ok = self.world == 1 or (bool(self.graph_allreduce) and dist.get_backend() == "nccl")
         cm_ok = (not compute_cm) or (cur_epoch > self.cm_init_epoch and meta is not None and
-                                     not (m.cm_model.global_batch and self.world > 1))
-        if self.graph_steps and cm_ok and not self.run_dead_backward and (not compute_ssl or ssl_masks is None):
+                                     (coll_ok or not m.cm_model.global_batch))
+        ssl_ok = (not compute_ssl) or coll_ok or not self.model_has_global_ntxent()
+        if self.graph_steps and cm_ok and ssl_ok and not self.run_dead_backward and (not compute_ssl or ssl_masks is None):
             kind = (("ssl" if compute_ssl else "") + ("cm" if compute_cm else "")) or "cls"
             byval = (float(m.cm_model.m_sch_loss_fn.margin), float(self.cm_weight)) if compute_cm else ()
-            byval = tuple(sorted(self.padding_hints_of(meta, batch).items())) + byval
+            plan = self.protein_plan_of(meta, batch)
+            byval = (self.padding_hints_of(meta, batch).get("drug_tokens", 0), None if plan is None else plan.key) + byval
             sig = (kind,) + GraphedStep.signature(batch) + byval
             if sig in self._graphs or self._eager_seen.get(sig, 0) >= self.graph_warmup:
                 return self._graphed_step(batch, sig, kind, meta)
+            if len(self._eager_seen) > 256:            # bounded bookkeeping (signatures of shapes seen once and never again)
+                self._eager_seen.clear()
             self._eager_seen[sig] = self._eager_seen.get(sig, 0) + 1
         feat_d, feat_p, labels, llm_d, llm_p = batch
-        with Fn.padding_hints(**self.padding_hints_of(meta, batch)):
-            _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p)
+        _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p, hints=self.hints_of(meta, batch))
         self._zero_grad()
         _, cls_loss = binary_cross_entropy(score, labels) if self.n_class == 1 else cross_entropy_logits(score, labels)
         last = "cm" if compute_cm else "ssl" if compute_ssl else "cls"     # the backward the optimisers consume
@@ -647,17 +743,25 @@ class Trainer:
         if compute_cm:
             self.opt_cm.step(idx, scale)
         Fn.bump_param_epoch()
+        self._post_guard()
         return out
 
     def _graphed_step(self, batch, sig, kind: str = "cls", meta=None) -> Dict[str, float]:
         g = self._graphs.get(sig)
         if g is None:
             if "cm" in kind:
-                # margin / cm_weight are by-value arguments of a capture: a graph of the same kind and shapes with older
-                # values (the margin moves once per epoch) will not be replayed again — release its pool first
-                for old in [k for k in self._graphs if k[:-2] == sig[:-2]]:       # same kind, shapes and hints
+                # margin / cm_weight are by-value arguments of a capture: EVERY graph with the CM head ("cm" and "sslcm"
+                # kinds, any shape or hint) captured under other values will not be replayed again (the margin moves once
+                # per epoch) — release their pools first
+                for old in [k for k, v in self._graphs.items() if "cm" in v.kind and k[-2:] != sig[-2:]]:
                     del self._graphs[old]
+            # Every GraphedStep owns a private pool with a whole step's activations (GBs at batch 64-128): keep at most
+            # graph_cache_max of them, least recently replayed first out (real SMILES batches vary the padding hint)
+            while len(self._graphs) >= self.graph_cache_max:
+                del self._graphs[next(iter(self._graphs))]
             g = self._graphs[sig] = GraphedStep(self, batch, kind, meta)     # records only; the replay below is the step
+        else:
+            self._graphs[sig] = self._graphs.pop(sig)                        # most recently used last
         out, idx = g.run(batch, meta)
         if self.world > 1 and not g.reduced:
             idx = self._agreed(g.last, idx)
@@ -668,6 +772,7 @@ class Trainer:
         if "cm" in kind:
             self.opt_cm.step(idx, 1.0 / self.world)
         Fn.bump_param_epoch()
+        self._post_guard()
         return out
 
     def static_batch(self, batch):
@@ -686,6 +791,7 @@ class Trainer:
         if compute_cm:
             self.opt_cm.lr = self.schd_cm.step()
             self.model.cm_model.step()
+        self.check_device_flags()                      # (an epoch boundary: a host sync costs nothing here)
 
     # -- evaluation (trainer.py:256-292; torchmetrics replaced by sklearn on the gathered predictions) -----
     @torch.no_grad()
@@ -705,6 +811,7 @@ class Trainer:
             loss_sum += loss.double() * labels.numel()              # per-batch means -> a sum over samples
         p = torch.cat(preds) if preds else torch.zeros(0, device=self.device)
         y = torch.cat(labs) if labs else torch.zeros(0, device=self.device)
+        self.check_device_flags()
         return p, y, loss_sum, p.numel()
 
     def evaluate(self, batches) -> Dict[str, float]:

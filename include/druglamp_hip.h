@@ -183,6 +183,22 @@ int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean, const floa
                     const float* gamma, const float* sums, float inv_n, int32_t relu_mask, void* dy,
                     int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid, int32_t dtype,
                     dl_stream s);
+/* Row-weight forms of the four BatchNorm passes (round 4: ProteinCNN on distinct rows, reference model/basic_model.py:155-180
+ * over the tiled sequences of utils.py:392-412; tables: druglamp_amd/protein_plan.py).  row_w [R] fp32 replaces the window
+ * rule: row_w[r] < 0 a halo row (excluded from every sum, written as zeros), 0 a context row (computed and normalised, not
+ * part of the statistics), m >= 1 a row that stands for m identical rows of the reference's layout:
+ *   stats_rw      sums = [sum m y | sum m y^2]                      (n of dl_bn_finalize = sum of the weights)
+ *   bwd_reduce_rw sums = [sum dz | sum dz * yhat] over rows with row_w >= 0 (a row's dz already is the sum over its copies)
+ *   bwd_apply_rw  dy = gamma * rstd * (dz - m * (S0 / n + yhat * S1 / n)), then the ReLU mask; halo rows zero. */
+int dl_bn_stats_rw(const void* y, int64_t R, int64_t C, const float* row_w, int32_t dtype, float* sums, void* workspace,
+                   size_t workspace_bytes, dl_stream s);
+int dl_bn_apply_fwd_rw(const void* y, void* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                       int64_t R, int64_t C, const float* row_w, int32_t dtype, dl_stream s);
+int dl_bn_bwd_reduce_rw(const void* dz, const void* y, const float* mean, const float* rstd, int64_t R, int64_t C,
+                        const float* row_w, int32_t dtype, float* sums, void* workspace, size_t workspace_bytes, dl_stream s);
+int dl_bn_bwd_apply_rw(const void* dz, const void* y, const float* mean, const float* rstd, const float* gamma,
+                       const float* sums, float inv_n, int32_t relu_mask, void* dy, int64_t R, int64_t C, const float* row_w,
+                       int32_t dtype, dl_stream s);
 /* Weighted tail rows (round 3: MolecularGCN's compact padding form, model/basic_model.py — the reference's virtual padding
  * nodes, handler/dataset.py:216-221, are identical in every layer and computed once).  Inside every window of `win` rows
  * the rows [lead, win) stand for w identical rows each; their incoming gradient is already the sum over those copies.
@@ -349,6 +365,28 @@ int dl_gather_pad(const void* store, const int64_t* offsets, const int32_t* leng
  * [V][D + 1] (last column ignored; 16-byte aligned rows); fill [B][L] and out [B][L + 2*halo][D + 1]; all `dtype`. */
 int dl_embed_pad(const int64_t* ids, const void* weight, const void* fill, void* out, int64_t B, int64_t L,
                  int32_t V, int32_t D, int32_t halo, int32_t dtype, dl_stream s);
+/* Device-side guard flags (sticky bits OR-ed into a caller-owned uint32 word; the trainer polls it):
+ * the compact forms below are only valid for inputs with the padding structure of the reference's collate. */
+enum { DL_FLAG_PROT_PERIOD = 1, DL_FLAG_DRUG_TOKEN_PAD = 2, DL_FLAG_GCN_NODE_PAD = 4 };
+/* ProteinCNN head on distinct rows (round 4; model/basic_model.py:168-171 over a sequence tiled by utils.py:392-412):
+ * out[r][:D] = weight[ids[src[r]]], out[r][D] = fill[src[r]] for src[r] >= 0 (a flat index into ids / fill [B * L]), a zero
+ * row for src[r] < 0.  weight padded to [V][D + 1] as for dl_embed_pad.  With `period` [B] given the same launch checks
+ * every sample's (id, fill bit) sequence: equal at distance period[b] inside the last whole period's end E, constant on
+ * [E, L) — what the row tables assume; a violation ORs DL_FLAG_PROT_PERIOD into *flags. */
+int dl_embed_rows(const int64_t* ids, const void* weight, const void* fill, const int32_t* src, void* out, int64_t R,
+                  int32_t V, int32_t D, const int32_t* period, int64_t B, int64_t L, uint32_t* flags, int32_t dtype, dl_stream s);
+/* out[i][:] = src[index[i]][:] (zeros where index[i] < 0), rows of row_bytes (a multiple of 16): the compact ProteinCNN
+ * output expanded to all positions (the reference's full (B, 2304, 128) activation, basic_model.py:179). */
+int dl_rows_gather(const void* src, const int32_t* index, void* out, int64_t N, int64_t row_bytes, dl_stream s);
+/* out[r][:] = sum_{k < rep[r][2]} x[rep[r][0] + k * rep[r][1]][:] — the gradient of dl_rows_gather for index maps whose
+ * preimages are arithmetic progressions (rep = (first, stride, count) per output row; count 0 gives a zero row); fixed
+ * summation order, fp32 accumulation. */
+int dl_rows_sum_strided(const void* x, const int32_t* rep, void* out, int64_t R, int64_t C, int32_t dtype, dl_stream s);
+/* Guard of the drug branch's compact padding forms (reference handler/dataset.py:211-222 virtual nodes; utils.py:304-312
+ * tail_pad zero rows): rows row0 .. N - 1 of every sample of x [B][N][row_bytes] must equal row row0 of sample 0 bit for bit,
+ * else `code` is OR-ed into *flags. */
+int dl_rows_equal_check(const void* x, int64_t B, int64_t N, int64_t row_bytes, int64_t row0, uint32_t code, uint32_t* flags,
+                        dl_stream s);
 /* ProteinCNN tail (model/basic_model.py:176-179 + DrugLAMP.py:39-40): the reference keeps the conv output
  * channel-first (B, C, L), REINTERPRETS that buffer with .view(B, L, C) and then site-pools it
  * (.view(B, site_len, n_site, C).mean(1)).  z is this library's channel-last conv output with `halo` zero rows

@@ -254,24 +254,61 @@ def test_cm_labels_pack_the_label_matrix_into_static_shapes():
 
 
 def test_padding_hints_from_the_collate_records():
-    """Trainer.padding_hints_of: the batch maximum of the collate's Drug_Tokens records, rounded up to a multiple of 64 (few
-    graph keys); no hint without the records or when the block would save nothing; functional.padding_hints nests."""
+    """Trainer.padding_hints_of: the batch maximum of the collate's Drug_Tokens records, rounded up to a multiple of 128 (few
+    graph keys); no hint without the records or when the block would save nothing.  Hints travel as an explicit argument
+    (protein_plan.BatchHints -> model(..., hints=...)): there is no module-global hint state."""
     from druglamp_amd import functional as Fn
+    from druglamp_amd.protein_plan import BatchHints
     from druglamp_amd.trainer import Trainer
     llm_d = torch.zeros(3, 512, 8)
     batch = (None, None, None, llm_d, None)
     mk = lambda *n: [{"Drug_Tokens": k} for k in n]      # noqa: E731
-    assert Trainer.padding_hints_of(mk(12, 64, 40), batch) == {"drug_tokens": 64}
-    assert Trainer.padding_hints_of(mk(12, 65, 40), batch) == {"drug_tokens": 128}
-    assert Trainer.padding_hints_of(mk(449, 3, 3), batch) == {}                  # block 512: nothing to save
-    assert Trainer.padding_hints_of(mk(448, 3, 3), batch) == {"drug_tokens": 448}
+    assert Trainer.padding_hints_of(mk(12, 64, 40), batch) == {"drug_tokens": 128}
+    assert Trainer.padding_hints_of(mk(12, 129, 40), batch) == {"drug_tokens": 256}
+    assert Trainer.padding_hints_of(mk(385, 3, 3), batch) == {}                  # block 512: nothing to save
+    assert Trainer.padding_hints_of(mk(384, 3, 3), batch) == {"drug_tokens": 384}
     assert Trainer.padding_hints_of([{"Drug_Tokens": 5}, {"Y": 1.0}], batch) == {} and Trainer.padding_hints_of(None, batch) == {}
-    assert Fn.padding_hint("drug_tokens") is None
-    with Fn.padding_hints(drug_tokens=128):
-        assert Fn.padding_hint("drug_tokens") == 128
-        with Fn.padding_hints():
-            assert Fn.padding_hint("drug_tokens") == 128
-    assert Fn.padding_hint("drug_tokens") is None
+    assert not hasattr(Fn, "padding_hints") and not hasattr(Fn, "padding_hint")
+    assert BatchHints().key() == (0, None) and BatchHints(128).drug_tokens == 128
+
+
+def test_protein_plan_covers_every_position_with_the_right_multiplicities():
+    """protein_plan: every position of the tiled sequence has exactly one representative row, the weights add up to the
+    sequence length, representatives keep their receptive field (7 left / 8 right) inside their segment, and the symbolic
+    input windows of a position and of its representative are identical (what makes the compact network equal to the full
+    one for ANY parameter values).  The fp64 network-level check lives in tests/test_protein_plan_cpu.py."""
+    import numpy as np
+    from druglamp_amd.data import repeat_integer_label
+    from druglamp_amd.protein_plan import HALO, RF_LEFT, RF_RIGHT, ProteinPlan, sample_template
+    S = 2304
+    for L in (13, 98, 254, 398, 766, 767, 1022, 1150, 1151, 2000):
+        src, w, first, stride, count, row_of = sample_template(L, S)
+        assert abs(float(np.clip(w, 0, None).sum()) - S) < 1e-6 and (row_of >= 0).all()
+        # symbolic sequence: distinct residue symbols inside a period (so only the tiling creates equalities), -1 outside
+        P = L + 2
+        sym = np.zeros(S, np.int64)
+        sym[:(S // P) * P] = np.tile(np.arange(1, P + 1), S // P)
+        ext = np.concatenate([np.full(RF_LEFT, -1), sym, np.full(RF_RIGHT, -1)])
+        win = np.lib.stride_tricks.sliding_window_view(ext, RF_LEFT + RF_RIGHT + 1)        # window of position t = win[t]
+        rep_pos = src[row_of]
+        assert (rep_pos >= 0).all() and (win[np.arange(S)] == win[rep_pos]).all(), L
+        # a representative's receptive field lies inside its segment (no halo row within reach unless it is a real boundary)
+        for r in np.unique(row_of):
+            t = src[r]
+            lo, hi = r - RF_LEFT, r + RF_RIGHT
+            seg = src[max(lo, 0):hi + 1]
+            inside = seg[seg >= 0]
+            assert (np.diff(inside) == 1).all()
+            assert t - inside.min() == min(RF_LEFT, t) and inside.max() - t == min(RF_RIGHT, S - 1 - t), (L, t)
+        # multiplicities = how many positions map to the row
+        cnt = np.bincount(row_of, minlength=len(w))
+        assert (cnt == np.clip(w, 0, None)).all()
+    plan = ProteinPlan([98, 398, 1022], S, bucket=64)
+    assert plan.rows % 64 == 0 and plan.row_of.shape == (3 * S,) and plan.src.shape == (plan.rows,)
+    assert plan.pays() and not ProteinPlan([1500], S).pays()
+    # flat tables: the representative of position (b, t) reads sample b
+    b_of = plan.src[plan.row_of] // S
+    assert (b_of == np.repeat(np.arange(3), S)).all()
 
 
 def test_ops_reject_cpu_tensors():

@@ -392,15 +392,15 @@ def test_drug_llm_adaptor_compact_padding_equals_the_full_computation(dt, tol):
     ref.pmma.embeddings.p_drop = 0.0
     ref.set_compute_dtype(dt)
     batch, meta = make_batch(4, DEV, seed=11, with_graph=True, llm_dtype=dt)
+    from druglamp_amd.protein_plan import BatchHints
     hints = Trainer.padding_hints_of(meta, batch)
     assert hints == {"drug_tokens": 128}
     cmp_ = copy.deepcopy(ref)
     cmp_.check_padding = True
     feat_d, feat_p, labels, llm_d, llm_p = batch
     outs = []
-    for m, h in ((ref, {}), (cmp_, hints)):
-        with Fn.padding_hints(**h):
-            score = m(feat_d, feat_p, llm_d, llm_p)[-1]
+    for m, h in ((ref, None), (cmp_, BatchHints(**hints))):
+        score = m(feat_d, feat_p, llm_d, llm_p, hints=h)[-1]
         score.float().sum().backward()
         outs.append(score.float())
     assert relerr(outs[1], outs[0]) <= tol
@@ -414,5 +414,11 @@ def test_drug_llm_adaptor_compact_padding_equals_the_full_computation(dt, tol):
             x, y = b.grad.double().flatten(), a.grad.double().flatten()
             assert float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)) >= 0.98, n
     with pytest.raises(ValueError, match="padding rows"):
-        with Fn.padding_hints(drug_tokens=64):
-            cmp_(feat_d, feat_p, llm_d, llm_p)
+        cmp_(feat_d, feat_p, llm_d, llm_p, hints=BatchHints(drug_tokens=64))
+    # ... and with the checks at their DEFAULTS (no host-side check) the device-side guard catches the same mistake:
+    from druglamp_amd import ops
+    ops.check_guard_flags(DEV)                       # clean so far
+    ref(feat_d, feat_p, llm_d, llm_p, hints=BatchHints(drug_tokens=64))
+    with pytest.raises(RuntimeError, match="Drug_Tokens"):
+        ops.check_guard_flags(DEV)
+    ops.check_guard_flags(DEV)                       # the word was cleared

@@ -1,0 +1,218 @@
+"""ProteinCNN on distinct rows (round 4) on the GPU: the row-table kernels against torch, the compact
+module against the full one, the whole model with the plan against the REFERENCE's goldens, the device-side periodicity
+guard, and trainer steps (eager and graph replay) with and without the plan."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import gradnorms, load, model_inputs, relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _plan_dev(lengths, S, bucket=2048):
+    from druglamp_amd.protein_plan import PlanDev, ProteinPlan
+    return PlanDev(ProteinPlan(lengths, S, bucket), DEV)
+
+
+def _tiled(B, S, lengths, seed=0):
+    from druglamp_amd.data import repeat_integer_label
+    rs = np.random.RandomState(seed)
+    ids = torch.zeros(B, S, dtype=torch.float64)
+    fill = torch.zeros(B, S)
+    for b, L in enumerate(lengths):
+        ids[b] = torch.from_numpy(repeat_integer_label(rs.randint(1, 26, L), S))
+        fill[b, (S // (L + 2)) * (L + 2):] = 1.0
+    return ids.to(DEV), fill.to(DEV)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_row_table_kernels_against_torch(dt):
+    from druglamp_amd import ops
+    torch.manual_seed(0)
+    S, lengths = 2304, [98, 398, 1022, 511]
+    pd = _plan_dev(lengths, S, bucket=64)
+    B, R, C = len(lengths), pd.rows, 128
+    ids, fill = _tiled(B, S, lengths)
+    w = torch.randn(27, C - 1, device=DEV).to(dt)
+    x = ops.embed_rows(ids.long(), w, fill.to(dt), pd.src, pd.period)
+    src = pd.src.long()
+    ref = torch.cat((w[ids.long().reshape(-1)[src.clamp(min=0)]], fill.to(dt).reshape(-1)[src.clamp(min=0)].unsqueeze(1)), 1)
+    ref = ref * (src >= 0).unsqueeze(1)
+    assert torch.equal(x, ref)
+    ops.check_guard_flags(DEV)                                        # tiled inputs: the guard stays quiet
+    # gather / strided sums
+    z = torch.randn(R, C, device=DEV).to(dt)
+    full = ops.rows_gather(z, pd.row_of)
+    assert torch.equal(full, z[pd.row_of.long()])
+    g = torch.randn(B * S, C, device=DEV).to(dt)
+    back = ops.rows_sum_strided(g, pd.rep)
+    want = torch.zeros(R, C, device=DEV, dtype=torch.float64).index_add_(0, pd.row_of.long(), g.double())
+    assert relerr(back, want) <= (1e-6 if dt == torch.float32 else 1e-2)
+    # BatchNorm passes with row weights against the weighted definitions
+    y = torch.randn(R, C, device=DEV).to(dt)
+    wr = pd.w
+    sums = ops.bn_stats(y, 0, 0, 0, wr)
+    wp = wr.clamp(min=0).double().unsqueeze(1)
+    yd = y.double()
+    assert relerr(sums[:C], (yd * wp).sum(0)) <= 1e-5 and relerr(sums[C:], (yd * yd * wp).sum(0)) <= 1e-5
+    n = float(wp.sum())
+    mean, var, rstd = ops.bn_finalize(sums, int(n), 1e-5)
+    gam, bet = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    zz = ops.bn_apply_fwd(y, mean, rstd, gam, bet, 0, 0, 0, wr)
+    zr = ((yd - mean.double()) * rstd.double() * gam.double() + bet.double()) * (wr >= 0).unsqueeze(1)
+    assert relerr(zz, zr) <= (1e-5 if dt == torch.float32 else 1e-2)
+    dz = (torch.randn(R, C, device=DEV) * (wr >= 0).unsqueeze(1)).to(dt)
+    s2 = ops.bn_bwd_reduce(dz, y, mean, rstd, 0, 0, 0, wr)
+    yh = (yd - mean.double()) * rstd.double()
+    ok = (wr >= 0).double().unsqueeze(1)
+    assert relerr(s2[:C], (dz.double() * ok).sum(0)) <= 1e-5 and relerr(s2[C:], (dz.double() * yh * ok).sum(0)) <= 1e-5
+    dy = ops.bn_bwd_apply(dz, y, mean, rstd, gam, s2, 1.0 / n, True, 0, 0, 0, wr)
+    want = gam.double() * rstd.double() * (dz.double() - wp * (s2[:C].double() / n + yh * s2[C:].double() / n)) * (yd > 0) * ok
+    assert relerr(dy, want) <= (1e-5 if dt == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_compact_protein_cnn_module_equals_the_full_one(dt, tol):
+    from druglamp_amd.model.basic_model import ProteinCNN
+    torch.manual_seed(1)
+    S, lengths = 2304, [98, 398, 1022, 511, 766, 254, 1150, 13]
+    B = len(lengths)
+    ids, fill = _tiled(B, S, lengths, seed=3)
+    pd = _plan_dev(lengths, S)
+    full = ProteinCNN(128, [128] * 3, [3, 6, 9]).to(DEV).train()
+    full.compute_dtype = dt
+    comp = copy.deepcopy(full)
+    proj = torch.randn(B, 256, 128, device=DEV)
+    outs = []
+    for m, plan in ((full, None), (comp, pd)):
+        z = m(ids, fill.to(dt), site_pool=9, plan=plan)
+        (z.float() * proj).sum().backward()
+        outs.append(z.float())
+    assert relerr(outs[1], outs[0]) <= tol
+    for (n, a), (_, b) in zip(full.named_parameters(), comp.named_parameters()):
+        if dt == torch.float32:
+            assert relerr(b.grad, a.grad) <= 20 * tol, n
+        else:
+            x, y = b.grad.double().flatten(), a.grad.double().flatten()
+            assert float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)) >= 0.995, n
+    for (n, a), (_, b) in zip(full.named_buffers(), comp.named_buffers()):
+        assert relerr(b, a) <= (1e-4 if dt == torch.float32 else 2e-2), n
+    # eval mode (running statistics) through the plan, pooled and unpooled
+    full.eval(), comp.eval()
+    with torch.no_grad():
+        assert relerr(comp(ids, fill.to(dt), site_pool=9, plan=pd), full(ids, fill.to(dt), site_pool=9)) <= tol
+        assert relerr(comp(ids, fill.to(dt), plan=pd), full(ids, fill.to(dt))) <= tol
+
+
+@pytest.mark.parametrize("kind", ["DrugLAMP", "DrugLAMPwoLLM"])
+def test_whole_model_with_the_plan_against_the_reference_goldens(kind):
+    """The goldens of tests/test_model_gpu.py::test_model_eval_and_train (outputs of the imported reference), with the
+    ProteinCNN on distinct rows and the drug-token block hinted: fp32, north-star tolerance."""
+    from druglamp_amd.model.basic_model import binary_cross_entropy
+    from druglamp_amd.protein_plan import BatchHints, lengths_from_codes
+    from tests.test_model_gpu import build, to_dev
+    g = load("model_" + kind)
+    m, _ = build(kind, g)
+
+    def hints(vp):
+        return BatchHints(0, _plan_dev(lengths_from_codes(vp), vp.shape[1]))
+
+    vd, vp, xd, xp, y = to_dev(*model_inputs("model." + kind, 2))
+    m.eval()
+    with torch.no_grad():
+        out = m(vd, vp, xd, xp, hints=hints(vp))
+    assert relerr(out[4], g["score"]) <= 1e-4
+    vd, vp, xd, xp, y = to_dev(*model_inputs("modeltrain." + kind, 8))
+    m.train()
+    m.zero_grad()
+    out = m(vd, vp, xd, xp, hints=hints(vp))
+    assert relerr(out[4], g["score_train"]) <= 1e-3
+    _, loss = binary_cross_entropy(out[4], y)
+    assert abs(float(loss) - float(g["cls_loss"])) <= 1e-4
+    loss.backward()
+    ref = gradnorms(g)
+    sd = dict(m.named_parameters())
+    scale = max(ref.values())
+    for k, n_ref in ref.items():
+        if k.startswith("ssl_model.extractor."):
+            continue
+        got = float(sd[k].grad.double().norm())
+        assert abs(got - n_ref) <= 2e-3 * max(n_ref, 1e-5 * scale), (k, got, n_ref)
+    from druglamp_amd import ops
+    ops.check_guard_flags(DEV)
+
+
+def test_periodicity_guard_rejects_a_batch_that_is_not_tiled():
+    """the tables assume the collate's tiling; a batch without it must be an ERROR with the checks
+    at their defaults, not silently wrong activations."""
+    from druglamp_amd import ops
+    from druglamp_amd.model.basic_model import ProteinCNN
+    S, lengths = 2304, [98, 398]
+    ids, fill = _tiled(2, S, lengths)
+    pd = _plan_dev(lengths, S)
+    m = ProteinCNN(128, [128] * 3, [3, 6, 9]).to(DEV).eval()
+    with torch.no_grad():
+        m(ids, fill, site_pool=9, plan=pd)
+    ops.check_guard_flags(DEV)
+    bad = ids.clone()
+    bad[1, 700] = 25 if float(bad[1, 700]) != 25 else 24            # one residue of a later period differs
+    with torch.no_grad():
+        m(bad, fill, site_pool=9, plan=pd)
+    with pytest.raises(RuntimeError, match="not tiled with the period"):
+        ops.check_guard_flags(DEV)
+    wrong = _plan_dev([99, 398], S)                                  # a wrong length record
+    with torch.no_grad():
+        m(ids, fill, site_pool=9, plan=wrong)
+    with pytest.raises(RuntimeError, match="not tiled with the period"):
+        ops.check_guard_flags(DEV)
+    f2 = fill.clone()
+    f2[0, S - 3] = 0.0                                               # the zero tail's fill bits are not constant
+    with torch.no_grad():
+        m(ids, f2, site_pool=9, plan=pd)
+    with pytest.raises(RuntimeError, match="not tiled with the period"):
+        ops.check_guard_flags(DEV)
+
+
+def _trainer(graph, compact, dt=torch.float32, B=8):
+    from druglamp_amd import ops
+    from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
+    from druglamp_amd.model import MInterface
+    from druglamp_amd.trainer import Trainer
+    torch.manual_seed(5)
+    ops.manual_seed(77)
+    cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP")
+    m = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(DEV)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.pmma.p_drop = 0.0
+    m.pmma.embeddings.p_drop = 0.0
+    m.compact_cnn = compact
+    tr = Trainer(m, cfg, device=torch.device(DEV), compute_dtype=dt, graph_steps=graph)
+    tr.set_lrs(1e-4, 3e-5, 1e-5)
+    return tr
+
+
+def test_training_steps_with_and_without_the_plan_and_as_graph_replays():
+    """Four cls steps + an SSL-epoch step on two alternating batches (different protein lengths): (a) eager with the plan
+    against eager without it — same parameters up to fp32 summation order; (b) graph replays with the plan against eager
+    with the plan — bit-identical (dropout off), including the per-replay refill of the row tables."""
+    from druglamp_amd.synthetic import make_batch
+    batches = [make_batch(8, DEV, seed=s, with_graph=True) for s in (21, 22)]
+    arenas = {}
+    for name, graph, compact in (("full", False, False), ("plan", False, True), ("graph", True, True)):
+        tr = _trainer(graph, compact)
+        for step in range(6):
+            batch, meta = batches[step % 2]
+            tr.training_step(batch, meta=meta, cur_epoch=5 if step == 4 else 1)
+        tr.check_device_flags()
+        arenas[name] = tr.flat.arena.clone()
+        if name == "graph":
+            assert len(tr._graphs) >= 1 and all(g.hints.protein_plan is not None for g in tr._graphs.values())
+    a, b, c = arenas["full"], arenas["plan"], arenas["graph"]
+    assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) and float((a - b).norm() / a.norm()) <= 2e-5
+    assert torch.equal(b, c)
