@@ -49,17 +49,23 @@ def _stale(out, deps):
 # launches per hundred WHEN ANOTHER PROCESS LOADS THE GPU (tools/contention_repeat.py: 8-27 mismatching launches of 80,
 # always pass 1, lanes 48-63, even elements; 0 of 80 without the packed forms) — a timing-dependent forwarding hazard the
 # compiler does not pad.  Found through the two-rank graph-vs-eager bit-identity test.
-# bn.hip / elementwise.hip carry the same unpack-then-fp32 pattern (v_pk_*_f32 behind a bf16 unpack: 361 / 251 packed ops with
-# the vectoriser on) and are HBM-bound, so they get the flag too; gemm / attention keep the vectoriser
+# elementwise.hip carries the same unpack-then-fp32 pattern (251 packed fp32 ops with the vectoriser on) and is HBM-bound: it
+# gets the flag too (same-box step time unchanged).  bn.hip does NOT: built without the vectoriser, the fp32
+# compact-MolecularGCN test (tests/test_model_gpu.py::test_gcn_compact_padding_equals_the_512_row_computation) fails with a
+# 5e-3 gradient error although every dl_bn_* call gives the same result in both builds when issued one at a time
+# (tools/bn_ab.py, tools/bn_ab_model.py) — an unresolved timing- or layout-dependent effect; bn.hip therefore stays on the
+# build that has passed every parity and contention test since round 2.  gemm / attention keep the vectoriser as well
 # (their epilogues rely on the packed forms: 15.70 -> 16.36 ms without) and are covered by tests/test_contention_gpu.py.
-FILE_FLAGS = {"norm.hip": ["-fno-slp-vectorize"], "bn.hip": ["-fno-slp-vectorize"], "elementwise.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"norm.hip": ["-fno-slp-vectorize"], "elementwise.hip": ["-fno-slp-vectorize"]}
 
 
 def _compile(src, force, objdir=OBJDIR, extra=()):
     obj = os.path.join(objdir, src[:-4] + ".o")
     path = os.path.join(CSRC, src)
     if force or _stale(obj, [path] + _headers() + [os.path.abspath(__file__)]):
-        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + list(extra) + ["-c", path, "-o", obj]
+        keep = os.environ.get("DL_BUILD_NOSLP_FILES")           # (A/B builds, tools: comma-separated files that get their FILE_FLAGS)
+        ff = FILE_FLAGS.get(src, []) if (keep is None or src in keep.split(",")) else []
+        cmd = [HIPCC] + FLAGS + ff + list(extra) + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
