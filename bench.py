@@ -95,8 +95,6 @@ def main():
                     help="replay cls steps as a hipGraph (auto: per-GPU batch <= 128)")
     ap.add_argument("--no-weak", action="store_true", help="skip the extra weak-scaling measurement at N > 1")
     ap.add_argument("--seq-len", type=int, default=2304, help="PROTEIN.SEQ_LEN (9216 = 1024 sites: BASELINE config 5, long proteins)")
-    ap.add_argument("--attention", default="native", choices=["native", "fp8"],
-                    help="fp8: PMMA attention forward on MXFP8 MFMA (dl_attn_fwd_fp8; BASELINE config 5)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model", default="DrugLAMP")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,7 +150,6 @@ def main():
     cfg["PROTEIN"]["SEQ_LEN"] = args.seq_len
     cfg["RS"]["DRUG_SSL_TYPE"] = args.drug_ssl
     model = MInterface(args.model, cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
-    model.pmma.attention_precision = args.attention
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     trainer = Trainer(model, cfg, device=dev, compute_dtype=cdt, graph_steps=use_graph)
     trainer.set_lrs(cfg["SOLVER"]["LR"], cfg["SOLVER"]["SSL_LR"], cfg["SOLVER"]["CM_LR"])
@@ -246,16 +243,14 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s training step (%s; fwd+bwd+grad all-reduce+AdamW), BindingDB-shaped synthetic pairs "
                                    "(512 drug nodes/tokens, %d protein tokens = %d sites, pre-extracted 384-d/640-d LLM embeddings), "
-                                   "global batch %d = %d per GPU x %d%s%s%s" % (
+                                   "global batch %d = %d per GPU x %d%s%s" % (
                                        args.model, "+".join(kinds) + " step, epoch %d" % ep, args.seq_len, args.seq_len // 9,
                                        args.batch * world, args.batch, world,
                                        ", step replayed as a hipGraph" if graphed else "",
                                        (", batch-level heads over the all-gathered global batch (RS.GLOBAL_BATCH)" if args.global_batch_cm else "") +
-                                       (", drug SSL = NT-Xent (simclr)" if args.drug_ssl == "simclr" else ""),
-                                       ", PMMA attention forward in MXFP8" if args.attention == "fp8" else ""),
+                                       (", drug SSL = NT-Xent (simclr)" if args.drug_ssl == "simclr" else "")),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "step_kind": "+".join(kinds), "epoch": ep, "hip_graph": bool(graphed), "protein_seq_len": args.seq_len,
-                       "attention": args.attention,
                        # identical padding rows of the drug branch (virtual GCN nodes beyond the adjacency block, zero token rows
                        # beyond the collate's Drug_Tokens) are computed once and expanded: same results as computing every row
                        # (tests/test_model_gpu.py); DL_GCN_COMPACT=0 DL_PAD_COMPACT=0 computes every row
@@ -277,7 +272,7 @@ def main():
             for pmc_name in ("r4_pmc_summary.json",):
                 pmc = os.path.join(ROOT, "profiles", pmc_name)
                 if os.path.exists(pmc) and args.batch == 256 and args.dtype == "bf16" and args.model == "DrugLAMP" and kinds == ["cls"] \
-                        and args.seq_len == 2304 and args.attention == "native":
+                        and args.seq_len == 2304:
                     # HBM bytes per dl_gemm launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
                     # workload (tools/pmc_summary.py; x2 gfx950 read correction), committed under profiles/ — a
                     # recorded counter measurement of the same command, NOT re-measured by this run

@@ -136,8 +136,6 @@ SIGNATURES = {
                                  c_i32, c_i64, c_i64, c_i32, c_vp, c_sz, C.POINTER(ReduceItem), c_vp]),
     "dl_attn_fwd": (c_i32, [C.POINTER(AttnFwdArgs), c_vp]),
     "dl_attn_bwd": (c_i32, [C.POINTER(AttnBwdArgs), c_vp]),
-    "dl_attn_fwd_fp8_workspace_bytes": (c_sz, [C.POINTER(AttnFwdArgs)]),
-    "dl_attn_fwd_fp8": (c_i32, [C.POINTER(AttnFwdArgs), c_vp, c_sz, c_vp]),
     "dl_token_gate_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "dl_token_gate_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "dl_add_rowmod_dropout": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_u64, c_vp, c_i32, c_vp]),

@@ -251,7 +251,7 @@ class TransformerBlockFn(torch.autograd.Function):
     """x: [S, B, L, d] (S = 2 stacked streams when paired, else 1).  Returns the same shape."""
 
     @staticmethod
-    def forward(ctx, x, paired, H, p_drop, training, eps, attn_fp8, *params):
+    def forward(ctx, x, paired, H, p_drop, training, eps, *params):
         S, B, L, d = x.shape
         assert S == (2 if paired else 1)
         cdt = x.dtype
@@ -279,8 +279,7 @@ class TransformerBlockFn(torch.autograd.Function):
         os_ = (L * nseg * d, hd, nseg * d)
         lse = ops.attn_fwd(qkv, qkv[..., d:], qkv[..., 2 * d:], n_problems=S * B, n_heads=H, n_segments=nseg,
                            partner_shift=B if paired else 0, Lq=L, Lk=L, head_dim=hd, scale=1.0 / math.sqrt(hd),
-                           q_strides=qs, k_strides=qs, v_strides=qs, out=a, o_strides=os_, o_ss=d,
-                           fp8=bool(attn_fp8) and cdt == torch.bfloat16)
+                           q_strides=qs, k_strides=qs, v_strides=qs, out=a, o_strides=os_, o_ss=d)
         out = torch.empty_like(x)
         saved: List[torch.Tensor] = [x, qkv, a, lse]
         seeds = [((ops.next_seed(), ops.next_seed()) if p_eff > 0 else (0, 0)) for _ in range(S)]
@@ -367,13 +366,11 @@ class TransformerBlockFn(torch.autograd.Function):
             out_grads += [dg1, dbt1, dwqkv[0:d], dbqkv[0:d], dwqkv[d:2 * d], dbqkv[d:2 * d], dwqkv[2 * d:],
                           dbqkv[2 * d:]]
             out_grads += list(grads_tail[s])
-        return (dx, None, None, None, None, None, None) + tuple(out_grads)
+        return (dx, None, None, None, None, None) + tuple(out_grads)
 
 
-def transformer_block(x, paired: bool, H: int, p_drop: float, training: bool, eps: float, params, attn_fp8: bool = False):
-    """attn_fp8: the attention FORWARD of the block runs in MXFP8 (bf16 compute dtype only; backward stays bf16 and
-    uses the forward's log-sum-exp)."""
-    return TransformerBlockFn.apply(x, paired, H, p_drop, training, eps, attn_fp8, *params)
+def transformer_block(x, paired: bool, H: int, p_drop: float, training: bool, eps: float, params):
+    return TransformerBlockFn.apply(x, paired, H, p_drop, training, eps, *params)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -130,9 +130,6 @@ class PairedMultimodelAttention(nn.Module):
         self.vis = vis
         self.compute_dtype = torch.float32
         self.keep_compute_dtype = False
-        # "native": attention in the compute dtype.  "fp8": with bf16 compute, QK^T and PV of every block's attention
-        # forward run on MXFP8 MFMA (dl_attn_fwd_fp8; BASELINE config 5).  No reference counterpart — off by default.
-        self.attention_precision = "native"
 
     def forward(self, prot, mol=None):
         if mol is None:
@@ -144,9 +141,6 @@ class PairedMultimodelAttention(nn.Module):
         cdt = self.compute_dtype
         emb, enc = self.embeddings, self.encoder
         H, p, tr = self.num_heads, self.p_drop, self.training
-        if self.attention_precision not in ("native", "fp8"):
-            raise ValueError("attention_precision must be 'native' or 'fp8'")
-        f8 = self.attention_precision == "fp8" and cdt == torch.bfloat16
         prot = Fn.cast(prot, cdt)
         mol = Fn.cast(mol, cdt)
         mol = Fn.LinearFn.apply(mol, emb.mol_embeddings.weight, emb.mol_embeddings.bias, emb.pe_mol, p, tr)
@@ -159,7 +153,7 @@ class PairedMultimodelAttention(nn.Module):
                     w, gw = Fn.attention_maps(x, blk, H, paired=True)
                     attn_maps.append(w)
                     guided_maps.append(gw)
-                x = Fn.transformer_block(x, True, H, p, tr, 1e-6, blk.stream_params(0) + blk.stream_params(1), attn_fp8=f8)
+                x = Fn.transformer_block(x, True, H, p, tr, 1e-6, blk.stream_params(0) + blk.stream_params(1))
             else:
                 if i == 2:
                     x = _concat_streams(x)                             # [1, B, L, 2d]
@@ -167,7 +161,7 @@ class PairedMultimodelAttention(nn.Module):
                     w, _ = Fn.attention_maps(x, blk, H, paired=False)
                     attn_maps.append(w)
                     guided_maps.append(None)
-                x = Fn.transformer_block(x, False, H, p, tr, 1e-6, blk.stream_params(0), attn_fp8=f8)
+                x = Fn.transformer_block(x, False, H, p, tr, 1e-6, blk.stream_params(0))
         if x.shape[0] == 2:                                       # fewer than 3 layers configured
             x = _concat_streams(x)
         encoded = Fn.layer_norm(x.reshape(x.shape[1:]), enc.encoder_norm.weight, enc.encoder_norm.bias, 1e-6)

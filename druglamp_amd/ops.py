@@ -357,9 +357,8 @@ def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 def attn_fwd(q, k, v, *, n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, scale,
-             q_strides, k_strides, v_strides, out, o_strides, o_ss, need_lse=True, raw_logits=None, algo=0, fp8=False):
-    """Strides are (problem, head, row) in elements.  Returns the LSE tensor (or None).
-    fp8=True: MXFP8 forward (dl_attn_fwd_fp8: e4m3 operands with E8M0 block scales, fp32 softmax / accumulate)."""
+             q_strides, k_strides, v_strides, out, o_strides, o_ss, need_lse=True, raw_logits=None, algo=0):
+    """Strides are (problem, head, row) in elements.  Returns the LSE tensor (or None)."""
     _need_gpu(q, k, v, out)
     a = AttnFwdArgs()
     a.Q, a.K, a.V, a.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
@@ -377,11 +376,6 @@ def attn_fwd(q, k, v, *, n_problems, n_heads, n_segments, partner_shift, Lq, Lk,
     a.Lq, a.Lk, a.head_dim, a.dtype = Lq, Lk, head_dim, _dt(q)
     a.scale = float(scale)
     a.algo = algo
-    if fp8:
-        L = _lib.lib()
-        ws = _ws.get(L.dl_attn_fwd_fp8_workspace_bytes(C.byref(a)), q.device)
-        check(L.dl_attn_fwd_fp8(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "dl_attn_fwd_fp8")
-        return lse
     check(_lib.lib().dl_attn_fwd(C.byref(a), _stream()), "dl_attn_fwd")
     return lse
 

@@ -279,14 +279,6 @@ typedef struct {
 } dl_attn_bwd_args;
 int dl_attn_bwd(const dl_attn_bwd_args* a, dl_stream s);
 
-/* MXFP8 forward (BASELINE.json config 5: long proteins, fp8 MFMA attention): same arguments and addressing as
- * dl_attn_fwd (dtype must be DL_BF16, raw_logits NULL).  Q / K / V are quantised to e4m3 with one E8M0 scale per
- * 32-element block into `workspace` (three small launches), then QK^T and PV both run on
- * v_mfma_scale_f32_32x32x64_f8f6f4 with fp32 softmax statistics and accumulation; O is bf16, LSE fp32 as above.
- * No reference counterpart (the reference computes attention in fp32, model/PMMA/attention.py:109-122); parity is
- * stated as a tolerance against the reference's fp32 outputs in tests/test_long_protein_gpu.py. */
-size_t dl_attn_fwd_fp8_workspace_bytes(const dl_attn_fwd_args* a);
-int dl_attn_fwd_fp8(const dl_attn_fwd_args* a, void* workspace, size_t workspace_bytes, dl_stream s);
 
 /* ------------------------------------------------------------------------------------------
  * MHLA token gate (MultiHeadLinearAttention.forward, model/PMMA/encoder.py:127-140):
@@ -493,7 +485,7 @@ int dl_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
 /* ------------------------------------------------------------------------------------------
  * Kernel timing hooks used by bench.py for the roofline object: when enabled for a kernel
  * family, launches are bracketed by hipEventRecord on their own stream.
- * family: 0 gemm, 1 attn_fwd, 2 attn_bwd, 3 layernorm, 4 attn_fwd_fp8 (quantisation + attention), 5 ntxent_fwd, 6 ntxent_bwd.
+ * family: 0 gemm, 1 attn_fwd, 2 attn_bwd, 3 layernorm, 4 (unused since round 4), 5 ntxent_fwd, 6 ntxent_bwd.
  * These event lists are the library's ONLY process-global state; they exist while a family is enabled and are
  * never touched otherwise (dl_prof_enable(family, 0) frees them).
  * dl_prof_enable(family, on): on = 0 off; on = N >= 1 times one launch in N of the family, picked by a hash

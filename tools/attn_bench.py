@@ -40,23 +40,3 @@ for name, P, H, S, shift, Lq, Lk, hd in ([] if long_only else cases):
     print("%-12s fwd %.0f -> %.0f us (%.0f -> %.0f TF/s)   bwd %.0f -> %.0f us (%.0f -> %.0f TF/s)   maxdiff o/lse/dq/dk/dv %s" % (
         name, res["0"][5], res["1"][5], fl / res["0"][5] / 1e6, fl / res["1"][5] / 1e6, res["0"][6], res["1"][6],
         3.5 * fl / res["0"][6] / 1e6, 3.5 * fl / res["1"][6] / 1e6, ["%.2g" % x for x in diffs]), flush=True)
-
-# ---- BASELINE config 5: 1024 protein sites, bf16 vs MXFP8 forward (dl_attn_fwd_fp8 = quantisation + attention) ----
-print("long-protein attention, forward only: bf16 (streamed K/V tiles) vs MXFP8 (e4m3 + E8M0 block scales, 32x32x64 MFMA)")
-for name, P, H, S, shift, L, hd in [("pmma paired L=1024 (B=64)", 128, 4, 2, 64, 1024, 64), ("pmma self L=1024 (B=64)", 64, 4, 1, 0, 1024, 128),
-                                    ("pmma paired L=1024 (B=256)", 512, 4, 2, 256, 1024, 64), ("pmma self L=1024 (B=256)", 256, 4, 1, 0, 1024, 128)]:
-    d = H * hd
-    qkv = (torch.randn(P * L, 3 * d, device=dev) * 0.5).to(dt)
-    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-    st = (L * 3 * d, hd, 3 * d)
-    res = {}
-    for fp8 in (False, True):
-        o = torch.zeros(S, P * L, d, device=dev, dtype=dt)
-        f = lambda: ops.attn_fwd(q, k, v, n_problems=P, n_heads=H, n_segments=S, partner_shift=shift, Lq=L, Lk=L, head_dim=hd,
-                                 scale=hd ** -0.5, q_strides=st, k_strides=st, v_strides=st, out=o, o_strides=(L * d, hd, d), o_ss=P * L * d, fp8=fp8)
-        f(); torch.cuda.synchronize()
-        res[fp8] = (timeit(f), o.clone())
-    fl = 4.0 * S * P * H * L * L * hd
-    diff = float((res[True][1].float() - res[False][1].float()).abs().max() / res[False][1].float().abs().max())
-    print("%-28s bf16 %.0f us (%.0f TF/s)   fp8 %.0f us (%.0f TF/s)   speed-up %.2fx   max |fp8 - bf16| / max |bf16| = %.3f" % (
-        name, res[False][0], fl / res[False][0] / 1e6, res[True][0], fl / res[True][0] / 1e6, res[False][0] / res[True][0], diff), flush=True)
