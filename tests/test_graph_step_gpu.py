@@ -43,14 +43,18 @@ def test_graphed_steps_are_bit_identical_to_eager_steps_without_dropout():
     from druglamp_amd.synthetic import make_batch
     batch, meta = make_batch(8, DEV, seed=7, with_graph=True, llm_dtype=torch.bfloat16)
     other, meta2 = make_batch(8, DEV, seed=8, with_graph=True, llm_dtype=torch.bfloat16)
-    seq = [batch, batch, batch, batch, other, batch]          # steps 3.. are replays; step 5 brings new data
+    # steps 3.. are replays; step 5 brings new data (its own meta: the batch's protein lengths are what the ProteinCNN row
+    # tables are built from — round 4 — and the device-side guard rejects records that do not belong to the batch)
+    seq = [(batch, meta), (batch, meta), (batch, meta), (batch, meta), (other, meta2), (batch, meta)]
     res = {}
     try:
         for graph in (False, True):
             tr = _make(0.0, graph)
-            losses = [float(tr.training_step(b, meta=meta, cur_epoch=1)["cls"]) for b in seq]
+            losses = [float(tr.training_step(b, meta=mt, cur_epoch=1)["cls"]) for b, mt in seq]
+            tr.check_device_flags()
             if graph:
-                assert len(tr._graphs) == 1 and next(iter(tr._graphs.values())).replays == len(seq) - tr.graph_warmup
+                # (one graph per table shape: the two batches' row counts fall into the same 2048-row bucket or not)
+                assert 1 <= len(tr._graphs) <= 2 and sum(g.replays for g in tr._graphs.values()) >= len(seq) - 2 * tr.graph_warmup
             res[graph] = (losses, _state(tr))
     finally:
         ops.use_seed_offset(False)
@@ -109,9 +113,12 @@ def test_cm_steps_replay_a_graph_bit_identical_to_eager_steps():
             for b, mt in seq:
                 o = tr.training_step(b, meta=mt, cur_epoch=6)
                 outs.append((float(o["cls"]), float(o["cm"])))
+            tr.check_device_flags()
             if graph:
-                (sig, g), = tr._graphs.items()
-                assert g.kind == "cm" and g.replays == len(seq) - tr.graph_warmup and sig[-2:] == (tr.model.cm_model.m_sch_loss_fn.margin, 10.0)
+                # (one graph per ProteinCNN row-table shape: the other batch's row count may fall into another bucket)
+                assert 1 <= len(tr._graphs) <= 2 and sum(g.replays for g in tr._graphs.values()) >= 1
+                for sig, g in tr._graphs.items():
+                    assert g.kind == "cm" and sig[-2:] == (tr.model.cm_model.m_sch_loss_fn.margin, 10.0)
             res[graph] = (outs, _state(tr) + (tr.opt_cm.exp_avg.clone(), tr.opt_cm.exp_avg_sq.clone()))
     finally:
         ops.use_seed_offset(False)
