@@ -329,6 +329,21 @@ def main():
                                              "hbm_achieved_GBps": round(gb2, 1), "hbm_frac": round(gb2 / HBM_PEAK_GBPS, 4),
                                              "launches": n2_all, "timed_launches": n2, "avg_launch_us": round(ms2 * 1e3 / n2, 2),
                                              "time_share_of_step": round(ms2 * n2_all / n2 / (events_dt * 1e3), 3)}
+            # attention BLOCK level (the 40 %-of-MFMA target only makes sense with the projections counted in): the
+            # QKV / fc / out projections (forward and data gradients, tag qkv_out) + the attention cores of every PMMA layer
+            # and of PGCA, flops over time
+            sub = fam_stats.get("gemm_sub", {}).get("qkv_out")
+            if sub and sub[0] and fam_stats["attn_fwd"][0] and fam_stats["attn_bwd"][0]:
+                fl_b, ms_b = sub[5], sub[1] * sub[4] / sub[0]
+                for name in ("attn_fwd", "attn_bwd"):
+                    n2, ms2, fl2, _, n2_all, fl2_all, _ = fam_stats[name]
+                    fl_b += fl2_all
+                    ms_b += ms2 * n2_all / n2
+                tf_b = fl_b / (ms_b * 1e-3) / 1e12
+                out["roofline"]["attention_block"] = {
+                    "what": "QKV / fc / out projections (fwd + dgrad) + attention cores (fwd + bwd), all PMMA layers and PGCA",
+                    "achieved": round(tf_b, 2), "unit": "TFLOP/s", "mfma_frac": round(tf_b / peak, 4),
+                    "ms_per_step": round(ms_b / events_steps, 3)}
         if weak is not None:
             out["weak"] = weak
         if not args.no_cpu_baseline and world == 1:

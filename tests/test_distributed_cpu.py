@@ -67,6 +67,18 @@ def _gather_worker(rank, world, port, q):
     ok &= bool(torch.allclose(x.grad, expect))
     meta = dist_ops.all_gather_meta([{"Prot_ID": "p%d" % rank, "Drug_ID": rank, "Y": 1.0}])
     ok &= [m["Prot_ID"] for m in meta] == ["p0", "p1"]
+    # round 4: the global-batch CM head gathers INTEGER id codes as one tensor collective and builds the label matrix of the
+    # gathered batch on the device — equal to the host label matrix of the concatenated records on every rank
+    from druglamp_amd.model.cross_modality import DeviceLabels, label_matrix
+    allmeta = [{"Prot_ID": "p%d" % (i % 3), "Drug_ID": (i * 5) % 4, "Y": float(i % 2)} for i in range(8)]
+    mine = allmeta[rank * 4:(rank + 1) * 4]
+    codes = dist_ops.all_gather_codes(torch.from_numpy(dist_ops.id_codes(mine)))
+    ok &= tuple(codes.shape) == (8, 3)
+    lab = DeviceLabels(codes, use_cm=True)
+    pidx, didx, gt = label_matrix(allmeta, True)
+    n_p, n_d = len(pidx), len(didx)
+    ok &= int(lab.n[0]) == n_p and int(lab.n[1]) == n_d and lab.idx[0][:n_p].tolist() == pidx and lab.idx[1][:n_d].tolist() == didx
+    ok &= bool((lab.gt[:n_p, :n_d].numpy() == gt).all())
     q.put((rank, ok))
     dist.destroy_process_group()
 
