@@ -166,6 +166,14 @@ def refresh_images() -> None:
     _refresh_all_images()
 
 
+def ensure_images_current() -> None:
+    """Refresh the weight images on the CURRENT stream if the masters moved since the last refresh.  A forward that forks
+    onto side streams calls this first: the refresh is otherwise triggered by whichever lowp() call comes first — on
+    whichever stream that branch runs — and the other branches would read images that are still being rewritten."""
+    if any(e.epoch != _param_epoch for e in _lowp_cache.values()):
+        _refresh_all_images()
+
+
 def lowp(params: Sequence[torch.Tensor], dtype: torch.dtype, transpose: bool = False, pad=None) -> torch.Tensor:
     """Compute-dtype tensor holding cat(params, dim=0) (a single fp32 param is returned as is in fp32).
     transpose=True gives the [in][out] copy used by the data-gradient products, so that those are

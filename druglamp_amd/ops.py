@@ -61,7 +61,9 @@ class _Workspace:
             # first time an eager call needs more room, and a later replay would write through the stale address.  Scratch
             # taken during capture comes from the graph's own pool and stays reserved for as long as the graph lives.
             return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
-        key = (device.type, device.index)
+        # one buffer per (device, stream): launches that share it are stream-ordered; branches of the forward that run on
+        # side streams (DL_BRANCH_STREAMS) get their own
+        key = (device.type, device.index, _stream() if device.type == "cuda" else 0)
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

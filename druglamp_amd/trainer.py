@@ -489,6 +489,8 @@ class Trainer:
         if self.overlap is not None:
             ops.dynamic_tiles(True)      # persistent GEMMs hand their tiles out dynamically while collectives share the CUs
             ops.reset_tickets()
+            if hasattr(model, "branch_streams"):
+                model.branch_streams = False     # bucket all-reduces are issued from backward hooks: keep them on one stream
         # hook-driven collectives cannot be launched from inside a graph replay: graphed steps reduce after the replay
         self.graph_steps = bool(graph_steps) and self.overlap is None
         self._graphs: Dict[tuple, GraphedStep] = {}

@@ -417,7 +417,9 @@ def test_drug_llm_adaptor_compact_padding_equals_the_full_computation(dt, tol):
         cmp_(feat_d, feat_p, llm_d, llm_p, hints=BatchHints(drug_tokens=64))
     # ... and with the checks at their DEFAULTS (no host-side check) the device-side guard catches the same mistake:
     from druglamp_amd import ops
-    ops.check_guard_flags(DEV)                       # clean so far
+    with pytest.raises(RuntimeError, match="Drug_Tokens"):
+        ops.check_guard_flags(DEV)                   # (the guard launch of the call above ran before the host-side check raised)
+    ops.check_guard_flags(DEV)                       # cleared
     ref(feat_d, feat_p, llm_d, llm_p, hints=BatchHints(drug_tokens=64))
     with pytest.raises(RuntimeError, match="Drug_Tokens"):
         ops.check_guard_flags(DEV)
