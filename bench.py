@@ -213,17 +213,23 @@ def main():
         return float(t), stats
 
     timing = not args.no_kernel_timing
-    # HIP events bracket library launches as they are enqueued; the nodes of a replayed graph cannot be bracketed, so a
-    # graphed run takes its kernel timings from a separate instrumented pass of eager steps (same process, same data)
-    dt, fam_stats = measure(args.batch, args.steps, args.warmup, timing and not graphed, busy=True)
-    events_steps, events_dt, events_note = args.steps, dt, "HIP events over the timed region"
-    if timing and graphed:
-        trainer.graph_steps = False
+    # The timed region runs the product configuration: on cls steps the forward's independent branches (and their backward
+    # passes) share the chip on side HIP streams, per-GPU batches <= 128 replay a hipGraph.  Kernel timings for the roofline
+    # object come from a SEPARATE instrumented pass of eager ONE-STREAM steps run right after it (same process, same data,
+    # same kernels): HIP events bracket a launch on its stream, and a launch that shares the chip with another stream's
+    # kernels — or is a node of a replayed graph — has no duration of its own to bracket.
+    dt, fam_stats = measure(args.batch, args.steps, args.warmup, False, busy=True)
+    events_steps, events_dt, events_note = args.steps, dt, None
+    if timing:
+        saved = (trainer.graph_steps, model.branch_streams)
+        trainer.graph_steps, model.branch_streams = False, False
         events_steps = min(args.steps, 20)
         events_dt, fam_stats = measure(args.batch, events_steps, 2, True)
-        trainer.graph_steps = True
-        events_note = ("HIP events over %d EAGER steps run right after the timed region (the timed region replays a hipGraph, "
-                       "whose nodes cannot be bracketed by events; same kernels, same data)" % events_steps)
+        trainer.graph_steps, model.branch_streams = saved
+        events_note = ("HIP events over %d eager one-stream steps run right after the timed region (%.3f ms per step there; the timed "
+                       "region %s: its launches overlap or are graph nodes and cannot be bracketed one by one; same kernels, same data)"
+                       % (events_steps, events_dt / events_steps * 1e3,
+                          "replays a hipGraph" if graphed else "runs the forward's independent branches on side HIP streams"))
     weak = None
     if world > 1 and scaling == "strong" and not args.no_weak:
         wsteps = max(10, min(args.steps // 4, 50))
@@ -258,7 +264,9 @@ def main():
                                                            os.environ.get("DL_PAD_COMPACT", "1") != "0") else "every row",
                        # the tiled protein sequences (period L + 2, utils.py:392-412) carry ~L + 31 distinct ProteinCNN rows of
                        # 2304: the CNN runs on those (weighted BatchNorm, device-side periodicity guard); DL_CNN_COMPACT=0 = all
-                       "protein_cnn_rows": "distinct rows" if os.environ.get("DL_CNN_COMPACT", "1") != "0" else "every position"},
+                       "protein_cnn_rows": "distinct rows" if os.environ.get("DL_CNN_COMPACT", "1") != "0" else "every position",
+                       # cls steps run MolecularGCN / ProteinCNN / the LLM adaptors / the v cross-attention branch concurrently
+                       "streams": "independent branches on side HIP streams" if (model.branch_streams and kinds == ["cls"]) else "one stream"},
             # (the per-pair flop count of BASELINE.md section 3 is for 256 sites; not applicable to other lengths)
             "hot_path_tflops_per_gpu": round(value * HOT_FLOPS_PER_PAIR_STEP / world / 1e12, 2) if args.seq_len == 2304 else None,
             "hot_path_frac_of_peak": round(value * HOT_FLOPS_PER_PAIR_STEP / world / 1e12 / peak, 4) if args.seq_len == 2304 else None,

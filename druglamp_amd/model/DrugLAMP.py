@@ -19,7 +19,7 @@ class DrugLAMP(DrugLAMPBase):
             return self._forward(vd, vp, xd, xp, mode, hints)
 
     def _forward(self, vd, vp, xd, xp, mode, hints=None):
-        if self.branch_streams and xp.is_cuda:
+        if self.branch_streams and hints is not None and hints.branch_streams and xp.is_cuda:
             return self._forward_branches(vd, vp, xd, xp, mode, hints)
         vd = self.drug_extractor(vd)
         # one pass over each LLM tensor: fill bit + (site-pooled) fill-bit-augmented features, already padded

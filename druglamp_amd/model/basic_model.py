@@ -276,9 +276,9 @@ class DrugLAMPBase(nn.Module):
         self.check_padding = os.environ.get("DL_PAD_CHECK", "0") == "1"         # debug: verify the padding rows on the host (sync)
         self.guard_padding = os.environ.get("DL_PAD_GUARD", "1") != "0"         # device-side check of the padding rows (no sync)
         self.compact_cnn = os.environ.get("DL_CNN_COMPACT", "1") != "0"         # A/B switch: ProteinCNN on distinct rows
-        # Independent branches of the forward (MolecularGCN, ProteinCNN, the two LLM adaptors, the v / x cross-attention
-        # branches) on side HIP streams — and, through autograd, their backward passes: measured 13.67 -> 12.97 ms at batch
-        # 256 and 4.02 -> 3.82 ms at batch 32 (hipGraph replay: parallel branches of the graph).  DL_BRANCH_STREAMS=0: one stream.
+        # Independent branches of the forward (MolecularGCN, ProteinCNN, the two LLM adaptors, the v cross-attention branch)
+        # on side HIP streams — and, through autograd, their backward passes — when the caller's hints ask for it
+        # (BatchHints.branch_streams: the trainer does on cls steps).  DL_BRANCH_STREAMS=0: never.
         self.branch_streams = os.environ.get("DL_BRANCH_STREAMS", "1") != "0"
         self._streams = None
         self.drug_extractor = MolecularGCN(in_feats=cfg["DRUG"]["NODE_IN_FEATS"], dim_embedding=n_hidden,

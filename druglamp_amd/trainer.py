@@ -260,7 +260,7 @@ class GraphedStep:
         self.tr = trainer
         dev = trainer.device
         self.static = self._clone(batch)
-        self.hints = trainer.hints_of(meta, batch, own_tables=True)       # (this graph's own device tables: refilled per replay)
+        self.hints = trainer.hints_of(meta, batch, own_tables=True, kind=kind)   # (this graph's own device tables: refilled per replay)
         self.labels = None
         if "cm" in kind:
             from .model.cross_modality import CMCodes, CMLabels
@@ -489,8 +489,7 @@ class Trainer:
         if self.overlap is not None:
             ops.dynamic_tiles(True)      # persistent GEMMs hand their tiles out dynamically while collectives share the CUs
             ops.reset_tickets()
-            if hasattr(model, "branch_streams"):
-                model.branch_streams = False     # bucket all-reduces are issued from backward hooks: keep them on one stream
+            # (bucket all-reduces are issued from backward hooks: hints_of keeps the forward on one stream then)
         # hook-driven collectives cannot be launched from inside a graph replay: graphed steps reduce after the replay
         self.graph_steps = bool(graph_steps) and self.overlap is None
         self._graphs: Dict[tuple, GraphedStep] = {}
@@ -614,7 +613,7 @@ class Trainer:
         from .protein_plan import plan_of
         return plan_of([int(m_["Prot_Len"]) for m_ in meta], int(vp.shape[1]))
 
-    def hints_of(self, meta, batch, own_tables: bool = False):
+    def hints_of(self, meta, batch, own_tables: bool = False, kind: str = "cls"):
         """BatchHints for model(..., hints=...): the drug-token block (padding_hints_of) and the ProteinCNN plan's device
         tables.  Eager steps share one table set per shape (refilled in place, stream-ordered); own_tables=True gives the
         caller its own (a captured graph keeps pointing at them)."""
@@ -633,7 +632,10 @@ class Trainer:
                 else:
                     pd.fill(plan)
                 self._plan_devs[plan.key] = pd           # most recently used last
-        return BatchHints(self.padding_hints_of(meta, batch).get("drug_tokens", 0), pd)
+        # side streams for the forward's independent branches on cls steps only (measured; BatchHints.__init__), and never
+        # while gradient buckets are reduced from backward hooks (one stream for the collectives)
+        return BatchHints(self.padding_hints_of(meta, batch).get("drug_tokens", 0), pd,
+                          branch_streams=(kind == "cls" and self.overlap is None))
 
     # -- device-side padding guards (ops.guard_flags): polled without a host sync, checked with one on demand -------------
     def _poll_guard(self):
@@ -702,7 +704,8 @@ class Trainer:
                 self._eager_seen.clear()
             self._eager_seen[sig] = self._eager_seen.get(sig, 0) + 1
         feat_d, feat_p, labels, llm_d, llm_p = batch
-        _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p, hints=self.hints_of(meta, batch))
+        kind_now = "cm" if compute_cm else "ssl" if compute_ssl else "cls"
+        _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p, hints=self.hints_of(meta, batch, kind=kind_now))
         self._zero_grad()
         _, cls_loss = binary_cross_entropy(score, labels) if self.n_class == 1 else cross_entropy_logits(score, labels)
         last = "cm" if compute_cm else "ssl" if compute_ssl else "cls"     # the backward the optimisers consume

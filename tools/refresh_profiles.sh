@@ -28,6 +28,9 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pmc_w.log" 2>&1
 F=$(find "$OUT/pmc_f" -name '*counter_collection.csv' | head -1); W=$(find "$OUT/pmc_w" -name '*counter_collection.csv' | head -1)
 python3 "$ROOT/tools/pmc_summary.py" "$F" "$W" "$OUT/pmc_summary.json" > "$OUT/pmc_summary.txt" 2>&1
+python3 "$ROOT/bench.py" --graph on --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_batch256_graph.json"
+DL_BRANCH_STREAMS=0 python3 "$ROOT/bench.py" --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_one_stream.json"
+DL_CNN_COMPACT=0 python3 "$ROOT/bench.py" --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_cnn_every_position.json"
 python3 "$ROOT/tools/gemm_shapes.py" > "$OUT/gemm_shapes.txt" 2>&1
 python3 "$ROOT/tools/gemm_shapes.py" --batch 32 > "$OUT/gemm_shapes_batch32.txt" 2>&1
 python3 "$ROOT/tools/cpu_baseline_sweep.py" > "$OUT/cpu_baseline_sweep.jsonl" 2>/dev/null
