@@ -37,8 +37,8 @@ class DrugLAMP(DrugLAMPBase):
         xpc, xdc = self._llm_adaptors(xp, xd, hints.drug_tokens if hints is not None else 0)
         vpf = vpc.float()                                                       # fp32 copies only for the returned tuple
         cp = {"prot": vpf, "aug_prot": xpc.float(), "drug": vd.float(), "aug_drug": xdc.float()} if self.two_c2p else None
-        mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, vdc)
-        mx, self.A_x_gca = self._gca_branch(self.x_gca, self.x_mhla, self.x_gca_norm, xpc, xdc)
+        mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, vdc, raw=(hints is None or hints.raw_attention))
+        mx, self.A_x_gca = self._gca_branch(self.x_gca, self.x_mhla, self.x_gca_norm, xpc, xdc, raw=(hints is None or hints.raw_attention))
         f, self.attn, self.guide_attn = self.pmma(mx, mv)
         with self._glue():
             score = self.mlp_classifier(Fn.TokenMeanFn.apply(f))
@@ -81,10 +81,10 @@ class DrugLAMP(DrugLAMPBase):
         # hipStreamEndCapture of the step crash on ROCm 7.2)
         sa.wait_stream(cur)
         with torch.cuda.stream(sa):
-            mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, vdc)
+            mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, vdc, raw=(hints is None or hints.raw_attention))
         cur.wait_stream(sb)
         cur.wait_stream(sc)
-        mx, self.A_x_gca = self._gca_branch(self.x_gca, self.x_mhla, self.x_gca_norm, xpc, xdc)
+        mx, self.A_x_gca = self._gca_branch(self.x_gca, self.x_mhla, self.x_gca_norm, xpc, xdc, raw=(hints is None or hints.raw_attention))
         cur.wait_stream(sa)
         # produced on one stream, consumed (or freed) on another: tell the caching allocator
         for t, sts in ((vd, (cur,)), (xpc, (cur,)), (xdc, (cur,)), (mv, (cur,)), (xps, (sb,)), (xdp, (sc,)), (vpc, (sa,))):

@@ -351,10 +351,13 @@ class DrugLAMPBase(nn.Module):
         n_site = self.seq_len_q // self.site_len
         return t.view(-1, self.site_len, n_site, t.size(-1)).mean(dim=1)
 
-    def _gca_branch(self, gca, mhla, norm, prot_sites, drug_nodes):
-        """PGCA -> concat -> MHLA + residual -> LayerNorm (DrugLAMP.py:55-71).  Returns (m, raw logits)."""
+    def _gca_branch(self, gca, mhla, norm, prot_sites, drug_nodes, raw=True):
+        """PGCA -> concat -> MHLA + residual -> LayerNorm (DrugLAMP.py:55-71).  Returns (m, raw logits).
+        raw=False (BatchHints.raw_attention, the trainer's steps): the (B, 1, 256, 512) fp32 pre-softmax logits the reference
+        keeps on self.A_*_gca for get_cross_attn_mat (basic_model.py:123-129) are not written — 134 MB per branch and step at
+        batch 256 that nothing in a training step reads."""
         m, raw = gca(prot_sites.permute(1, 0, 2), drug_nodes.permute(1, 0, 2), drug_nodes.permute(1, 0, 2),
-                     need_weights=self.keep_raw_attention, need_raw=True)
+                     need_weights=self.keep_raw_attention and raw, need_raw=True)
         g = m.permute(1, 0, 2)
         if prot_sites.dtype != g.dtype:
             prot_sites = Fn.cast(prot_sites, g.dtype)

@@ -237,9 +237,10 @@ class BatchHints:
       protein_plan  PlanDev tables of the ProteinCNN compact layout (from the proteins' residue counts)
       branch_streams  see __init__
     The first two are verified on the device (ops.guard_flags)."""
-    __slots__ = ("drug_tokens", "protein_plan", "branch_streams")
+    __slots__ = ("drug_tokens", "protein_plan", "branch_streams", "raw_attention")
 
-    def __init__(self, drug_tokens: int = 0, protein_plan=None, branch_streams: bool = False):
+    def __init__(self, drug_tokens: int = 0, protein_plan=None, branch_streams: bool = False, raw_attention: bool = True):
+        self.raw_attention = bool(raw_attention)      # False: the PGCA raw-logit maps (A_v_gca / A_x_gca) are not produced
         self.drug_tokens = int(drug_tokens or 0)
         self.protein_plan = protein_plan
         # run the forward's independent branches on side HIP streams (model/DrugLAMP.py): the trainer asks for it on the

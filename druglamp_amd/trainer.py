@@ -635,7 +635,8 @@ class Trainer:
         # side streams for the forward's independent branches on cls steps only (measured; BatchHints.__init__), and never
         # while gradient buckets are reduced from backward hooks (one stream for the collectives)
         return BatchHints(self.padding_hints_of(meta, batch).get("drug_tokens", 0), pd,
-                          branch_streams=(kind == "cls" and self.overlap is None))
+                          branch_streams=(kind == "cls" and self.overlap is None),
+                          raw_attention=False)       # (a training step never reads the PGCA raw-logit maps: reference trainer.py:179-231)
 
     # -- device-side padding guards (ops.guard_flags): polled without a host sync, checked with one on demand -------------
     def _poll_guard(self):

@@ -47,7 +47,8 @@ def test_default_line_has_the_contract_keys():
 def test_small_batch_line_replays_a_graph_and_says_so():
     d = _run("--batch", "32", "--steps", "6", "--warmup", "4", "--no-cpu-baseline")
     assert d["config"]["hip_graph"] is True and d["scaling"] == "weak" and d["config"]["per_gpu_batch"] == 32
-    assert "EAGER" in d["roofline"]["timing_source"] and "cpu_baseline" not in d
+    assert "eager one-stream steps" in d["roofline"]["timing_source"] and "replays a hipGraph" in d["roofline"]["timing_source"]
+    assert "cpu_baseline" not in d
 
 
 def test_two_rank_launch_line_over_gloo_on_one_gpu():
