@@ -4,6 +4,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+python3 "$ROOT/bench.py" --steps 30 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1     # (a fresh box runs its first process ~2 % slower: not recorded)
 python3 "$ROOT/bench.py" 2>/dev/null | tail -1 > "$OUT/bench_line.json"
 # strong-scaling operating points of one GPU (per-GPU batch = 256 / N for N = 2, 4, 8): hipGraph-replayed steps
 for b in 128 64 32; do python3 "$ROOT/bench.py" --batch $b --steps 100 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_line_batch$b.json"; done
@@ -19,14 +20,22 @@ rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace32" -o t -- python3 "
 T32=$(find "$OUT/trace32" -name '*kernel_trace.csv' | head -1)
 python3 "$ROOT/tools/prof_summary.py" "$T32" 0.25 > "$OUT/batch32_graph_kernel_summary.txt" 2>&1
 rm -rf "$OUT/trace32"
+# the same command with the forward on ONE stream: per-kernel durations that are a kernel's own (with the branches on side
+# streams a traced duration includes the kernels it shares the chip with) — what the bench line's roofline object is checked against
+export DL_BRANCH_STREAMS=0
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace1" -o t -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 > "$OUT/under_rocprof_one_stream.log" 2>&1
+unset DL_BRANCH_STREAMS
+S1=$(find "$OUT/trace1" -name '*kernel_stats.csv' | head -1); cp "$S1" "$OUT/bench_kernel_stats_one_stream.csv"; rm -rf "$OUT/trace1"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 > "$OUT/under_rocprof.log" 2>&1
 grep '"metric"' "$OUT/under_rocprof.log" | tail -1 > "$OUT/bench_line_under_rocprof.json"
 T=$(find "$OUT/trace" -name '*kernel_trace.csv' | head -1); S=$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)
 cp "$S" "$OUT/bench_kernel_stats.csv"
 python3 "$ROOT/tools/prof_summary.py" "$T" 0.25 > "$OUT/bench_timed_window_summary.txt" 2>&1
+export DL_BRANCH_STREAMS=0      # (counter collection serialises the kernels anyway; one stream keeps the dispatch order that of the step)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o f -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pmc_f.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pmc_w.log" 2>&1
 F=$(find "$OUT/pmc_f" -name '*counter_collection.csv' | head -1); W=$(find "$OUT/pmc_w" -name '*counter_collection.csv' | head -1)
+unset DL_BRANCH_STREAMS
 python3 "$ROOT/tools/pmc_summary.py" "$F" "$W" "$OUT/pmc_summary.json" > "$OUT/pmc_summary.txt" 2>&1
 python3 "$ROOT/bench.py" --graph on --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_batch256_graph.json"
 DL_BRANCH_STREAMS=0 python3 "$ROOT/bench.py" --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_one_stream.json"
