@@ -170,6 +170,8 @@ SIGNATURES = {
     "dl_bn_apply_fwd_rw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp]),
     "dl_bn_bwd_reduce_rw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "dl_bn_bwd_apply_rw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp]),
+    "dl_cnn_sitepool_rows_fwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
+    "dl_cnn_sitepool_rows_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "dl_embed_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp]),
     "dl_rows_gather": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "dl_rows_sum_strided": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp]),

@@ -280,7 +280,7 @@ constexpr int SP_RR = 32;
 constexpr int SP_PITCH = 34;      // elements per LDS image row of the forward kernel (68 bytes)
 template <typename T>
 __global__ __launch_bounds__(256) void cnn_sitepool_fwd_kernel(const T* __restrict__ z, T* __restrict__ out, int L, int C,
-                                                                int halo, int S) {
+                                                                int halo, int S, const int32_t* __restrict__ row_of) {
   // LDS image T[v = c * S + k][i] (pitch SP_PITCH elements): the row index v is exactly the order in which the
   // S contributions of output column q are consumed (v = s * C + q), so the gather below reads contiguous rows;
   // the scattered 2-byte writes of the load phase land on 8 different banks per 16 lanes with this pitch.
@@ -296,7 +296,9 @@ __global__ __launch_bounds__(256) void cnn_sitepool_fwd_kernel(const T* __restri
     const int l = n_site * k + r0 + i;
     T v[8];
     if (r0 + i < n_site) {
-      *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(zb + (int64_t)(halo + l) * C + ch * 8);
+      // row_of (round 4: ProteinCNN on distinct rows): position (b, l) is represented by compact row row_of[b * L + l] of z
+      const T* src = row_of ? z + (int64_t)row_of[(int64_t)b * L + l] * C : zb + (int64_t)(halo + l) * C;
+      *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(src + ch * 8);
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(0.f);
@@ -848,8 +850,165 @@ extern "C" int dl_cnn_sitepool_fwd(const void* z, void* pooled, int64_t B, int64
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)cnn_sitepool_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   hipLaunchKernelGGL((cnn_sitepool_fwd_kernel<bf16_t>), dim3((uint32_t)((n_site + SP_RR - 1) / SP_RR), (uint32_t)B), dim3(256), lds, s,
-                     (const bf16_t*)z, (bf16_t*)pooled, (int)L, (int)C, (int)halo, (int)site_len);
+                     (const bf16_t*)z, (bf16_t*)pooled, (int)L, (int)C, (int)halo, (int)site_len, (const int32_t*)nullptr);
   DL_CHECK_LAUNCH("dl_cnn_sitepool_fwd");
+  return DL_OK;
+}
+extern "C" int dl_cnn_sitepool_rows_fwd(const void* z, const int32_t* row_of, void* pooled, int64_t B, int64_t L, int64_t C,
+                                        int32_t site_len, int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int rc = sitepool_check("dl_cnn_sitepool_rows_fwd", z, pooled, B, L, C, 0, site_len, dtype);
+  if (rc != DL_OK) return rc;
+  DL_CHECK_ARG(row_of && B * L < (1ll << 31), DL_ERR_ARG, "dl_cnn_sitepool_rows_fwd: row map");
+  const int n_site = (int)(L / site_len);
+  const size_t lds = (size_t)site_len * C * SP_PITCH * 2;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)cnn_sitepool_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL((cnn_sitepool_fwd_kernel<bf16_t>), dim3((uint32_t)((n_site + SP_RR - 1) / SP_RR), (uint32_t)B), dim3(256), lds, s,
+                     (const bf16_t*)z, (bf16_t*)pooled, (int)L, (int)C, 0, (int)site_len, row_of);
+  DL_CHECK_LAUNCH("dl_cnn_sitepool_rows_fwd");
+  return DL_OK;
+}
+
+// Backward through the row map: dz[r][c] = 1/S sum_{k < count} dpooled[b][n_site * ((c S + l_k / n_site) % C) + l_k % n_site] over the
+// positions l_k = pos0 + k * stride the compact row stands for (rep = (first = b L + pos0, stride, count); count 0: a zero
+// row).  One workgroup per (sample, slice of its compact rows): the sample's dpooled (n_site x C bf16 = 64 KB) sits in LDS,
+// every thread owns one channel pair of one row and walks the row's positions.  Rows of sample b are [row_lo[b], row_lo[b+1]).
+namespace {
+constexpr int SPB_CHUNK = 512;   // compact rows whose (first, stride, count) triples are staged in LDS at a time
+constexpr int SPB_DEEP = 48;     // a row standing for more positions than this is walked by all four waves
+// CT / NT: compile-time C and n_site (0 = run-time values): the model's shape (128 channels, 256 sites) turns every index
+// division of the walk into a shift — the kernel is bound by exactly that integer work
+template <int CT, int NT>
+__global__ __launch_bounds__(256) void cnn_sitepool_rows_bwd_kernel(const bf16_t* __restrict__ dpooled, const int32_t* __restrict__ rep,
+                                                                     const int32_t* __restrict__ row_of, bf16_t* __restrict__ dz,
+                                                                     int L, int C_rt, int S, int R, int slices) {
+  const int C = CT ? CT : C_rt;
+  extern __shared__ __attribute__((aligned(16))) char spb_smem[];
+  // LDS image g[q][r] of the sample's pooled gradient, row pitch n_site + 2 elements (an ODD number of dwords): the 64 lanes
+  // of a wave read 64 different q (stride 2 S) at one r — with the dense pitch of n_site = 256 elements every lane hit the
+  // same bank
+  bf16_t* g = reinterpret_cast<bf16_t*>(spb_smem);
+  const int n_site = NT ? NT : L / S, pitch = n_site + 2;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(dpooled + (int64_t)b * n_site * C);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(spb_smem);
+    const int cpr = n_site / 8, total = cpr * C;                    // 16-byte chunks per row (n_site % 8 == 0: checked by the caller)
+    for (int i0 = tid; i0 < total; i0 += 256 * 8) {                 // eight 16-byte loads in flight per thread, then the LDS writes
+      u32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * 256 < total) v[u] = src[i0 + u * 256];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        if (i < total) {
+          const int q = i / cpr, d = q * (cpr * 4 + 1) + (i - q * cpr) * 4;
+          dst[d] = v[u][0]; dst[d + 1] = v[u][1]; dst[d + 2] = v[u][2]; dst[d + 3] = v[u][3];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // the sample's compact rows: from the row of its position 0 to the row of the next sample's position 0 (rows are laid out
+  // sample by sample, segment A of a sample first); the rows in between that belong to halos have count 0
+  const int lo = row_of[(int64_t)b * L] - 4 < 0 ? 0 : row_of[(int64_t)b * L] - 4;
+  // (the last sample ends 4 halo rows after the row of its last position; the bucket's padding rows behind it — up to 2047,
+  //  several samples' worth — are zeroed by all workgroups together instead of landing on the last sample's workgroups)
+  const int last_end = min(R, row_of[(int64_t)gridDim.y * L - 1] + 5);
+  const int hi = (b + 1 < (int)gridDim.y) ? row_of[(int64_t)(b + 1) * L] - 4 : last_end;
+  {
+    const int64_t n16 = (int64_t)(R - last_end) * C / 8, nwg = (int64_t)gridDim.x * gridDim.y, me = (int64_t)b * gridDim.x + blockIdx.x;
+    const int64_t share = (n16 + nwg - 1) / nwg, z0 = me * share, z1 = z0 + share < n16 ? z0 + share : n16;
+    u32x4* zdst = reinterpret_cast<u32x4*>(dz + (int64_t)last_end * C);
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (int64_t i = z0 + tid; i < z1; i += 256) zdst[i] = zero;
+  }
+  const int per = (hi - lo + slices - 1) / slices;
+  const int r_begin = lo + blockIdx.x * per, r_end = min(hi, r_begin + per);
+  const float inv = 1.0f / (float)S, inv_site = 1.0f / (float)n_site;
+  const int cp = C / 2;                                             // channel pairs per row
+  __shared__ int32_t srep[SPB_CHUNK * 3];                           // the chunk's (first, stride, count) triples
+  __shared__ int32_t deep[SPB_CHUNK];                               // rows of the chunk with a long position list
+  __shared__ int32_t n_deep;
+  float* part = reinterpret_cast<float*>(spb_smem + (size_t)pitch * C * 2);   // [4][C] partial sums of a deep row
+  // sum of the pooled gradient over positions first + k * stride, k = k0, k0 + kstep, ... < count, for channels c and c + 1
+  auto walk = [&](int first, int stride, int count, int c, int k0, int kstep, float& a0, float& a1) {
+    const int q0 = (c * S) % C, q1 = ((c + 1) * S) % C;             // + kk (< S <= C): one conditional subtraction below
+#pragma unroll 4
+    for (int k = k0; k < count; k += kstep) {
+      const int l = first + k * stride;
+      const int kk = NT ? l / NT : (int)(((float)l + 0.5f) * inv_site);   // l / n_site (the float form is exact for l < 2^22)
+      const int rr = l - kk * n_site;
+      int qa = q0 + kk, qb = q1 + kk;
+      qa -= qa >= C ? C : 0;
+      qb -= qb >= C ? C : 0;
+      a0 += (float)g[qa * pitch + rr];
+      a1 += (float)g[qb * pitch + rr];
+    }
+  };
+  for (int chunk = r_begin; chunk < r_end; chunk += SPB_CHUNK) {
+    const int n = min(SPB_CHUNK, r_end - chunk);
+    if (tid == 0) n_deep = 0;
+    for (int i = tid; i < 3 * n; i += 256) srep[i] = rep[(int64_t)3 * chunk + i];
+    __syncthreads();
+    for (int i = tid; i < n; i += 256)
+      if (srep[3 * i + 2] > SPB_DEEP) deep[atomicAdd(&n_deep, 1)] = i;
+    for (int w = tid; w < n * cp; w += 256) {
+      const int rl = w / cp, c = (w - rl * cp) * 2;
+      const int count = srep[3 * rl + 2];
+      if (count > SPB_DEEP) continue;                               // the whole workgroup walks those below
+      float a0 = 0.f, a1 = 0.f;
+      walk(srep[3 * rl] - b * L, srep[3 * rl + 1], count, c, 0, 1, a0, a1);
+      *reinterpret_cast<uint32_t*>(dz + (int64_t)(chunk + rl) * C + c) = pack_bf16x2(a0 * inv, a1 * inv);
+    }
+    __syncthreads();
+    // deep rows (the tail representative stands for up to a whole period of positions): four waves split the position list
+    for (int d = 0; d < n_deep; ++d) {
+      const int rl = deep[d];
+      const int first = srep[3 * rl] - b * L, stride = srep[3 * rl + 1], count = srep[3 * rl + 2];
+      const int wv = tid >> 6;
+      for (int pr = tid & 63; pr < cp; pr += 64) {
+        float a0 = 0.f, a1 = 0.f;
+        walk(first, stride, count, 2 * pr, wv, 4, a0, a1);
+        part[wv * C + 2 * pr] = a0;
+        part[wv * C + 2 * pr + 1] = a1;
+      }
+      __syncthreads();
+      for (int pr = tid; pr < cp; pr += 256) {
+        const int c = 2 * pr;
+        // (fixed order of the four partial sums: repeatable)
+        const float a0 = (part[c] + part[C + c]) + (part[2 * C + c] + part[3 * C + c]);
+        const float a1 = (part[c + 1] + part[C + c + 1]) + (part[2 * C + c + 1] + part[3 * C + c + 1]);
+        *reinterpret_cast<uint32_t*>(dz + (int64_t)(chunk + rl) * C + c) = pack_bf16x2(a0 * inv, a1 * inv);
+      }
+      __syncthreads();
+    }
+  }
+}
+}  // namespace
+extern "C" int dl_cnn_sitepool_rows_bwd(const void* dpooled, const int32_t* rep, const int32_t* row_of, void* dz, int64_t B, int64_t L,
+                                        int64_t C, int64_t R, int32_t site_len, int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(dpooled && rep && row_of && dz && B > 0 && L > 0 && C > 0 && R > 0 && site_len > 0, DL_ERR_ARG, "dl_cnn_sitepool_rows_bwd: bad args");
+  DL_CHECK_ARG(L % site_len == 0 && C % 8 == 0 && dtype == DL_BF16 && (L / site_len + 2) * C * 2 + C * 16 + 16 * 1024 <= 160 * 1024 && B <= 65535 && R < (1ll << 31) &&
+                   B * L < (1ll << 31) && (L / site_len) % 8 == 0 && site_len <= C, DL_ERR_SHAPE, "dl_cnn_sitepool_rows_bwd: needs bf16, L %% site_len == 0, C %% 8 == 0, one sample's pooled gradient in LDS");
+  const size_t lds = (size_t)(L / site_len + 2) * C * 2 + (size_t)C * 16;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)cnn_sitepool_rows_bwd_kernel<128, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    (void)hipFuncSetAttribute((const void*)cnn_sitepool_rows_bwd_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    attr = true;
+  }
+  const int slices = B >= 128 ? 4 : (B >= 32 ? 8 : 16);          // workgroups per sample: balance (samples differ 10x in rows) and fill the chip at small batches
+  if (C == 128 && L / site_len == 256)
+    hipLaunchKernelGGL((cnn_sitepool_rows_bwd_kernel<128, 256>), dim3((uint32_t)slices, (uint32_t)B), dim3(256), lds, s, (const bf16_t*)dpooled, rep,
+                       row_of, (bf16_t*)dz, (int)L, (int)C, (int)site_len, (int)R, slices);
+  else
+    hipLaunchKernelGGL((cnn_sitepool_rows_bwd_kernel<0, 0>), dim3((uint32_t)slices, (uint32_t)B), dim3(256), lds, s, (const bf16_t*)dpooled, rep,
+                       row_of, (bf16_t*)dz, (int)L, (int)C, (int)site_len, (int)R, slices);
+  DL_CHECK_LAUNCH("dl_cnn_sitepool_rows_bwd");
   return DL_OK;
 }
 extern "C" int dl_cnn_sitepool_bwd(const void* dpooled, void* dz, int64_t B, int64_t L, int64_t C, int32_t halo,

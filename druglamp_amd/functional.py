@@ -1151,6 +1151,24 @@ class ExpandRowsFn(torch.autograd.Function):
         return ops.rows_sum_strided(dout.contiguous(), rep), None, None
 
 
+class SitePoolRowsFn(torch.autograd.Function):
+    """Site pooling of the compact ProteinCNN output THROUGH the row map (dl_cnn_sitepool_rows_fwd / _bwd): the pooling reads
+    position (b, l) at compact row row_of[b * L + l], and the backward writes the compact gradient directly (a row's gradient =
+    the sum over the positions it stands for) — no expansion to (B, 2304, C) in either direction."""
+
+    @staticmethod
+    def forward(ctx, z, row_of, rep, B, L, site_len):
+        ctx.save_for_backward(row_of, rep)
+        ctx.cfg = (L, site_len)
+        return ops.cnn_sitepool_rows_fwd(z, row_of, B, L, site_len)
+
+    @staticmethod
+    def backward(ctx, dout):
+        row_of, rep = ctx.saved_tensors
+        L, site_len = ctx.cfg
+        return ops.cnn_sitepool_rows_bwd(dout, rep, row_of, L, site_len), None, None, None, None, None
+
+
 class SitePoolFn(torch.autograd.Function):
     """The reference's (B, C, L).view(B, L, C) reinterpretation + site pooling (basic_model.py:179, DrugLAMP.py:35-40) of a
     channel-last (B, L, C) activation without halo rows: dl_cnn_sitepool_fwd / _bwd with halo = 0."""

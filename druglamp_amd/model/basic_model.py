@@ -177,6 +177,8 @@ class ProteinCNN(nn.Module):
         self.bn2 = nn.BatchNorm1d(in_ch[2])
         self.conv3 = nn.Conv1d(in_ch[2], in_ch[3], kernel_size[2], padding="same")
         self.bn3 = nn.BatchNorm1d(in_ch[3])
+        # A/B switch (DL_POOL_THROUGH_MAP=0): site pooling of the distinct-row output by expansion + the dense kernels
+        self.pool_through_map = os.environ.get("DL_POOL_THROUGH_MAP", "1") != "0"
 
     compute_dtype = torch.float32
 
@@ -190,7 +192,7 @@ class ProteinCNN(nn.Module):
         (utils.py:392-412), so only ~L + 31 of the 2304 positions of a sample have distinct outputs; the network runs on
         those rows (BatchNorm weighted by the multiplicities) and the result is expanded: same values, ~3.5x fewer rows.
         The tiling is verified on the device (ops.guard_flags)."""
-        from ..functional import EmbedPadFn, EmbedRowsFn, ExpandRowsFn, ProteinCNNFn, SitePoolFn, cast
+        from ..functional import EmbedPadFn, EmbedRowsFn, ExpandRowsFn, ProteinCNNFn, SitePoolFn, SitePoolRowsFn, cast
         ids = v.long()
         w = self.embedding.weight
         wc = cast(w, self.compute_dtype) if w.requires_grad else w.detach().to(self.compute_dtype)
@@ -208,6 +210,10 @@ class ProteinCNN(nn.Module):
             if self.training:
                 for bn in (self.bn1, self.bn2, self.bn3):
                     Fn.bn_tick(bn.num_batches_tracked)
+            if site_pool and outs[0].dtype == torch.bfloat16 and L % int(site_pool) == 0 and (L // int(site_pool)) % 8 == 0 and int(site_pool) <= outs[0].shape[1] \
+                    and self.pool_through_map:
+                # the reference's view reinterpretation + site pooling read through the row map: no (B, 2304, C) round trip
+                return SitePoolRowsFn.apply(outs[0], plan.row_of, plan.rep, B, L, int(site_pool))
             z = ExpandRowsFn.apply(outs[0], plan.row_of, plan.rep).view(B, L, C)      # channel-last, every position
             if site_pool and z.dtype == torch.bfloat16 and L % int(site_pool) == 0:
                 return SitePoolFn.apply(z, int(site_pool))

@@ -724,6 +724,28 @@ def cnn_sitepool_bwd(dpooled: torch.Tensor, L: int, halo: int, site_len: int) ->
     return dz
 
 
+def cnn_sitepool_rows_fwd(z2d: torch.Tensor, row_of: torch.Tensor, B: int, L: int, site_len: int) -> torch.Tensor:
+    """compact rows z2d (R, C) + position map -> pooled (B, L // site_len, C); see dl_cnn_sitepool_rows_fwd."""
+    _need_gpu(z2d, row_of)
+    z2d = z2d.contiguous()
+    Cc = z2d.shape[1]
+    out = torch.empty((B, L // site_len, Cc), dtype=z2d.dtype, device=z2d.device)
+    check(_lib.lib().dl_cnn_sitepool_rows_fwd(z2d.data_ptr(), row_of.data_ptr(), out.data_ptr(), B, L, Cc, site_len, _dt(z2d), _stream()),
+          "dl_cnn_sitepool_rows_fwd")
+    return out
+
+
+def cnn_sitepool_rows_bwd(dpooled: torch.Tensor, rep: torch.Tensor, row_of: torch.Tensor, L: int, site_len: int) -> torch.Tensor:
+    _need_gpu(dpooled, rep, row_of)
+    dpooled = dpooled.contiguous()
+    B, _, Cc = dpooled.shape
+    R = rep.shape[0]
+    dz = torch.empty((R, Cc), dtype=dpooled.dtype, device=dpooled.device)
+    check(_lib.lib().dl_cnn_sitepool_rows_bwd(dpooled.data_ptr(), rep.data_ptr(), row_of.data_ptr(), dz.data_ptr(), B, L, Cc, R, site_len,
+                                              _dt(dpooled), _stream()), "dl_cnn_sitepool_rows_bwd")
+    return dz
+
+
 def embed_pad(ids: torch.Tensor, weight: torch.Tensor, fill: torch.Tensor, halo: int) -> torch.Tensor:
     """ids (B, L) int64, weight (V, D), fill (B, L) -> (B, L + 2*halo, D + 1); see dl_embed_pad."""
     _need_gpu(ids, weight, fill)

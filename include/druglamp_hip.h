@@ -388,6 +388,14 @@ int dl_cnn_sitepool_fwd(const void* z, void* pooled, int64_t B, int64_t L, int64
                         int32_t site_len, int32_t dtype, dl_stream s);
 int dl_cnn_sitepool_bwd(const void* dpooled, void* dz, int64_t B, int64_t L, int64_t C, int32_t halo,
                         int32_t site_len, int32_t dtype, dl_stream s);
+/* The same through the row map of the distinct-row layout (round 4, druglamp_amd/protein_plan.py): z is the COMPACT conv
+ * output [R][C]; position (b, l) is represented by row row_of[b * L + l].  fwd reads the pooling's operands through the map
+ * (no expansion to [B][L][C]); bwd writes the compact gradient dz [R][C] directly: a row's gradient is the sum over the
+ * positions it stands for (rep[r] = (first flat position, stride, count), count 0 = a zero row).  bf16 only. */
+int dl_cnn_sitepool_rows_fwd(const void* z, const int32_t* row_of, void* pooled, int64_t B, int64_t L, int64_t C,
+                             int32_t site_len, int32_t dtype, dl_stream s);
+int dl_cnn_sitepool_rows_bwd(const void* dpooled, const int32_t* rep, const int32_t* row_of, void* dz, int64_t B, int64_t L,
+                             int64_t C, int64_t R, int32_t site_len, int32_t dtype, dl_stream s);
 /* Weight preparation: ONE launch refreshes every compute-dtype (and transposed) image of the fp32 master
  * parameters after an optimiser step — the per-parameter `.to(dtype)` / `.t().contiguous()` / `cat(q,k,v)` copies
  * a torch implementation of the reference's modules makes implicitly, batched.  items / block_map are DEVICE

@@ -75,6 +75,32 @@ def test_row_table_kernels_against_torch(dt):
     assert relerr(dy, want) <= (1e-5 if dt == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("S,site_len,C,lengths", [(2304, 9, 128, [98, 398, 1022, 511, 60]),      # the model's shape: shift-indexed kernel
+                                                  (1152, 9, 64, [98, 398, 511]),                # other shapes: run-time index math
+                                                  (2304, 8, 128, [700, 1022])])                 # long tails: rows walked by four waves
+def test_site_pooling_through_the_row_map(S, site_len, C, lengths):
+    """dl_cnn_sitepool_rows_fwd / _bwd against the definition in fp64 (the reference's (B,C,L).view(B,L,C) reinterpretation of
+    the expanded output, then the mean over site_len chunks — models.py:262-269), forward bit-equal to the expansion + dense
+    pooling kernels and backward equal to autograd through the fp64 definition."""
+    from druglamp_amd import ops
+    torch.manual_seed(1)
+    pd = _plan_dev(lengths, S, bucket=64)
+    B, R = len(lengths), pd.rows
+    z = torch.randn(R, C, device=DEV).bfloat16()
+    out = ops.cnn_sitepool_rows_fwd(z, pd.row_of, B, S, site_len)
+    dense = ops.cnn_sitepool_fwd(ops.rows_gather(z, pd.row_of).view(B, S, C), S, 0, site_len)
+    assert torch.equal(out, dense)
+    zd = z.double().requires_grad_(True)
+    full = zd[pd.row_of.long()].view(B, S, C).transpose(1, 2).contiguous().view(B, S, C)
+    want = full.view(B, site_len, S // site_len, C).mean(dim=1)
+    assert relerr(out, want) <= 1e-2
+    g = torch.randn(B, S // site_len, C, device=DEV).bfloat16()
+    dz = ops.cnn_sitepool_rows_bwd(g, pd.rep, pd.row_of, S, site_len)
+    want.backward(g.double())
+    assert relerr(dz, zd.grad) <= 5e-3                                  # one bf16 rounding of an fp32 sum
+    assert torch.equal(dz, ops.cnn_sitepool_rows_bwd(g, pd.rep, pd.row_of, S, site_len))   # repeatable
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
 def test_compact_protein_cnn_module_equals_the_full_one(dt, tol):
     from druglamp_amd.model.basic_model import ProteinCNN
