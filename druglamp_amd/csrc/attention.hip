@@ -984,6 +984,286 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void attn_bwd_dkv_ring_kernel(const
   }
 }
 
+// =================================== backward in ONE pass (head_dim 64, bf16, Lk <= 256) =============================
+// dQ, dK and dV of an attention from one evaluation of P and dS (the two-kernel form above evaluates the scores, the exp
+// and dP twice — once per orientation — and runs 7 tile products where 5 are needed).
+//   workgroup = 8 waves; wave w owns keys 32w .. 32w+31 of the attention's (<= 256) keys: K / V fragments and the dK / dV
+//   accumulators in registers.
+//   per block of 32 query rows:   S = Q K^T, dP = dO V^T  ->  P, dS   (lane: q = 4g + r, key = il: the dK / dV operand form)
+//                                 dV^T += dO^T P,  dK^T += Q^T dS
+//                                 dS -> LDS as dS^T[key][q] (the packed accumulator fragments are 8-byte rows of it)
+//                                 barrier
+//                                 dQ^T[d][q] = sum over ALL 256 keys K^T[d][key] dS^T[key][q]: the 32 x 64 block is 8 output
+//                                 tiles, one per wave (K^T fragments of its 16 d-columns in registers, dS^T fragments by the
+//                                 transposing LDS read) -> final for this (attention, segment): no cross-wave reduction
+//   The dS image is double buffered: one barrier per block.
+// Paired attention (two segments, partner(partner(p)) = p): ONE workgroup handles the pair {a, b = partner(a)} — passes
+// (Q(a), KV(a)), (Q(b), KV(a)), (Q(b), KV(b)), (Q(a), KV(b)) — so both shares of every dQ row come from the same lane of
+// the same workgroup, passes apart: the first share is stored (bf16), the second pass adds to it in fp32 and stores the sum.
+// dK / dV of an attention accumulate over its two passes in registers.
+// Data movement: the register budget (256 per wave at two waves per SIMD) leaves ONE workgroup per CU, so nothing else
+// covers a load phase: a first version that loaded a pass's whole Q / dO images up front spent 40 % of its time in those
+// prologues (every CU of the chip asking HBM for ~130 KB at the same moment, then none for 30 us).  Here the 32-row Q / dO /
+// O tiles and their LSE rows stream through a FOUR-stage LDS ring by LDS-DMA, issued three blocks ahead and counted with
+// vmcnt (in-order), so HBM sees an even demand; Delta = sum_d dO * O of a tile is formed from the ring by all threads one
+// block before it is used; the partner's K / V images are fetched a whole pass early into their own LDS regions.
+template <typename T, int HD>
+__global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(const AttnP p) {
+  static_assert(sizeof(T) == 2 && HD == 64, "bf16, head_dim 64");
+  using TL = ATile<T, HD>;
+  constexpr int KF = Mma<T>::KF, NKF = HD / KF, NDT = HD / 16, KT = 2, NQT = 2, QBLK = 32, NT = 512, NST = 4;
+  constexpr int TILE = QBLK * TL::RB;                     // 4 KB: one 32-row tile
+  constexpr int STAGE = 3 * TILE;                         // Q, dO, O
+  constexpr int IMG = 256 * TL::RB;                       // K / V image
+  constexpr int DSB = 256 * 64;                           // one dS^T image: 256 keys x 32 q
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + 2 * IMG + 2 * DSB + NST * (64 + QBLK) * (int)sizeof(float)];
+  char* ring = smem;
+  char* Ks = smem + NST * STAGE;
+  char* Vs = Ks + IMG;
+  char* dSs = Vs + IMG;
+  float* lse_s = reinterpret_cast<float*>(dSs + 2 * DSB);  // [NST][64] (raw natural-log LSE; one 64-lane dword DMA per stage, lanes 32-63 repeat)
+  float* del_s = lse_s + NST * 64;                          // [NST][32]
+  const int tid = threadIdx.x, lane = tid & 63, il = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything keyed on the wave stays on the scalar unit
+                                                               // (as a vector value, the Q / dO choice below became per-lane loads
+                                                               //  of the kernel arguments from memory, with a full vmcnt(0) wait)
+  const int h = blockIdx.y;
+  const int a0 = blockIdx.z;                               // S == 2: the pair {a0, a0 + shift}; S == 1: the attention
+  const int npass = p.S == 2 ? 4 : 1;
+  const int kw0 = wave * KT * 16;
+  const int qt_o = wave & 1, dt_o = wave >> 1;            // this wave's dQ output tile of a block
+  const float c = p.scale * LOG2E;
+  const int nblk = (p.Lq + QBLK - 1) / QBLK;
+  const int G = npass * nblk;                              // blocks of the whole workgroup, in order
+  const uint32_t smem_base = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address (for M0)
+  const char* zero = reinterpret_cast<const char*>(attn_zero_page);
+
+  // ---- ring DMA, one block per call, in block order: wave w moves rows 8 (w & 3) .. + 7 of the Q (w < 4) or dO (w >= 4) tile,
+  // waves 0-3 also the same rows of the O tile, wave 4 the 32 LSE values: two instructions for waves 0-4, one for waves 5-7.
+  // The cursor (pass, block, stage) and the pass's base pointers are wave-uniform and advance incrementally (no division,
+  // no 64-bit products per block) -------------------------------------------------------------------------------------------
+  const int nd = wave <= 4 ? 2 : 1;
+  int pf_pass = 0, pf_blk = 0, pf_stage = 0;
+  const T* pfA = nullptr;
+  const T* pfO = nullptr;
+  const float* pfL = nullptr;
+  int64_t pfA_rs = 0;
+  auto pf_setup = [&]() {
+    const int pa = pf_pass < 2 ? a0 : a0 + p.shift;
+    const int seg = pf_pass & 1;
+    const int qprob = seg == 0 ? pa : (pa + p.shift) % p.P;
+    if (wave < 4) { pfA = reinterpret_cast<const T*>(p.Q) + ((int64_t)qprob * p.q_ps + (int64_t)h * p.q_hs); pfA_rs = p.q_rs; }
+    else { pfA = reinterpret_cast<const T*>(p.dO) + ((int64_t)seg * p.do_ss + (int64_t)pa * p.do_ps + (int64_t)h * p.do_hs); pfA_rs = p.do_rs; }
+    pfO = reinterpret_cast<const T*>(p.O) + ((int64_t)seg * p.o_ss + (int64_t)pa * p.o_ps + (int64_t)h * p.o_hs);
+    pfL = p.LSE + (((int64_t)seg * p.P + pa) * p.H + h) * p.Lq;
+  };
+  pf_setup();
+  auto issue_next = [&]() {
+    const uint32_t st = smem_base + (uint32_t)(pf_stage * STAGE);
+    const int row = 8 * (wave & 3) + (lane >> 3), q = pf_blk * QBLK + row;
+    const int ch = (lane & 7) ^ TL::swz(row);
+    const bool ok = q < p.Lq;
+    lds_dma16(ok ? reinterpret_cast<const char*>(pfA + (int64_t)q * pfA_rs + ch * TL::EPC) : zero,
+              st + (uint32_t)((wave < 4 ? 0 : TILE) + (wave & 3) * 1024));
+    if (wave < 4) {
+      lds_dma16(ok ? reinterpret_cast<const char*>(pfO + (int64_t)q * p.o_rs + ch * TL::EPC) : zero, st + (uint32_t)(2 * TILE + wave * 1024));
+    } else if (wave == 4) {
+      // rows beyond Lq read the last valid row's LSE: their Q / dO rows are zero, so any finite value gives P dS = 0 contributions
+      const int ql = pf_blk * QBLK + (lane & 31);
+      lds_dma4(pfL + (ql < p.Lq ? ql : p.Lq - 1), smem_base + (uint32_t)((char*)lse_s - smem) + (uint32_t)(pf_stage * 256));
+    }
+    pf_stage = (pf_stage + 1) & (NST - 1);
+    if (++pf_blk == nblk) {
+      pf_blk = 0;
+      if (++pf_pass < npass) pf_setup();
+    }
+  };
+  // K and V images of attention pa (rows >= Lk: zero rows — the dQ product sums over all 256): 8 instructions per wave
+  auto issue_kv = [&](int pa) {
+    const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)pa * p.k_ps + (int64_t)h * p.k_hs;
+    const T* Vb = reinterpret_cast<const T*>(p.V) + (int64_t)pa * p.v_ps + (int64_t)h * p.v_hs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (i * 8 + wave) * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ TL::swz(row);
+      const bool ok = row < p.Lk;
+      lds_dma16(ok ? reinterpret_cast<const char*>(Kb + (int64_t)row * p.k_rs + ch * TL::EPC) : zero,
+                smem_base + (uint32_t)(Ks - smem) + (uint32_t)((i * 8 + wave) * 1024));
+      lds_dma16(ok ? reinterpret_cast<const char*>(Vb + (int64_t)row * p.v_rs + ch * TL::EPC) : zero,
+                smem_base + (uint32_t)(Vs - smem) + (uint32_t)((i * 8 + wave) * 1024));
+    }
+  };
+  // Delta of the ring block in stage sg from its dO and O tiles: 16 lanes per row, 4 elements each
+  auto form_delta = [&](int sg) {
+    const char* st = ring + sg * STAGE;
+    const int row = tid >> 4, off = TL::off(row, 4 * (tid & 15));
+    const u32x2 a = *reinterpret_cast<const u32x2*>(st + TILE + off), b = *reinterpret_cast<const u32x2*>(st + 2 * TILE + off);
+    float part = bf16lo(a[0]) * bf16lo(b[0]) + bf16hi(a[0]) * bf16hi(b[0]) + bf16lo(a[1]) * bf16lo(b[1]) + bf16hi(a[1]) * bf16hi(b[1]);
+    part = row16_sum(part);
+    if ((tid & 15) == 0) del_s[sg * QBLK + row] = part;
+  };
+  // ---- prologue: K / V images of the first attention, ring blocks 0..2, Delta of blocks 0 and 1 ---------------------------
+  issue_kv(a0);
+  for (int t = 0; t < 3 && t < G; ++t) issue_next();
+  vm_wait<0>();
+  __syncthreads();
+  form_delta(0);
+  if (G > 1) form_delta(1);
+  __syncthreads();
+  u32x4 kfr[KT][NKF], vfr[KT][NKF], ktr[8];
+  f32x4 dk[NDT][KT], dv[NDT][KT];
+  int gb = 0;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int pa = pass < 2 ? a0 : a0 + p.shift;          // the attention (its K, V, dO, O, LSE)
+    const int seg = pass & 1;
+    const int qprob = seg == 0 ? pa : (pa + p.shift) % p.P;
+    const bool new_kv = (pass & 1) == 0;
+    if (new_kv) {
+      // (the images landed at least one barrier ago: prologue, or issued a whole pass earlier)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int kf = 0; kf < NKF; ++kf) {
+          kfr[kt][kf] = frag_kc<T, HD>(Ks, kw0 + kt * 16, kf, il, g);
+          vfr[kt][kf] = frag_kc<T, HD>(Vs, kw0 + kt * 16, kf, il, g);
+        }
+#pragma unroll
+      for (int cki = 0; cki < 8; ++cki) ktr[cki] = frag_tr<T, HD>(Ks, cki * 32, dt_o * 16, il, g);
+#pragma unroll
+      for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) { dk[d][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    T* dQb = reinterpret_cast<T*>(p.dQ) + (int64_t)qprob * p.dq_ps + (int64_t)h * p.dq_hs;
+    const bool add_share = pass >= 2;                     // this Q's other share was stored two / three passes ago
+    for (int blk = 0; blk < nblk; ++blk, ++gb) {
+      const int q0 = blk * QBLK;
+      const int sg = gb & (NST - 1);
+      const char* stg = ring + sg * STAGE;
+      const char* Qt = stg;
+      const char* dOt = stg + TILE;
+      const float* lse_t = lse_s + sg * 64;
+      const float* del_t = del_s + sg * QBLK;
+      char* dSb = dSs + (gb & 1) * DSB;
+      // this lane's 4 dQ outputs of the block; in the adding passes the stored first share is fetched now, a block's work ahead
+      // of its use.  (As assembly: a load the compiler sees makes it wait vmcnt(0) — the ring DMA in flight included — before
+      // the register is rewritten and again before its use.  Only in the adding passes: a load in the storing passes would
+      // leave the row's line in this CU's L1 and the adding pass would read that stale copy.)
+      const int qo = q0 + qt_o * 16 + il;
+      T* dst = dQb + (int64_t)(qo < p.Lq ? qo : p.Lq - 1) * p.dq_rs + dt_o * 16 + 4 * g;
+      u32x2 prevw = {0u, 0u};
+      if (add_share) asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(prevw) : "v"(dst) : "memory");
+      // the partner's K / V images, a whole pass before they are used (the regions were last read at the start of pass 0)
+      const bool kv_now = npass == 4 && pass == 1 && blk == 0;
+      if (kv_now) issue_kv(a0 + p.shift);
+      // ring: block gb + 3 (its stage was last read in block gb - 1, which every wave has left)
+      if (gb + 3 < G) issue_next();
+      // S = Q K^T, dP = dO V^T, P, dS one 16-row q tile at a time; the packed P / dS fragments (contraction over the block's
+      // 32 rows: words 0-1 <- q tile 0, words 2-3 <- q tile 1) are filled as each tile finishes
+      u32x4 pb[KT], sb[KT];
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) {
+        f32x4 s[KT], dp[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) { s[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kf = 0; kf < NKF; ++kf) {
+          const u32x4 qa = frag_kc<T, HD>(Qt, qt * 16, kf, il, g);
+          const u32x4 da = frag_kc<T, HD>(dOt, qt * 16, kf, il, g);
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) {
+            s[kt] = Mma<T>::mma(qa, kfr[kt][kf], s[kt]);
+            dp[kt] = Mma<T>::mma(da, vfr[kt][kf], dp[kt]);
+          }
+        }
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_t + qt * 16 + 4 * g) * LOG2E;
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_t + qt * 16 + 4 * g);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = fast_exp2(s[kt][r] * c - l4[r]);
+            s[kt][r] = pv;                              // P
+            dp[kt][r] = pv * (dp[kt][r] - d4[r]);       // dS
+          }
+          pb[kt][2 * qt] = pack_bf16x2(s[kt][0], s[kt][1]);
+          pb[kt][2 * qt + 1] = pack_bf16x2(s[kt][2], s[kt][3]);
+          sb[kt][2 * qt] = pack_bf16x2(dp[kt][0], dp[kt][1]);
+          sb[kt][2 * qt + 1] = pack_bf16x2(dp[kt][2], dp[kt][3]);
+        }
+      }
+      // dS^T[key][q] image: row = key (64 bytes = 32 q), the 32-byte half of q tile qt sits at half qt ^ ((key >> 2) & 1);
+      // words 0-1 of the packed fragment are rows 4g .. 4g+3 of q tile 0 at this lane's key, words 2-3 the same of q tile 1
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int key = kw0 + kt * 16 + il, sw = (key >> 2) & 1;
+        *reinterpret_cast<u32x2*>(dSb + key * 64 + ((0 ^ sw) << 5) + 8 * g) = u32x2{sb[kt][0], sb[kt][1]};
+        *reinterpret_cast<u32x2*>(dSb + key * 64 + ((1 ^ sw) << 5) + 8 * g) = u32x2{sb[kt][2], sb[kt][3]};
+      }
+      // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) {
+        const u32x4 dota = frag_tr<T, HD>(dOt, 0, d * 16, il, g);
+        const u32x4 qta = frag_tr<T, HD>(Qt, 0, d * 16, il, g);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          dv[d][kt] = Mma<T>::mma(dota, pb[kt], dv[d][kt]);
+          dk[d][kt] = Mma<T>::mma(qta, sb[kt], dk[d][kt]);
+        }
+      }
+      // everything this wave issued before the newest ring block (and the K / V images when they were issued in this
+      // block) has landed: in particular ring block gb + 2, which the barrier publishes to the other waves
+      if (gb + 3 < G) {
+        if (nd == 2) vm_wait<2>(); else vm_wait<1>();
+      } else {
+        vm_wait<0>();
+      }
+      __syncthreads();
+      if (gb + 2 < G) form_delta((gb + 2) & (NST - 1));     // visible after the NEXT block's barrier, used the block after
+      // dQ^T tile (d columns dt_o, q tile qt_o) over all 256 keys
+      f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cki = 0; cki < 8; ++cki) {
+        const int r0 = cki * 32 + 4 * g + (il >> 2), sw = (r0 >> 2) & 1;     // (r0 + 16) >> 2 has the same parity
+        const uint32_t off = (uint32_t)(r0 * 64 + ((qt_o ^ sw) << 5) + (il & 3) * 8);
+        const u32x2 lo = lds_read_tr16(dSb, off);
+        const u32x2 hi = lds_read_tr16(dSb, off + 16 * 64);
+        dq = Mma<T>::mma(ktr[cki], u32x4{lo[0], lo[1], hi[0], hi[1]}, dq);
+      }
+      // the first share must be in its registers now.  LDS-DMA and register loads retire out of order with respect to each
+      // other, so a counted wait cannot single the load out (measured: vmcnt(nd) let stale registers through): everything
+      // this wave has in flight is waited for — the newest ring block was issued a whole block ago and has normally landed
+      if (add_share) asm volatile("s_waitcnt vmcnt(0)" : "+v"(prevw) :: "memory");
+      if (qo < p.Lq) {
+        f32x4 v = dq * p.scale;
+        if (add_share) {
+          v = v + f32x4{bf16lo(prevw[0]), bf16hi(prevw[0]), bf16lo(prevw[1]), bf16hi(prevw[1])};
+          store4_fam<4, T>(dst, v);
+        } else if (npass == 1) {
+          store4_fam<4, T>(dst, v);
+        } else {
+          store4<T>(dst, v);                               // read back by this lane in a later pass: keep it cacheable
+        }
+      }
+    }
+    if (!new_kv || npass == 1) {
+      T* dKb = reinterpret_cast<T*>(p.dK) + (int64_t)pa * p.dk_ps + (int64_t)h * p.dk_hs;
+      T* dVb = reinterpret_cast<T*>(p.dV) + (int64_t)pa * p.dv_ps + (int64_t)h * p.dv_hs;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int key = kw0 + kt * 16 + il;
+        if (key < p.Lk) {
+#pragma unroll
+          for (int d = 0; d < NDT; ++d) {
+            store4_fam<4, T>(dKb + (int64_t)key * p.dk_rs + d * 16 + 4 * g, dk[d][kt] * p.scale);
+            store4_fam<4, T>(dVb + (int64_t)key * p.dv_rs + d * 16 + 4 * g, dv[d][kt]);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <typename T> constexpr int fwd_qt() { return sizeof(T) == 2 ? 2 : 1; }
 
 int check_common(const char* who, int dtype, int head_dim, int nseg, int P, int H, int Lq, int Lk,
@@ -1038,6 +1318,16 @@ int launch_bwd(const AttnP& p, hipStream_t s) {
   const dim3 gk((uint32_t)((p.Lk + KVB - 1) / KVB), (uint32_t)p.H, (uint32_t)p.P);
   if constexpr (sizeof(T) == 2 && HD == 64) {
     // LDS-resident forms (64 KB images, two workgroups per CU); Delta comes out of the dQ kernel
+    // one pass for dQ, dK and dV; a paired attention's two problems {a, partner(a)} share a workgroup.  One 8-wave workgroup
+    // per CU: taken when there is at least one workgroup for every CU (measured, paired, Lq = Lk = 256: 256 pairs 361 vs 408 us,
+    // 64 pairs 84 vs 108, 32 pairs — half the CUs idle for four serial passes — 73 vs 56), or when asked for
+    const int64_t nwg = (int64_t)p.H * (p.S == 2 ? p.shift : p.P);
+    if (p.Lk <= 256 && (p.S == 1 || 2 * p.shift == p.P) &&
+        (p.algo == DL_ATTN_ALGO_ONE_PASS || (p.algo == DL_ATTN_ALGO_AUTO && nwg >= 256))) {
+      const dim3 gf(1u, (uint32_t)p.H, (uint32_t)(p.S == 2 ? p.shift : p.P));
+      hipLaunchKernelGGL((attn_bwd_fused_kernel<T, HD>), gf, dim3(512), 0, s, p);
+      return DL_OK;
+    }
     if (p.Lk <= 256 && p.Lq <= 256 && p.algo != DL_ATTN_ALGO_STREAM) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, QT, true>), gq, dim3(ATT_THREADS), 0, s, p);
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD, KT, true>), gk, dim3(ATT_THREADS), 0, s, p);

@@ -382,6 +382,9 @@ def attn_fwd(q, k, v, *, n_problems, n_heads, n_segments, partner_shift, Lq, Lk,
     return lse
 
 
+_ATTN_BWD_ALGO = int(os.environ.get("DL_ATTN_BWD_ALGO", "0"))    # A/B switch: 2 = always the dQ + dK/dV kernel pair, 3 = one-pass wherever eligible
+
+
 def attn_bwd(q, k, v, o, do, lse, *, n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, scale,
              q_strides, k_strides, v_strides, o_strides, o_ss, do_strides, do_ss, dq, dq_strides, dk, dk_strides,
              dv, dv_strides, algo=0):
@@ -404,7 +407,7 @@ def attn_bwd(q, k, v, o, do, lse, *, n_problems, n_heads, n_segments, partner_sh
     a.n_problems, a.n_heads, a.n_segments, a.partner_shift = n_problems, n_heads, n_segments, partner_shift
     a.Lq, a.Lk, a.head_dim, a.dtype = Lq, Lk, head_dim, _dt(q)
     a.scale = float(scale)
-    a.algo = algo
+    a.algo = algo if algo else _ATTN_BWD_ALGO
     check(_lib.lib().dl_attn_bwd(C.byref(a), _stream()), "dl_attn_bwd")
 
 

@@ -259,7 +259,10 @@ typedef struct {
   int32_t algo;   /* DL_ATTN_ALGO_AUTO, or DL_ATTN_ALGO_STREAM: key tiles streamed through LDS whatever the lengths
                      (the form every long sequence takes; AUTO keeps K/V LDS-resident when Lk <= 256 at head_dim 64) */
 } dl_attn_fwd_args;
-enum { DL_ATTN_ALGO_AUTO = 0, DL_ATTN_ALGO_STREAM = 1 };
+enum { DL_ATTN_ALGO_AUTO = 0, DL_ATTN_ALGO_STREAM = 1, DL_ATTN_ALGO_TWO_PASS = 2, DL_ATTN_ALGO_ONE_PASS = 3 };
+/* Backward at head_dim 64, bf16, Lk <= 256 (one segment, or two with partner(partner(p)) = p): AUTO takes the one-pass kernel
+ * (dQ, dK, dV from one evaluation of P and dS) when it has a workgroup for every CU, the dQ + dK/dV kernel pair otherwise;
+ * TWO_PASS / ONE_PASS force the choice (tests, A/B); ONE_PASS on an ineligible shape falls back to the pair. */
 int dl_attn_fwd(const dl_attn_fwd_args* a, dl_stream s);
 
 /* Backward.  dO is addressed like O (do_* strides); Delta has the shape of LSE and is scratch

@@ -543,3 +543,43 @@ def test_conv_weight_images_follow_the_masters_through_weight_prep():
                 with torch.no_grad():
                     w.data.view(-1).mul_(1.5).add_(0.25)          # a raw update of the master
                 Fn.bump_param_epoch()
+
+
+@pytest.mark.parametrize("P,H,S,Lq,Lk", [(320, 4, 2, 256, 256),      # paired, 640 workgroups: several per CU, AUTO takes the one-pass kernel
+                                         (288, 4, 1, 160, 200),      # one segment, ragged lengths
+                                         (160, 2, 2, 72, 250)])      # forced (too few workgroups for AUTO), ragged, short q
+def test_one_pass_attention_backward_equals_the_kernel_pair(P, H, S, Lq, Lk):
+    """dl_attn_bwd at head_dim 64 in bf16 with Lk <= 256: the one-pass kernel (one evaluation of P and dS for dQ, dK, dV; the two
+    shares of a paired dQ row summed inside one workgroup) against the dQ + dK/dV kernel pair — same fp32 accumulation, so
+    equal to bf16 rounding; bitwise repeatable."""
+    from druglamp_amd import ops
+    dev, dt, hd = "cuda:0", torch.bfloat16, 64
+    d, shift = H * hd, (P // 2 if S == 2 else 0)
+    g = torch.Generator().manual_seed(3)
+    q = (torch.randn(P * Lq, d, generator=g) * 0.5).to(dev, dt)
+    kv = (torch.randn(P * Lk, 2 * d, generator=g) * 0.5).to(dev, dt)
+    k, v = kv[:, :d], kv[:, d:]
+    qs, ks = (Lq * d, hd, d), (Lk * 2 * d, hd, 2 * d)
+    do = (torch.randn(S, P * Lq, d, generator=g) * 0.1).to(dev, dt)
+    o = torch.zeros(S, P * Lq, d, device=dev, dtype=dt)
+    common = dict(n_problems=P, n_heads=H, n_segments=S, partner_shift=shift, Lq=Lq, Lk=Lk, head_dim=hd, scale=hd ** -0.5,
+                  q_strides=qs, k_strides=ks, v_strides=ks)
+    lse = ops.attn_fwd(q, k, v, out=o, o_strides=(Lq * d, hd, d), o_ss=P * Lq * d, **common)
+    got = {}
+    for name, algo in (("pair", 2), ("one", 3), ("one2", 3), ("auto", 0)):
+        dq = torch.full((P * Lq, d), float("nan"), device=dev, dtype=dt)
+        dk = torch.full((P * Lk, d), float("nan"), device=dev, dtype=dt)
+        dv = torch.full((P * Lk, d), float("nan"), device=dev, dtype=dt)
+        ops.attn_bwd(q, k, v, o, do, lse, o_strides=(Lq * d, hd, d), o_ss=P * Lq * d, do_strides=(Lq * d, hd, d), do_ss=P * Lq * d,
+                     dq=dq, dq_strides=(Lq * d, hd, d), dk=dk, dk_strides=(Lk * d, hd, d), dv=dv, dv_strides=(Lk * d, hd, d),
+                     algo=algo, **common)
+        got[name] = (dq, dk, dv)
+    for i, what in enumerate(("dq", "dk", "dv")):
+        ref = got["pair"][i].float()
+        assert torch.isfinite(got["one"][i].float()).all(), what
+        err = float((got["one"][i].float() - ref).abs().max() / ref.abs().max())
+        assert err <= 1.2e-2, (what, err)                                   # a bf16 ulp at the largest magnitude
+        assert torch.equal(got["one"][i], got["one2"][i]), what           # repeatable
+    nwg = H * (shift if S == 2 else P)
+    same = all(torch.equal(got["auto"][i], got["one" if nwg >= 256 else "pair"][i]) for i in range(3))
+    assert same, "AUTO did not take the form its rule names"

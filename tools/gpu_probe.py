@@ -175,18 +175,23 @@ def attn_cases():
             dk = dqkv[:, :Lk, d:2 * d]
             dv = dqkv[:, :Lk, 2 * d:3 * d]
             ost = (Lq * nseg * d, hd, nseg * d)
-            ops.attn_bwd(q, k, v, out, do, lse, n_problems=P, n_heads=H, n_segments=nseg, partner_shift=shift, Lq=Lq,
-                         Lk=Lk, head_dim=hd, scale=scale, q_strides=st, k_strides=st, v_strides=st, o_strides=ost,
-                         o_ss=d, do_strides=ost, do_ss=d, dq=dq, dq_strides=st, dk=dk, dk_strides=st, dv=dv,
-                         dv_strides=st)
             loss = 0
             for sidx, oref in enumerate(refs):
                 dor = do[:, :, sidx * d:(sidx + 1) * d].double().reshape(P, Lq, H, hd).permute(0, 2, 1, 3)
                 loss = loss + (oref * dor).sum()
             loss.backward()
-            report("attn bwd dq %s" % tag, rel_err(dq.reshape(P, Lq, H, hd).permute(0, 2, 1, 3), qd.grad), tols(dt) * 2)
-            report("attn bwd dk %s" % tag, rel_err(dk.reshape(P, Lk, H, hd).permute(0, 2, 1, 3), kd.grad), tols(dt) * 2)
-            report("attn bwd dv %s" % tag, rel_err(dv.reshape(P, Lk, H, hd).permute(0, 2, 1, 3), vd.grad), tols(dt) * 2)
+            # algo 0 = the library's choice; 3 = DL_ATTN_ALGO_ONE_PASS (these shapes are too small for AUTO to pick the one-pass
+            # kernel, which wants a workgroup per CU): dQ, dK, dV from one evaluation of P and dS, both shares of a paired dQ
+            for algo in ((0, 3) if dt == torch.bfloat16 and hd == 64 and Lk <= 256 else (0,)):
+                dqkv.zero_()
+                ops.attn_bwd(q, k, v, out, do, lse, n_problems=P, n_heads=H, n_segments=nseg, partner_shift=shift, Lq=Lq,
+                             Lk=Lk, head_dim=hd, scale=scale, q_strides=st, k_strides=st, v_strides=st, o_strides=ost,
+                             o_ss=d, do_strides=ost, do_ss=d, dq=dq, dq_strides=st, dk=dk, dk_strides=st, dv=dv,
+                             dv_strides=st, algo=algo)
+                t2 = tag + (" one-pass" if algo == 3 else "")
+                report("attn bwd dq %s" % t2, rel_err(dq.reshape(P, Lq, H, hd).permute(0, 2, 1, 3), qd.grad), tols(dt) * 2)
+                report("attn bwd dk %s" % t2, rel_err(dk.reshape(P, Lk, H, hd).permute(0, 2, 1, 3), kd.grad), tols(dt) * 2)
+                report("attn bwd dv %s" % t2, rel_err(dv.reshape(P, Lk, H, hd).permute(0, 2, 1, 3), vd.grad), tols(dt) * 2)
 
 
 # ---------------------------------------------------------------- token gate / elementwise / adamw
