@@ -143,6 +143,7 @@ SIGNATURES = {
     "dl_fill_pool": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "dl_cnn_sitepool_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "dl_cnn_sitepool_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "dl_bn_stats_finalize": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_i32, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "dl_bn_finalize": (c_i32, [c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dl_interleave_streams": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "dl_norm_adjacency": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),

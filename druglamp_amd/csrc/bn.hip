@@ -492,3 +492,78 @@ extern "C" int dl_bn_finalize(const float* sums, int64_t n, float eps, float mom
   DL_CHECK_LAUNCH("dl_bn_finalize");
   return DL_OK;
 }
+
+// ---- batch statistics in TWO launches instead of three: the second stage of the column reduction and the finalize step in
+// one kernel.  Workgroup b owns channels 8b .. 8b+7: columns c (sum) and C + c (sum of squares) of the partials, reduced with
+// EXACTLY the arithmetic of dl_reduce_partials_kernel (row-lane k sums chunks k, k + 64, ... four at a time, then the fixed
+// LDS tree), so sums / mean / var / rstd are bit-identical to dl_bn_stats + dl_bn_finalize. ---------------------------------
+namespace {
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float inv_n,
+                                                                   float unbias, float eps, float momentum, float* __restrict__ sums,
+                                                                   float* __restrict__ mean, float* __restrict__ var,
+                                                                   float* __restrict__ rstd, float* __restrict__ rmean,
+                                                                   float* __restrict__ rvar) {
+  __shared__ float red[64][17];
+  const int cl = threadIdx.x & 15, k = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 8 + (cl & 7);
+  const int c = (cl < 8 ? 0 : C) + ch;                    // column of the [chunks][2C] partials
+  const int64_t stride = 2 * (int64_t)C;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (ch < C) {
+    int z = k;
+    for (; z + 192 < chunks; z += 256) {
+      a0 += partial[(int64_t)z * stride + c];
+      a1 += partial[(int64_t)(z + 64) * stride + c];
+      a2 += partial[(int64_t)(z + 128) * stride + c];
+      a3 += partial[(int64_t)(z + 192) * stride + c];
+    }
+    for (; z < chunks; z += 64) a0 += partial[(int64_t)z * stride + c];
+  }
+  red[k][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  for (int half = 32; half > 0; half >>= 1) {
+    if (k < half) red[k][cl] += red[k + half][cl];
+    __syncthreads();
+  }
+  if (k == 0 && ch < C) {
+    if (sums) sums[c] = red[0][cl];
+    if (cl < 8) {
+      const float m = red[0][cl] * inv_n;
+      const float v = fmaxf(red[0][cl + 8] * inv_n - m * m, 0.f);
+      mean[ch] = m;
+      var[ch] = v;
+      rstd[ch] = rsqrtf(v + eps);
+      if (rmean) rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * m;
+      if (rvar) rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (v * unbias);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int dl_bn_stats_finalize(const void* y, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid, const float* row_w,
+                                    int32_t dtype, int64_t n, float eps, float momentum, float* sums, float* mean, float* var,
+                                    float* rstd, float* running_mean, float* running_var, void* ws, size_t ws_bytes, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(y && mean && var && rstd && R > 0 && C > 0 && C % 4 == 0 && n > 0, DL_ERR_ARG, "dl_bn_stats_finalize: bad args");
+  DL_CHECK_ARG(R < (1ll << 31), DL_ERR_SHAPE, "dl_bn_stats_finalize: R must fit 31 bits");
+  DL_CHECK_ARG(ws && ws_bytes >= dl_bn_workspace_bytes(R, C), DL_ERR_WORKSPACE, "dl_bn_stats_finalize: workspace too small");
+  const int rpb = bn_rows_per_block(R, C);
+  const int chunks = (int)((R + rpb - 1) / rpb);
+  dim3 grid((uint32_t)((C + 255) / 256), (uint32_t)chunks);
+  if (row_w) { win = 0; halo = 0; valid = 0; }
+  if (dtype == DL_BF16 && (C == 64 || C == 128 || C == 256) && ((uintptr_t)y & 15) == 0)
+    hipLaunchKernelGGL((bn_partial_wide_kernel<0>), dim3(1, (uint32_t)chunks), dim3(256), 0, s, (const bf16_t*)y, (const bf16_t*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, R, (int)C, win, halo, valid, row_w, (float*)ws, rpb);
+  else if (dtype == DL_BF16)
+    hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 0>), grid, dim3(256), 0, s, (const bf16_t*)y, (const bf16_t*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, R, (int)C, win, halo, valid, row_w, (float*)ws, rpb);
+  else if (dtype == DL_F32)
+    hipLaunchKernelGGL((bn_partial_kernel<float, 0>), grid, dim3(256), 0, s, (const float*)y, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, R, (int)C, win, halo, valid, row_w, (float*)ws, rpb);
+  else { dl_set_error("dl_bn_stats_finalize: bad dtype"); return DL_ERR_ARG; }
+  const float unbias = n > 1 ? (float)((double)n / (double)(n - 1)) : 1.f;
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((uint32_t)((C + 7) / 8)), dim3(1024), 0, s, (const float*)ws, chunks, (int)C,
+                     (float)(1.0 / (double)n), unbias, eps, momentum, sums, mean, var, rstd, running_mean, running_var);
+  DL_CHECK_LAUNCH("dl_bn_stats_finalize");
+  return DL_OK;
+}

@@ -831,10 +831,9 @@ class ProteinCNNFn(torch.autograd.Function):
                 ops.gemm(cur, Wg, M=Mg, N=C, K=k * C, ldx=C, bias=_f32(b), act=2, out=y[pl:pl + Mg])
             if training:
                 # batch statistics + nn.BatchNorm1d's running-stat update (momentum given) in one tiny launch
-                sums = ops.bn_stats(y, LP, _CNN_HALO, Lv, rw)
                 upd = momenta is not None and rmean.dtype == torch.float32
-                mean, var, rstd = ops.bn_finalize(sums, n, eps, momenta[i] if upd else 0.0,
-                                                  rmean.detach() if upd else None, rvar.detach() if upd else None)
+                mean, var, rstd = ops.bn_stats_finalize(y, LP, _CNN_HALO, Lv, n, eps, momenta[i] if upd else 0.0,
+                                                        rmean.detach() if upd else None, rvar.detach() if upd else None, rw)
             else:
                 mean, var = rmean.detach().float(), rvar.detach().float()
                 rstd = torch.rsqrt(var + eps)
@@ -1194,10 +1193,9 @@ class BatchNormRowsFn(torch.autograd.Function):
         R, C = x.shape
         x = x.contiguous()
         if training:
-            sums = ops.bn_stats(x, 0, 0, 0)
             upd = momentum is not None and rmean is not None and rmean.dtype == torch.float32
-            mean, var, rstd = ops.bn_finalize(sums, R, eps, momentum if upd else 0.0, rmean.detach() if upd else None,
-                                              rvar.detach() if upd else None)
+            mean, var, rstd = ops.bn_stats_finalize(x, 0, 0, 0, R, eps, momentum if upd else 0.0, rmean.detach() if upd else None,
+                                                    rvar.detach() if upd else None)
         else:
             mean, var = rmean.detach().float(), rvar.detach().float()
             rstd = torch.rsqrt(var + eps)

@@ -612,6 +612,18 @@ def bn_stats(y2d, win, halo, valid, rw=None):
     return sums
 
 
+def bn_stats_finalize(y2d, win, halo, valid, n, eps, momentum=0.0, running_mean=None, running_var=None, rw=None):
+    """bn_stats + bn_finalize in two launches instead of three (dl_bn_stats_finalize): (mean, biased var, rstd), bit-identical."""
+    R, Cc = y2d.shape
+    L = _lib.lib()
+    out = torch.empty((3, Cc), dtype=torch.float32, device=y2d.device)
+    ws = _ws2.get(L.dl_bn_workspace_bytes(R, Cc), y2d.device)
+    check(L.dl_bn_stats_finalize(y2d.data_ptr(), R, Cc, win, halo, valid, _ptr(rw), _dt(y2d), int(n), float(eps), float(momentum), None,
+                                 out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), _ptr(running_mean), _ptr(running_var),
+                                 ws.data_ptr(), ws.numel(), _stream()), "dl_bn_stats_finalize")
+    return out[0], out[1], out[2]
+
+
 def bn_finalize(sums, n, eps, momentum=0.0, running_mean=None, running_var=None):
     """(mean, biased var, rstd) from dl_bn_stats sums; updates the running statistics in place when given."""
     Cc = sums.numel() // 2

@@ -192,6 +192,13 @@ int dl_bn_bwd_apply(const void* dz, const void* y, const float* mean, const floa
  *   bwd_apply_rw  dy = gamma * rstd * (dz - m * (S0 / n + yhat * S1 / n)), then the ReLU mask; halo rows zero. */
 int dl_bn_stats_rw(const void* y, int64_t R, int64_t C, const float* row_w, int32_t dtype, float* sums, void* workspace,
                    size_t workspace_bytes, dl_stream s);
+/* dl_bn_stats (row_w = NULL: the window rule) or dl_bn_stats_rw (row_w given) followed by dl_bn_finalize, in two launches
+ * instead of three: the second stage of the column reduction also forms mean / biased var / rstd and updates the running
+ * statistics (nn.BatchNorm1d, basic_model.py:160-178).  Same arithmetic in the same order: bit-identical results.  sums [2C]
+ * may be NULL. */
+int dl_bn_stats_finalize(const void* y, int64_t R, int64_t C, int64_t win, int64_t halo, int64_t valid, const float* row_w,
+                         int32_t dtype, int64_t n, float eps, float momentum, float* sums, float* mean, float* var, float* rstd,
+                         float* running_mean, float* running_var, void* workspace, size_t workspace_bytes, dl_stream s);
 int dl_bn_apply_fwd_rw(const void* y, void* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                        int64_t R, int64_t C, const float* row_w, int32_t dtype, dl_stream s);
 int dl_bn_bwd_reduce_rw(const void* dz, const void* y, const float* mean, const float* rstd, int64_t R, int64_t C,

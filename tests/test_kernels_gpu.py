@@ -583,3 +583,31 @@ def test_one_pass_attention_backward_equals_the_kernel_pair(P, H, S, Lq, Lk):
     nwg = H * (shift if S == 2 else P)
     same = all(torch.equal(got["auto"][i], got["one" if nwg >= 256 else "pair"][i]) for i in range(3))
     assert same, "AUTO did not take the form its rule names"
+
+
+@pytest.mark.parametrize("dt,R,C,win", [(torch.bfloat16, 5000, 128, (0, 0, 0)), (torch.bfloat16, 4 * 2312, 128, (2312, 4, 2304)),
+                                       (torch.float32, 777, 72, (0, 0, 0)), (torch.bfloat16, 3000, 96, (0, 0, 0)),
+                                       (torch.bfloat16, 9000, 256, (0, 0, 0))])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_bn_stats_finalize_is_bit_identical_to_the_three_launch_form(dt, R, C, win, weighted):
+    """dl_bn_stats_finalize (partial sums, then ONE kernel for the second reduction stage + mean / var / rstd + the running
+    statistics) against dl_bn_stats (+ _rw) followed by dl_bn_finalize: every output bitwise equal."""
+    from druglamp_amd import ops
+    if weighted and win != (0, 0, 0):
+        pytest.skip("row weights replace the window rule")
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(11)
+    y = torch.randn(R, C, generator=g).to(dev, dt)
+    rw = None
+    n = R if win == (0, 0, 0) else (R // win[0]) * win[2]
+    if weighted:
+        rw = torch.randint(-1, 4, (R,), generator=g).float().to(dev)
+        n = int(rw.clamp(min=0).sum().item())
+    rm0, rv0 = torch.randn(C, generator=g).to(dev), (torch.rand(C, generator=g) + 0.5).to(dev)
+    rm_a, rv_a, rm_b, rv_b = rm0.clone(), rv0.clone(), rm0.clone(), rv0.clone()
+    sums = ops.bn_stats(y, *win, rw)
+    ma, va, ra = ops.bn_finalize(sums, n, 1e-5, 0.1, rm_a, rv_a)
+    mb, vb, rb = ops.bn_stats_finalize(y, *win, n, 1e-5, 0.1, rm_b, rv_b, rw)
+    for a, b, what in ((ma, mb, "mean"), (va, vb, "var"), (ra, rb, "rstd"), (rm_a, rm_b, "running mean"), (rv_a, rv_b, "running var")):
+        assert torch.equal(a, b), what
+    assert not torch.equal(rm_a, rm0)

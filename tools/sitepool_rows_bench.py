@@ -1,11 +1,12 @@
 """Site pooling of the compact ProteinCNN output: through the row map (dl_cnn_sitepool_rows_fwd / _bwd) against the
 expansion + dense pooling pair (ExpandRowsFn + SitePoolFn), forward and backward, at the default batch's sizes.
 HIP-event time per call, one stream.  Run on the GPU box: python tools/sitepool_rows_bench.py [B]"""
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from druglamp_amd import ops, synthetic                              # noqa: E402
 from druglamp_amd.functional import ExpandRowsFn, SitePoolFn, SitePoolRowsFn   # noqa: E402
 from druglamp_amd.protein_plan import PlanDev, plan_of                # noqa: E402
