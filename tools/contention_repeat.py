@@ -48,7 +48,24 @@ def misc():
         outs.append(ops.dropout_apply(h, 0.1, 11))
         return tuple(outs)
     return f
-cases = {"tt 2048x512x65536": tt(2048, 512, 65536), "tt 1024x256x65536": tt(1024, 256, 65536), "tt 128x768x591867": tt(128, 768, 591867),
+def attn_bwd(P, H, S, L, algo):
+    hd = 64; d = H * hd; shift = P // 2 if S == 2 else 0
+    qkv = (torch.randn(P * L, 3 * d, device=dev) * 0.5).to(dt)
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    st = (L * 3 * d, hd, 3 * d)
+    do = (torch.randn(S, P * L, d, device=dev) * 0.1).to(dt)
+    o = torch.zeros(S, P * L, d, device=dev, dtype=dt)
+    kw = dict(n_problems=P, n_heads=H, n_segments=S, partner_shift=shift, Lq=L, Lk=L, head_dim=hd, scale=hd ** -0.5, q_strides=st, k_strides=st, v_strides=st)
+    lse = ops.attn_fwd(q, k, v, out=o, o_strides=(L * d, hd, d), o_ss=P * L * d, **kw)
+    def f():
+        dqkv = torch.empty_like(qkv)
+        ops.attn_bwd(q, k, v, o, do, lse, o_strides=(L * d, hd, d), o_ss=P * L * d, do_strides=(L * d, hd, d), do_ss=P * L * d, dq=dqkv, dq_strides=st,
+                     dk=dqkv[:, d:], dk_strides=st, dv=dqkv[:, 2 * d:], dv_strides=st, algo=algo, **kw)
+        return (dqkv,)
+    return f
+cases = {"attention backward one-pass, paired 384 x 4 x 256^2 (LDS-DMA ring, counted waits)": attn_bwd(384, 4, 2, 256, 3),
+         "attention backward one-pass, one segment 300 x 4 x 200^2": attn_bwd(300, 4, 1, 200, 3),
+         "tt 2048x512x65536": tt(2048, 512, 65536), "tt 1024x256x65536": tt(1024, 256, 65536), "tt 128x768x591867": tt(128, 768, 591867),
          "tt 256x256x65536 (128-tile)": tt(256, 256, 65536), "nn 65536x512x2048": nn(65536, 512, 2048), "nn 65536x768x256": nn(65536, 768, 256),
          "nn gelu+pre+dropout 65536x2048x512": nn_gelu(65536, 2048, 512), "nn gelu'(pre)+dropout 65536x2048x512": nn_dgelu(65536, 2048, 512),
          "nn bias+dropout+residual 65536x512x2048": nn_res(65536, 512, 2048), "nn gelu 128-tile 65536x128x648": nn_gelu(65536, 128, 648),
