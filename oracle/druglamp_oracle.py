@@ -240,7 +240,7 @@ def model_forward(sd: SD, kind: str, vd: torch.Tensor, vp: torch.Tensor, xd: Opt
 
 def bce_loss(score: torch.Tensor, labels: torch.Tensor):
     n = torch.sigmoid(score).squeeze(1)                                   # basic_model.py:17-22
-    return n, F.binary_cross_entropy(n, labels.float())
+    return n, F.binary_cross_entropy(n, labels.to(n.dtype))
 
 
 # ------------------------------------------------------------------------------------------

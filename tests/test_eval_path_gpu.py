@@ -131,3 +131,53 @@ def test_config1_wollm_on_real_human_rows_batch_32():
     e32 = tr.evaluate(tab.batches_only("val", 32))
     e7 = tr.evaluate(tab.batches_only("val", 7))
     assert np.isfinite(e32["auroc"]) and abs(e32["auroc"] - e7["auroc"]) <= 1e-6 and abs(e32["loss"] - e7["loss"]) <= 1e-5
+
+
+def test_config2_training_step_at_batch_256_vs_oracle():
+    """Training-mode parity at the bench's FULL size (the golden fixtures stop at batch 8; BatchNorm couples the samples of a
+    training batch, so no slice of it can stand in): one cls step of DrugLAMP at batch 256 in the fp32 pipeline against the CPU
+    oracle's step on the same weights and inputs (oracle/druglamp_oracle.py::OracleTrainer, pinned by the reference's
+    train_steps golden; run in fp64) — loss at the north-star tolerance 1e-4, every parameter's gradient against the oracle's by relative
+    L2 error.  The large-tile GEMMs, the many-chunk reductions and the compact row forms only occur at this size."""
+    import time
+    from oracle import druglamp_oracle as O
+    from druglamp_amd.synthetic import make_batch
+    from druglamp_amd.trainer import Trainer
+    m, cfg = _model("DrugLAMP", torch.float32, dropout=0.0)
+    tr = Trainer(m, cfg, device=DEV, compute_dtype=torch.float32)
+    (vd, vp, y, xd, xp), meta = make_batch(256, DEV, seed=33, with_graph=False)
+    # (the oracle runs in fp64 here: at 590 000 conv rows per BatchNorm channel an fp32 CPU reduction is no better a yardstick than
+    #  the kernels under test)
+    sd = {k: (v.detach().double() if v.is_floating_point() else v.detach()).cpu().clone() for k, v in m.state_dict().items()}
+    names = {id(p): n for n, p in m.named_parameters()}
+    out = tr.training_step((vd, vp, y, xd, xp), meta=meta, cur_epoch=1)
+    tr.check_device_flags()
+    got = {names[id(p)]: g.detach().double().cpu().clone() for p, g in zip(tr.flat.params, tr.flat.grad_views) if id(p) in names}
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    t0 = time.time()
+    ot = O.OracleTrainer(sd, "DrugLAMP", use_ssl=False, use_cm=False)
+    rec = ot.step(vd.double().cpu(), vp.cpu(), xd.double().cpu(), xp.double().cpu(), y.double().cpu(), cur_epoch=1)
+    print("oracle step at batch 256: %.1f s" % (time.time() - t0))
+    assert abs(float(out["cls"]) - rec["cls"]) <= 1e-4 * max(1.0, abs(rec["cls"])), (float(out["cls"]), rec["cls"])
+    rows = []
+    gmax = max(float(v.grad.norm()) for v in sd.values() if getattr(v, "grad", None) is not None)
+    for k, v in sd.items():
+        if getattr(v, "grad", None) is None or k not in got:
+            continue
+        ref = v.grad
+        # (parameters whose true gradient is zero carry rounding noise only: the embedding Linear the reference never uses, and
+        #  every bias in front of a training-mode BatchNorm — the batch mean absorbs it)
+        if float(ref.norm()) < 1e-4 * gmax:
+            continue
+        rows.append((float((got[k] - ref).norm() / ref.norm()), k, float(ref.norm())))
+    rows.sort(reverse=True)
+    # The ProteinCNN parameters in front of its last BatchNorm are ill-conditioned in fp32 at this size: that BatchNorm's backward
+    # subtracts the batch mean and the projection on y-hat from an upstream gradient that is mostly exactly those two components
+    # (torch's own fp32 CPU path lands at 2e-3 - 3.5e-3 against fp64 on the same layer, these kernels at 4e-4 - 2e-3:
+    # DESIGN section 5); everything else is held to 5e-4 (measured: 1.4e-4).
+    soft = lambda k: k.startswith("protein_extractor.") and ".bn3." not in k     # noqa: E731
+    worst_soft = max((r for r in rows if soft(r[1])), default=(0.0, None, 0.0))
+    worst_rest = max((r for r in rows if not soft(r[1])), default=(0.0, None, 0.0))
+    print("gradients checked: %d of %d; worst relative L2 error: ProteinCNN before its last BatchNorm %.1e (%s), all others %.1e (%s)" % (
+        len(rows), len(got), worst_soft[0], worst_soft[1], worst_rest[0], worst_rest[1]))
+    assert len(rows) >= 100 and worst_soft[0] <= 5e-3 and worst_rest[0] <= 5e-4, (worst_soft, worst_rest)
