@@ -143,9 +143,17 @@ def test_config2_training_step_at_batch_256_vs_oracle():
     from oracle import druglamp_oracle as O
     from druglamp_amd.synthetic import make_batch
     from druglamp_amd.trainer import Trainer
+    (vd, vp, y, xd, xp), meta = make_batch(256, DEV, seed=33, with_graph=False)
+    # the bench's own dtype on the same weights and inputs (same seed -> same initial weights), checked against the same oracle step below
+    mb, cfgb = _model("DrugLAMP", torch.bfloat16, dropout=0.0)
+    trb = Trainer(mb, cfgb, device=DEV, compute_dtype=torch.bfloat16)
+    nb = {id(p): n for n, p in mb.named_parameters()}
+    outb = trb.training_step((vd, vp, y, xd.bfloat16(), xp.bfloat16()), meta=meta, cur_epoch=1)
+    trb.check_device_flags()
+    gotb = {nb[id(p)]: g.detach().double().cpu().clone() for p, g in zip(trb.flat.params, trb.flat.grad_views) if id(p) in nb}
+    del mb, trb
     m, cfg = _model("DrugLAMP", torch.float32, dropout=0.0)
     tr = Trainer(m, cfg, device=DEV, compute_dtype=torch.float32)
-    (vd, vp, y, xd, xp), meta = make_batch(256, DEV, seed=33, with_graph=False)
     # (the oracle runs in fp64 here: at 590 000 conv rows per BatchNorm channel an fp32 CPU reduction is no better a yardstick than
     #  the kernels under test)
     sd = {k: (v.detach().double() if v.is_floating_point() else v.detach()).cpu().clone() for k, v in m.state_dict().items()}
@@ -181,3 +189,14 @@ def test_config2_training_step_at_batch_256_vs_oracle():
     print("gradients checked: %d of %d; worst relative L2 error: ProteinCNN before its last BatchNorm %.1e (%s), all others %.1e (%s)" % (
         len(rows), len(got), worst_soft[0], worst_soft[1], worst_rest[0], worst_rest[1]))
     assert len(rows) >= 100 and worst_soft[0] <= 5e-3 and worst_rest[0] <= 5e-4, (worst_soft, worst_rest)
+    # bf16 pipeline (the bench's): loss at the bf16 tolerance; direction of the whole gradient and of every large parameter's
+    assert abs(float(outb["cls"]) - rec["cls"]) <= 3e-2 * max(1.0, abs(rec["cls"])), (float(outb["cls"]), rec["cls"])
+    keys = [k for _, k, _ in rows]
+    a = torch.cat([gotb[k].reshape(-1) for k in keys])
+    b = torch.cat([sd[k].grad.reshape(-1) for k in keys])
+    cos_all = float(torch.dot(a, b) / (a.norm() * b.norm()))
+    big = [k for _, k, n in rows if n >= 0.05 * gmax]
+    cos_min = min((float(torch.dot(gotb[k].reshape(-1), sd[k].grad.reshape(-1)) / (gotb[k].norm() * sd[k].grad.norm())), k) for k in big)
+    print("bf16 step: loss %.6f (fp64 %.6f), cosine of the whole gradient %.5f, lowest cosine among the %d largest parameters %.4f (%s)" % (
+        float(outb["cls"]), rec["cls"], cos_all, len(big), cos_min[0], cos_min[1]))
+    assert cos_all >= 0.995 and cos_min[0] >= 0.98, (cos_all, cos_min)
