@@ -1411,7 +1411,9 @@ extern "C" int dl_attn_bwd(const dl_attn_bwd_args* a, dl_stream stream) {
   DL_CHECK_LAUNCH("dl_attn_bwd");
   const double nq = (double)a->n_segments * a->n_problems * a->n_heads * a->Lq;
   const int es = (int)dl_dtype_size(a->dtype);
-  dl_prof_after(2, s, 14.0 * nq * a->Lk * a->head_dim,
+  // (algorithmic flops of the backward: the FIVE products S, dP, dV, dK, dQ — 10 nq Lk hd.  Through round 4 this said 14: the
+  //  seven products the two-kernel form executes, i.e. its recomputation counted as work)
+  dl_prof_after(2, s, 10.0 * nq * a->Lk * a->head_dim,
                 (4.0 * nq + 4.0 * a->n_problems * a->n_heads * a->Lk) * a->head_dim * es);
   return rc;
 }

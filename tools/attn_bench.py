@@ -39,4 +39,4 @@ for name, P, H, S, shift, Lq, Lk, hd in ([] if long_only else cases):
     diffs = [float((res["0"][i].float() - res["1"][i].float()).abs().max()) for i in range(5)]
     print("%-12s fwd %.0f -> %.0f us (%.0f -> %.0f TF/s)   bwd %.0f -> %.0f us (%.0f -> %.0f TF/s)   maxdiff o/lse/dq/dk/dv %s" % (
         name, res["0"][5], res["1"][5], fl / res["0"][5] / 1e6, fl / res["1"][5] / 1e6, res["0"][6], res["1"][6],
-        3.5 * fl / res["0"][6] / 1e6, 3.5 * fl / res["1"][6] / 1e6, ["%.2g" % x for x in diffs]), flush=True)
+        2.5 * fl / res["0"][6] / 1e6, 2.5 * fl / res["1"][6] / 1e6, ["%.2g" % x for x in diffs]), flush=True)

@@ -48,9 +48,9 @@ def run(name, P, H, S, shift, Lq, Lk, hd=64):
                                   dk_strides=(Lk * d, hd, d), dv=dv, dv_strides=(Lk * d, hd, d), algo=algo)
         t = timed(fb)
         res[algo] = (dq.float(), dk.float(), dv.float(), t)
-    fl = 14.0 * S * P * H * Lq * Lk * hd
+    fl = 10.0 * S * P * H * Lq * Lk * hd        # algorithmic: S, dP, dV, dK, dQ
     diffs = ["%.2g / %.2g" % (float((res[3][i] - res[2][i]).abs().max()), float(res[2][i].abs().max())) for i in range(3)]
-    print("%-28s two-pass %7.1f us  one-pass %7.1f us (%.0f -> %.0f TF/s of the two-pass flop count)   max|diff| / max|ref| dq dk dv: %s" % (
+    print("%-28s two-pass %7.1f us  one-pass %7.1f us (%.0f -> %.0f TF/s, five products)   max|diff| / max|ref| dq dk dv: %s" % (
         name, res[2][3], res[3][3], fl / res[2][3] / 1e6, fl / res[3][3] / 1e6, diffs), flush=True)
 
 
