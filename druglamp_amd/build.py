@@ -54,7 +54,8 @@ def _stale(out, deps):
 # compact-MolecularGCN test (tests/test_model_gpu.py::test_gcn_compact_padding_equals_the_512_row_computation) fails with a
 # 5e-3 gradient error although every dl_bn_* call gives the same result in both builds when issued one at a time
 # (tools/bn_ab.py, tools/bn_ab_model.py) — an unresolved timing- or layout-dependent effect; bn.hip therefore stays on the
-# build that has passed every parity and contention test since round 2.  gemm / attention keep the vectoriser as well
+# build that has passed every parity and contention test since round 2 (the contention test runs the BatchNorm statistics /
+# apply / backward kernels, wide and generic, with and without row weights, since round 4).  gemm / attention keep the vectoriser as well
 # (their epilogues rely on the packed forms: 15.70 -> 16.36 ms without) and are covered by tests/test_contention_gpu.py.
 FILE_FLAGS = {"norm.hip": ["-fno-slp-vectorize"], "elementwise.hip": ["-fno-slp-vectorize"]}
 

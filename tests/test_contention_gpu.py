@@ -21,6 +21,6 @@ def test_kernels_repeat_bitwise_while_another_process_loads_the_gpu():
                        timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     rows = re.findall(r"^(.*\S)\s+mismatching launches (\d+) / (\d+)$", r.stdout, flags=re.M)
-    assert len(rows) >= 16, r.stdout[-2000:]
+    assert len(rows) >= 20, r.stdout[-2000:]
     bad = [(name, int(b), int(n)) for name, b, n in rows if int(b) != 0]
     assert not bad, bad

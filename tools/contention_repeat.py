@@ -63,7 +63,32 @@ def attn_bwd(P, H, S, L, algo):
                      dk=dqkv[:, d:], dk_strides=st, dv=dqkv[:, 2 * d:], dv_strides=st, algo=algo, **kw)
         return (dqkv,)
     return f
-cases = {"attention backward one-pass, paired 384 x 4 x 256^2 (LDS-DMA ring, counted waits)": attn_bwd(384, 4, 2, 256, 3),
+def bn(R, C, weighted):
+    y = torch.relu(torch.randn(R, C, device=dev) * 0.3 + 0.1).to(dt); dz = (torch.randn(R, C, device=dev) * 1e-3).to(dt)
+    rw = torch.randint(-1, 4, (R,), device=dev).float() if weighted else None
+    n = int(rw.clamp(min=0).sum().item()) if weighted else R
+    gam, bet = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+    def f():
+        mean, var, rstd = ops.bn_stats_finalize(y, 0, 0, 0, n, 1e-5, 0.0, None, None, rw)
+        z = ops.bn_apply_fwd(y, mean, rstd, gam, bet, 0, 0, 0, rw)
+        s2 = ops.bn_bwd_reduce(dz, y, mean, rstd, 0, 0, 0, rw)
+        dy = ops.bn_bwd_apply(dz, y, mean, rstd, gam, s2, 1.0 / n, True, 0, 0, 0, rw)
+        return mean, var, rstd, z, s2, dy
+    return f
+def rows_pool(B):
+    from druglamp_amd import synthetic
+    from druglamp_amd.protein_plan import PlanDev, plan_of
+    _, meta = synthetic.make_batch(B, "cpu", seed=0, with_graph=False)
+    plan = plan_of([m["Prot_Len"] for m in meta], 2304)
+    pd = PlanDev(plan, dev); pd.fill(plan)
+    z = torch.randn(plan.rows, 128, device=dev).to(dt); g = torch.randn(B, 256, 128, device=dev).to(dt)
+    x32 = torch.randn(4096, 640, device=dev)
+    return lambda: (ops.cnn_sitepool_rows_fwd(z, pd.row_of, B, 2304, 9), ops.cnn_sitepool_rows_bwd(g, pd.rep, pd.row_of, 2304, 9),
+                    ops.rows_gather(z, pd.row_of), ops.cast(x32, dt))
+cases = {"BatchNorm stats+finalize / apply / bwd reduce / bwd apply 300000x128 (wide kernels)": bn(300000, 128, False),
+         "BatchNorm with row weights 165888x128": bn(165888, 128, True), "BatchNorm 70000x96 (generic kernels)": bn(70000, 96, False),
+         "site pooling through the row map fwd / bwd, rows_gather, cast": rows_pool(128),
+         "attention backward one-pass, paired 384 x 4 x 256^2 (LDS-DMA ring, counted waits)": attn_bwd(384, 4, 2, 256, 3),
          "attention backward one-pass, one segment 300 x 4 x 200^2": attn_bwd(300, 4, 1, 200, 3),
          "tt 2048x512x65536": tt(2048, 512, 65536), "tt 1024x256x65536": tt(1024, 256, 65536), "tt 128x768x591867": tt(128, 768, 591867),
          "tt 256x256x65536 (128-tile)": tt(256, 256, 65536), "nn 65536x512x2048": nn(65536, 512, 2048), "nn 65536x768x256": nn(65536, 768, 256),
