@@ -210,8 +210,7 @@ class ProteinCNN(nn.Module):
             if self.training:
                 for bn in (self.bn1, self.bn2, self.bn3):
                     Fn.bn_tick(bn.num_batches_tracked)
-            if site_pool and outs[0].dtype == torch.bfloat16 and L % int(site_pool) == 0 and (L // int(site_pool)) % 8 == 0 and int(site_pool) <= outs[0].shape[1] \
-                    and self.pool_through_map:
+            if site_pool and self.pool_through_map and ops.cnn_sitepool_rows_supported(L, int(site_pool), outs[0].shape[1], outs[0].dtype):
                 # the reference's view reinterpretation + site pooling read through the row map: no (B, 2304, C) round trip
                 return SitePoolRowsFn.apply(outs[0], plan.row_of, plan.rep, B, L, int(site_pool))
             z = ExpandRowsFn.apply(outs[0], plan.row_of, plan.rep).view(B, L, C)      # channel-last, every position

@@ -739,6 +739,16 @@ def cnn_sitepool_bwd(dpooled: torch.Tensor, L: int, halo: int, site_len: int) ->
     return dz
 
 
+def cnn_sitepool_rows_supported(L: int, site_len: int, C: int, dtype: torch.dtype) -> bool:
+    """The shape rules of dl_cnn_sitepool_rows_fwd / _bwd (bf16; the forward's strip of site_len x 32 rows and the backward's
+    image of one sample's pooled gradient must fit the 160 KB of LDS: 256 sites at 128 channels do, the 1024 sites of
+    PROTEIN.SEQ_LEN 9216 do not — such shapes take the expansion + dense pooling kernels)."""
+    if dtype != torch.bfloat16 or site_len <= 0 or L % site_len or C % 8 or site_len > C:
+        return False
+    n_site = L // site_len
+    return n_site % 8 == 0 and site_len * C * 34 * 2 <= 160 * 1024 and (n_site + 2) * C * 2 + C * 16 + 16 * 1024 <= 160 * 1024
+
+
 def cnn_sitepool_rows_fwd(z2d: torch.Tensor, row_of: torch.Tensor, B: int, L: int, site_len: int) -> torch.Tensor:
     """compact rows z2d (R, C) + position map -> pooled (B, L // site_len, C); see dl_cnn_sitepool_rows_fwd."""
     _need_gpu(z2d, row_of)

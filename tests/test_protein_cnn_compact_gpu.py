@@ -101,6 +101,36 @@ def test_site_pooling_through_the_row_map(S, site_len, C, lengths):
     assert torch.equal(dz, ops.cnn_sitepool_rows_bwd(g, pd.rep, pd.row_of, S, site_len))   # repeatable
 
 
+def test_long_proteins_take_the_expansion_path_with_the_plan():
+    """BASELINE config 5 (PROTEIN.SEQ_LEN 9216 = 1024 sites): one sample's pooled gradient (1024 x 128 bf16) does not fit the LDS
+    image of dl_cnn_sitepool_rows_bwd, so the module must fall back to expansion + the dense pooling kernels — and give the
+    full computation's output and gradients there too."""
+    from druglamp_amd import ops
+    from druglamp_amd.model.basic_model import ProteinCNN
+    assert ops.cnn_sitepool_rows_supported(2304, 9, 128, torch.bfloat16) and not ops.cnn_sitepool_rows_supported(9216, 9, 128, torch.bfloat16)
+    assert not ops.cnn_sitepool_rows_supported(2304, 9, 128, torch.float32)
+    S, lengths = 9216, [4094, 1500, 300]
+    torch.manual_seed(0)
+    full = ProteinCNN(128, [128, 128, 128], [3, 6, 9]).to(DEV)
+    full.compute_dtype = torch.bfloat16
+    comp = copy.deepcopy(full)
+    ids, fill = _tiled(len(lengths), S, lengths)
+    pd = _plan_dev(lengths, S)
+    up = torch.randn(len(lengths), S // 9, 128, device=DEV).bfloat16()
+    outs = []
+    for m, plan in ((full, None), (comp, pd)):
+        m.train()
+        z = m(ids, fill.bfloat16(), site_pool=9, plan=plan)
+        (z.float() * up.float()).sum().backward()
+        outs.append(z)
+    ops.check_guard_flags(DEV)
+    assert relerr(outs[1], outs[0]) <= 3e-2
+    for (k, a), (_, b) in zip(comp.named_parameters(), full.named_parameters()):
+        if float(b.grad.norm()) > 1e-3 * max(float(p.grad.norm()) for p in full.parameters()):
+            cos = float(torch.dot(a.grad.flatten(), b.grad.flatten()) / (a.grad.norm() * b.grad.norm()))
+            assert cos >= 0.99, (k, cos)
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
 def test_compact_protein_cnn_module_equals_the_full_one(dt, tol):
     from druglamp_amd.model.basic_model import ProteinCNN
