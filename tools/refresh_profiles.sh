@@ -42,6 +42,7 @@ DL_BRANCH_STREAMS=0 python3 "$ROOT/bench.py" --steps 100 --no-cpu-baseline --no-
 DL_CNN_COMPACT=0 python3 "$ROOT/bench.py" --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_cnn_every_position.json"
 DL_ATTN_BWD_ALGO=2 python3 "$ROOT/bench.py" --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_attn_bwd_kernel_pair.json"
 DL_POOL_THROUGH_MAP=0 python3 "$ROOT/bench.py" --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_sitepool_by_expansion.json"
+python3 "$ROOT/bench.py" --seq-len 9216 --batch 32 --steps 50 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_line_config5_seq9216_batch32.json"
 python3 "$ROOT/tools/attn_bwd_onepass.py" 256 128 64 32 > "$OUT/attn_bwd_onepass.txt" 2>/dev/null
 python3 "$ROOT/tools/sitepool_rows_bench.py" 256 > "$OUT/sitepool_rows.txt" 2>/dev/null; python3 "$ROOT/tools/sitepool_rows_bench.py" 32 >> "$OUT/sitepool_rows.txt" 2>/dev/null
 python3 "$ROOT/tools/gemm_shapes.py" > "$OUT/gemm_shapes.txt" 2>&1
