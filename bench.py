@@ -107,6 +107,10 @@ def main():
     ap.add_argument("--drug-ssl", default="simsiam", choices=["simsiam", "simclr"],
                     help="RS.DRUG_SSL_TYPE: simclr = the reference's nt_xent_loss over the B*512 node rows (config C3 with "
                          "--global-batch-heads: its denominator runs over the all-gathered global batch)")
+    ap.add_argument("--distinct-batches", type=int, default=8,
+                    help="distinct synthetic (batch, meta) pairs cycled through the warm-up and the timed steps — other protein "
+                         "lengths, token counts and ids every step, so the per-batch host work (layout spec, table refill, label "
+                         "blocks) and the capacity logic of captured graphs are inside the timed region (ADVICE r4)")
     ap.add_argument("--min-busy-seconds", type=float, default=2.0,
                     help="after the K timed steps, keep stepping (untimed) until the GPU has been busy this long in total, so "
                          "that a short --steps run is visible to an external utilisation sampler")
@@ -165,22 +169,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    batch_sets = {}
+
+    def batches_of(per_gpu_batch):
+        """`--distinct-batches` synthetic batches of one size, resident in HBM (generated once per size)."""
+        if per_gpu_batch not in batch_sets:
+            batch_sets[per_gpu_batch] = [
+                make_batch(per_gpu_batch, dev, seed=100 + rank + 1009 * i, with_graph=True, llm_dtype=cdt, seq_len=args.seq_len,
+                           max_prot_len=1022 if args.seq_len <= 2304 else args.seq_len // 2 - 2)
+                for i in range(max(args.distinct_batches, 1))]
+        return batch_sets[per_gpu_batch]
+
     def measure(per_gpu_batch, steps, warmup, with_events, busy=False):
-        """W untimed + K timed steps at one per-GPU batch; returns (seconds, max over ranks; family statistics)."""
-        batch, meta = make_batch(per_gpu_batch, dev, seed=100 + rank, with_graph=True, llm_dtype=cdt, seq_len=args.seq_len,
-                                 max_prot_len=1022 if args.seq_len <= 2304 else args.seq_len // 2 - 2)
-        for _ in range(max(warmup, trainer.graph_warmup + 1 if graphed else 0)):
+        """W untimed + K timed steps at one per-GPU batch, cycling through the distinct batches (a replayed graph receives each
+        as a device-to-device copy into its static inputs — the stand-in for a loader that assembles the next batch there);
+        returns (seconds, max over ranks; family statistics)."""
+        pairs = batches_of(per_gpu_batch)
+        it = [0]
+
+        def step():
+            batch, meta = pairs[it[0] % len(pairs)]
+            it[0] += 1
             trainer.training_step(batch, meta=meta, cur_epoch=ep)
-        batch = trainer.static_batch(batch)       # inputs stay resident: the graph's own input tensors (no per-step copy)
+
+        # (graph mode: every distinct batch is seen once more than the warm-up count, so the captures the capacity classes
+        #  need have all been made before the timed region starts)
+        for _ in range(max(warmup, (trainer.graph_warmup + 1) * len(pairs) if graphed else 0)):
+            step()
         sync()
         if with_events:
             for fam in (0, 1, 2):
                 L.dl_prof_enable(fam, max(args.time_every, 1))
+        captures0 = trainer.graph_captures
         t0 = time.perf_counter()
         for _ in range(steps):
-            trainer.training_step(batch, meta=meta, cur_epoch=ep)
+            step()
         sync()
         dt = time.perf_counter() - t0
+        measure.captures_in_timed_region = trainer.graph_captures - captures0
         trainer.check_device_flags()              # the padding guards of the compact forms (raises if one tripped)
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         if world > 1:
@@ -208,7 +234,7 @@ def main():
             # untimed, after the K timed steps and the event collection: keeps the GPU busy long enough for an external
             # utilisation sampler to see a short --steps run (every rank runs the same count: t is the max over ranks)
             for _ in range(int((args.min_busy_seconds - float(t)) / max(float(t) / steps, 1e-6)) + 1):
-                trainer.training_step(batch, meta=meta, cur_epoch=ep)
+                step()
             sync()
         return float(t), stats
 
@@ -219,6 +245,7 @@ def main():
     # same kernels): HIP events bracket a launch on its stream, and a launch that shares the chip with another stream's
     # kernels — or is a node of a replayed graph — has no duration of its own to bracket.
     dt, fam_stats = measure(args.batch, args.steps, args.warmup, False, busy=True)
+    timed_captures, live_graphs = getattr(measure, "captures_in_timed_region", 0), len(trainer._graphs)
     events_steps, events_dt, events_note = args.steps, dt, None
     if timing:
         saved = (trainer.graph_steps, model.branch_streams)
@@ -257,6 +284,11 @@ def main():
                                        (", drug SSL = NT-Xent (simclr)" if args.drug_ssl == "simclr" else "")),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "step_kind": "+".join(kinds), "epoch": ep, "hip_graph": bool(graphed), "protein_seq_len": args.seq_len,
+                       # the timed steps cycle through this many distinct batches (other lengths / token counts / ids each);
+                       # graph mode: graphs live after the run and captures that fell INTO the timed region (0 = none)
+                       "distinct_batches": max(args.distinct_batches, 1),
+                       "hip_graphs_live": live_graphs if graphed else None,
+                       "hip_graph_captures_in_timed_region": timed_captures if graphed else None,
                        # identical padding rows of the drug branch (virtual GCN nodes beyond the adjacency block, zero token rows
                        # beyond the collate's Drug_Tokens) are computed once and expanded: same results as computing every row
                        # (tests/test_model_gpu.py); DL_GCN_COMPACT=0 DL_PAD_COMPACT=0 computes every row

@@ -63,7 +63,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-FLAG_PROT_PERIOD, FLAG_DRUG_TOKEN_PAD, FLAG_GCN_NODE_PAD = 1, 2, 4
+FLAG_PROT_PERIOD, FLAG_DRUG_TOKEN_PAD, FLAG_GCN_NODE_PAD, FLAG_PLAN_ROWS = 1, 2, 4, 8
 TAG_OTHER, TAG_QKV_OUT, TAG_FFN, TAG_CONV, TAG_WGRAD, TAG_ADAPTOR = 0, 1, 2, 3, 4, 5
 TAG_NAMES = {0: "other", 1: "qkv_out", 2: "ffn", 3: "conv", 4: "wgrad", 5: "adaptor"}
 
@@ -177,6 +177,7 @@ SIGNATURES = {
     "dl_rows_gather": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "dl_rows_sum_strided": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp]),
     "dl_rows_equal_check": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i64, C.c_uint32, c_vp, c_vp]),
+    "dl_protein_plan_build": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dl_prof_enable": (c_i32, [c_i32, c_i32]),
     "dl_prof_collect": (c_i32, [c_i32, C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),

@@ -8,6 +8,9 @@
 //   dl_rows_sum_strided  out[r] = sum_{k < count[r]} x[first[r] + k * stride[r]]: the gather's backward, fixed summation order
 //   dl_rows_equal_check  rows row0.. of every sample equal row row0 of sample 0 (bitwise) — else flag bit `code`
 //                        (the drug branch's "identical padding rows" contract)
+//   dl_protein_plan_build  the row tables themselves (src, w, rep, row_of, period) from the batch's residue counts, on the
+//                        device (round 5): the host hands over B integers instead of building and copying ~6 MB of tables
+//                        per batch (protein_plan.ProteinPlan stays as the host statement of the same tables; tests compare)
 #include "common.cuh"
 
 namespace {
@@ -29,8 +32,10 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const int64_t* __restri
     const int P = period[b];
     const int64_t* idb = ids + (int64_t)b * L;
     const T* fb = fill + (int64_t)b * L;
-    bool bad = P < 1 || P > L;
-    if (!bad) {
+    // P == 0: the tables keep every position of this sample (plain layout, protein_plan._segments: fewer than two whole
+    // periods fit) — nothing is assumed about it, nothing to check
+    bool bad = P < 0 || P > L;
+    if (!bad && P > 0) {
       const int E = (L / P) * P;
       for (int t = tid; t < L; t += 256) {
         if (t + P < E) bad |= idb[t] != idb[t + P] || bits_of(fb[t]) != bits_of(fb[t + P]);
@@ -161,6 +166,107 @@ __global__ __launch_bounds__(256) void rows_equal_check_kernel(const W* __restri
   }
   if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) atomicOr(flags, code);
 }
+// ---- row tables of the compact ProteinCNN layout, built on the device ------------------------------------------------------
+// One sample with Lr residues in a sequence of S positions (protein_plan.py states the same rules on the host):
+//   P = Lr + 2, E = (S / P) * P.  mode 0 (plain): every position its own row, S + 8 rows.
+//   mode 1: segments A = [0, P + 14], B = [E - 15, E + 15], C = [S - 15, S - 1]   (P + 85 rows with 4 halo rows per side each)
+//   mode 2: segments A, BC = [E - 15, S - 1]                                     (P + S - E + 46 rows)
+constexpr int PL_HALO = 4, PL_RFL = 7, PL_RFR = 8;
+struct PlanSample { int P, E, mode, rows; };
+__device__ __forceinline__ PlanSample plan_sample(int Lr, int S) {
+  PlanSample p;
+  p.P = Lr + 2;
+  const int reps = p.P > 0 ? S / p.P : 0;
+  p.E = reps * p.P;
+  const bool plain = reps < 2 || p.P + 2 * PL_RFL + 2 * PL_RFR + 40 >= S || p.P + PL_RFL - 1 + PL_RFR >= p.E - PL_RFR - PL_RFL;
+  p.mode = plain ? 0 : (S - p.E > 2 * (PL_RFL + PL_RFR) + 2 ? 1 : 2);
+  p.rows = plain ? S + 2 * PL_HALO : (p.mode == 1 ? p.P + 85 : p.P + S - p.E + 46);
+  return p;
+}
+
+__device__ __forceinline__ int block_sum_256(int v, int* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void plan_build_kernel(const int32_t* __restrict__ lengths, int B, int S, int R,
+                                                          int32_t* __restrict__ src, float* __restrict__ w, int32_t* __restrict__ rep,
+                                                          int32_t* __restrict__ row_of, int32_t* __restrict__ period,
+                                                          uint32_t* __restrict__ flags) {
+  __shared__ int red[4];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  // rows in front of this sample (blocks >= B: all rows) — B is a few hundred, every block sums for itself
+  int part = 0;
+  const int upto = b < B ? b : B;
+  for (int i = tid; i < upto; i += 256) part += plan_sample(lengths[i], S).rows;
+  const int off = block_sum_256(part, red);
+  if (b >= B) {                                                // bucket padding behind the last sample
+    if (off > R) {
+      if (tid == 0 && b == B && flags) atomicOr(flags, (uint32_t)DL_FLAG_PLAN_ROWS);
+      return;
+    }
+    const int nb = gridDim.x - B;
+    for (int r = off + (b - B) * 256 + tid; r < R; r += nb * 256) {
+      src[r] = -1; w[r] = -1.f; rep[3 * r] = 0; rep[3 * r + 1] = 1; rep[3 * r + 2] = 0;
+    }
+    return;
+  }
+  const PlanSample p = plan_sample(lengths[b], S);
+  if (off + p.rows > R) return;                                // (the padding blocks raise the flag)
+  const int P = p.P, E = p.E, base = b * S;
+  if (tid == 0) period[b] = p.mode == 0 ? 0 : P;
+  // segment table: first row, first position, number of positions, representative range
+  const int nA = P + PL_RFL + PL_RFR;                          // positions 0 .. P + 14
+  const int oB = nA + 2 * PL_HALO, oC = oB + 31 + 2 * PL_HALO;
+  for (int j = tid; j < p.rows; j += 256) {
+    int pos = -1, count = 0, stride = 1;
+    if (p.mode == 0) {
+      if (j >= PL_HALO && j < PL_HALO + S) { pos = j - PL_HALO; count = 1; }
+    } else if (j < oB) {                                        // A
+      if (j >= PL_HALO && j < PL_HALO + nA) {
+        pos = j - PL_HALO;
+        if (pos <= P + PL_RFL - 1) {
+          count = 1;
+          if (pos >= PL_RFL) { const int k = (E - PL_RFR - 1 - pos) / P + 1; count = k > 1 ? k : 1; stride = P; }
+        }
+      }
+    } else if (p.mode == 2) {                                   // B and C merged: [E - 15, S - 1], representatives E - 8 ..
+      const int n = S - E + 15, q = j - oB - PL_HALO;
+      if (q >= 0 && q < n) { pos = E - 15 + q; count = pos >= E - PL_RFR ? 1 : 0; }
+    } else if (j < oC) {                                        // B: representatives E - 8 .. E + 7, E + 7 = the deep tail
+      const int q = j - oB - PL_HALO;
+      if (q >= 0 && q < 31) {
+        pos = E - 15 + q;
+        count = (pos >= E - PL_RFR && pos <= E + PL_RFL) ? 1 : 0;
+        if (pos == E + PL_RFL) { const int c = S - PL_RFR - (E + PL_RFL); count = c > 1 ? c : 1; }
+      }
+    } else {                                                    // C: representatives S - 8 .. S - 1
+      const int q = j - oC - PL_HALO;
+      if (q >= 0 && q < 15) { pos = S - 15 + q; count = pos >= S - PL_RFR ? 1 : 0; }
+    }
+    const int r = off + j;
+    src[r] = pos < 0 ? -1 : base + pos;
+    w[r] = pos < 0 ? -1.f : (float)count;
+    rep[3 * r] = base + (pos < 0 ? 0 : pos);
+    rep[3 * r + 1] = stride;
+    rep[3 * r + 2] = count;
+  }
+  for (int t = tid; t < S; t += 256) {
+    int j;
+    if (p.mode == 0 || t <= P + PL_RFL - 1) j = PL_HALO + t;
+    else if (t <= E - PL_RFR - 1) j = PL_HALO + PL_RFL + (t - PL_RFL) % P;           // a copy of representative 7 + (t - 7) mod P
+    else if (p.mode == 2 || t <= E + PL_RFL) j = oB + PL_HALO + (t - (E - 15));
+    else if (t <= S - PL_RFR - 1) j = oB + PL_HALO + 22;                               // the deep tail: representative E + 7
+    else j = oC + PL_HALO + (t - (S - 15));
+    row_of[base + t] = off + j;
+  }
+}
 }  // namespace
 
 extern "C" int dl_embed_rows(const int64_t* ids, const void* weight, const void* fill, const int32_t* src, void* out, int64_t R,
@@ -238,5 +344,18 @@ extern "C" int dl_rows_equal_check(const void* x, int64_t B, int64_t N, int64_t 
   if (wide) hipLaunchKernelGGL((rows_equal_check_kernel<u32x4>), dim3((uint32_t)blocks), dim3(256), 0, s, (const u32x4*)x, B, (int)N, cpr, (int)row0, code, flags);
   else hipLaunchKernelGGL((rows_equal_check_kernel<uint32_t>), dim3((uint32_t)blocks), dim3(256), 0, s, (const uint32_t*)x, B, (int)N, cpr, (int)row0, code, flags);
   DL_CHECK_LAUNCH("dl_rows_equal_check");
+  return DL_OK;
+}
+
+extern "C" int dl_protein_plan_build(const int32_t* lengths, int64_t B, int64_t S, int64_t R, int32_t* src, float* w, int32_t* rep,
+                                     int32_t* row_of, int32_t* period, uint32_t* flags, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(lengths && src && w && rep && row_of && period && B > 0 && S > 0 && R > 0, DL_ERR_ARG, "dl_protein_plan_build: bad args");
+  DL_CHECK_ARG(B * S < (1ll << 31) && R < (1ll << 30) && B < (1 << 20), DL_ERR_SHAPE, "dl_protein_plan_build: index range");
+  int64_t pad_blocks = R / (256 * 16) + 1;
+  if (pad_blocks > 64) pad_blocks = 64;
+  hipLaunchKernelGGL(plan_build_kernel, dim3((uint32_t)(B + pad_blocks)), dim3(256), 0, s, lengths, (int)B, (int)S, (int)R, src, w, rep,
+                     row_of, period, flags);
+  DL_CHECK_LAUNCH("dl_protein_plan_build");
   return DL_OK;
 }

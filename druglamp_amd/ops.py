@@ -793,7 +793,9 @@ FLAG_TEXT = {_lib.FLAG_PROT_PERIOD: "a protein's residue codes / fill bits are n
              _lib.FLAG_DRUG_TOKEN_PAD: "drug LLM token rows beyond the hinted block (meta 'Drug_Tokens') are not identical padding rows; "
                                        "disable with DL_PAD_COMPACT=0",
              _lib.FLAG_GCN_NODE_PAD: "drug graph nodes beyond the adjacency block are not identical virtual padding nodes "
-                                     "(handler/dataset.py:216-221); disable with DL_GCN_COMPACT=0"}
+                                     "(handler/dataset.py:216-221); disable with DL_GCN_COMPACT=0",
+             _lib.FLAG_PLAN_ROWS: "the ProteinCNN row tables were built with fewer rows than the batch's residue counts need "
+                                  "(dl_protein_plan_build capacity)"}
 
 
 def guard_flags(device) -> torch.Tensor:
@@ -834,6 +836,15 @@ def embed_rows(ids: torch.Tensor, weight: torch.Tensor, fill: torch.Tensor, src:
     check(_lib.lib().dl_embed_rows(ids.data_ptr(), weight.data_ptr(), fill.data_ptr(), src.data_ptr(), out.data_ptr(), R, V, D,
                                    _ptr(period), B, L, _ptr(flags), _dt(weight), _stream()), "dl_embed_rows")
     return out
+
+
+def protein_plan_build(pd) -> None:
+    """The ProteinCNN distinct-row tables of protein_plan.PlanDev `pd` from its residue counts `pd.len_dev`, on the device
+    (dl_protein_plan_build, current stream); a capacity overflow sets the device guard word."""
+    _need_gpu(pd.buf)
+    check(_lib.lib().dl_protein_plan_build(pd.len_dev.data_ptr(), pd.B, pd.S, pd.rows, pd.src.data_ptr(), pd.w.data_ptr(),
+                                           pd.rep.data_ptr(), pd.row_of.data_ptr(), pd.period.data_ptr(),
+                                           guard_flags(pd.buf.device).data_ptr(), _stream()), "dl_protein_plan_build")
 
 
 def rows_gather(src2d: torch.Tensor, index: torch.Tensor) -> torch.Tensor:

@@ -31,6 +31,14 @@ BatchNorm statistics (weighted) and all parameter gradients are those of the ref
 The tables depend on (L, S) only.  Whether a batch really has this structure is verified ON THE DEVICE by the kernel
 that builds the compact input (dl_embed_rows: ids and fill bits periodic with period P up to E, constant behind E); a
 violation sets a sticky flag word that the trainer polls (Trainer.check_device_flags).
+
+Round 5: on the GPU the tables are BUILT ON THE DEVICE (csrc/compact.hip, dl_protein_plan_build) from the batch's B residue
+counts — what the training thread does per batch is `PlanSpec` (a vectorised row count, microseconds) and a B x 4 byte
+copy; round 4 built ~170 k table rows in per-sample numpy calls (8-14 ms at batch 256) and copied 5.8 MB per
+batch.  `ProteinPlan` below remains the host statement of the same tables: the CPU tests run the network through it, and the
+GPU tests compare the device-built tables with it entry by entry.  Row capacities: eager steps round the needed rows up to
+ROW_BUCKET; captured graphs use geometric size classes (`row_class`, ratio ~1.25) so that batches of varying lengths share
+one graph instead of one per 2048-row bucket.
 """
 from __future__ import annotations
 
@@ -43,6 +51,47 @@ RF_LEFT, RF_RIGHT = 7, 8          # receptive field of the three convolutions: 1
 ROW_BUCKET = 2048   # compact row counts are rounded up to a multiple of this (few distinct shapes for captured graphs)
 
 _template_cache: Dict[Tuple[int, int], tuple] = {}
+
+
+def sample_rows(lengths, S: int) -> np.ndarray:
+    """Compact rows (halo rows included) of every sample, vectorised — the same case split as `_segments`."""
+    L = np.asarray(lengths, dtype=np.int64).reshape(-1)
+    P = L + 2
+    reps = np.where(P > 0, S // np.maximum(P, 1), 0)
+    E = reps * P
+    plain = (reps < 2) | (P + 2 * RF_LEFT + 2 * RF_RIGHT + 40 >= S) | (P + RF_LEFT - 1 + RF_RIGHT >= E - RF_RIGHT - RF_LEFT)
+    sep = (S - E) > 2 * (RF_LEFT + RF_RIGHT) + 2
+    return np.where(plain, S + 2 * HALO, np.where(sep, P + 85, P + S - E + 46))
+
+
+def row_class(rows: int, unit: int = ROW_BUCKET) -> int:
+    """Row capacity of a captured graph's tables: the next value of a geometric ladder of `unit` multiples (ratio ~1.25:
+    2048 x {1, 2, 3, 4, 5, 7, 9, 12, 15, 19, 24, 30, ...}).  Batches whose random lengths differ by a few buckets land in
+    one class; a graph captured for a class serves every batch that needs at most that many rows."""
+    k = -(-max(int(rows), 1) // unit)
+    c = 1
+    while c < k:
+        c = max(c + 1, int(c * 1.25))
+    return c * unit
+
+
+class PlanSpec:
+    """What the training thread knows about a batch's ProteinCNN layout without building any table: the residue counts, the
+    rows the compact layout needs (bucket padding excluded) and whether it pays."""
+    __slots__ = ("lengths", "S", "B", "need", "n")
+
+    def __init__(self, lengths: Sequence[int], S: int):
+        self.lengths = np.ascontiguousarray(np.asarray(lengths, dtype=np.int32).reshape(-1))
+        self.S, self.B = int(S), int(self.lengths.shape[0])
+        self.need = int(sample_rows(self.lengths, self.S).sum())
+        self.n = self.B * self.S
+
+    def rows(self, bucket: int = ROW_BUCKET) -> int:
+        return -(-max(self.need, 1) // bucket) * bucket
+
+    def pays(self, rows: int = 0) -> bool:
+        """Whether the compact layout (at `rows` capacity) is meaningfully smaller than the padded full one."""
+        return (rows or self.rows()) * 4 <= self.B * (self.S + 2 * HALO) * 3
 
 
 def _segments(P: int, S: int):
@@ -154,7 +203,9 @@ class ProteinPlan:
         rep[:, 1] = np.maximum(rep[:, 1], 1)
         self.rep = np.ascontiguousarray(rep)
         self.row_of = np.concatenate(maps).astype(np.int32)
-        self.period = np.array([L + 2 for L in self.lengths], dtype=np.int32)
+        # period 0 = "plain layout, no periodic claim" (the device guard then checks nothing for the sample: a protein whose
+        # period exceeds the sequence, reps = 0, is legal and keeps every position — ADVICE r4)
+        self.period = np.array([0 if _segments(L + 2, self.S) is None else L + 2 for L in self.lengths], dtype=np.int32)
         self.n = self.B * self.S
         self.key = (self.rows, self.B, self.S)
 
@@ -164,68 +215,79 @@ class ProteinPlan:
 
 
 class PlanDev:
-    """A ProteinPlan's tables on the device: ONE buffer, five views (src, w, rep, row_of, period), refilled in place from a
-    pinned staging ring with one non-blocking copy (a captured graph keeps pointing at the same tensors; an eager step's
-    refill is stream-ordered behind the previous step's kernels).  Shapes are fixed by plan.key = (rows, B, S)."""
+    """Row tables on the device: ONE buffer, five views (src, w, rep, row_of, period) + the residue counts, with a fixed row
+    capacity.  `fill(spec)` makes them the tables of a batch: on the GPU a B x 4 byte copy from a pinned ring and one
+    dl_protein_plan_build launch on the current stream (a captured graph keeps pointing at the same tensors; the refill is
+    stream-ordered behind the previous step's kernels); on the CPU (tests) the host tables of `ProteinPlan`.
+    key = (rows, B, S) is what shapes — and captured graphs — depend on."""
 
-    def __init__(self, plan: ProteinPlan, device):
+    def __init__(self, plan, device, rows: int = 0):
+        """plan: a PlanSpec (rows = capacity, default: the spec's rows rounded up to ROW_BUCKET) or a ProteinPlan (its rows)."""
         import torch
-        self.key = plan.key
-        R, B, S = plan.rows, plan.B, plan.S
+        if isinstance(plan, ProteinPlan):
+            rows = rows or plan.rows
+            plan = PlanSpec(plan.lengths, plan.S)
+        R, B, S = int(rows or plan.rows()), plan.B, plan.S
+        if plan.need > R:
+            raise ValueError("PlanDev: %d rows do not hold a batch that needs %d" % (R, plan.need))
+        self.key = (R, B, S)
         self.rows, self.B, self.S, self.n = R, B, S, plan.n
         o_w, o_rep, o_map, o_per = 4 * R, 8 * R, 20 * R, 20 * R + 4 * B * S
-        self.nbytes = (o_per + 4 * B + 15) // 16 * 16
-        self._off = (o_w, o_rep, o_map, o_per)
+        o_len = o_per + 4 * B
+        self.nbytes = (o_len + 4 * B + 15) // 16 * 16
+        self._off = (o_w, o_rep, o_map, o_per, o_len)
         self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
         self.src = self.buf[:o_w].view(torch.int32)
         self.w = self.buf[o_w:o_rep].view(torch.float32)
         self.rep = self.buf[o_rep:o_map].view(torch.int32).view(R, 3)
         self.row_of = self.buf[o_map:o_per].view(torch.int32)
-        self.period = self.buf[o_per:o_per + 4 * B].view(torch.int32)
-        on_gpu = torch.device(device).type == "cuda"
-        self._pins = [torch.zeros(self.nbytes, dtype=torch.uint8).pin_memory() if on_gpu else torch.zeros(self.nbytes, dtype=torch.uint8)
-                      for _ in range(3)]
+        self.period = self.buf[o_per:o_len].view(torch.int32)
+        self.len_dev = self.buf[o_len:o_len + 4 * B].view(torch.int32)
+        self.on_gpu = torch.device(device).type == "cuda"
+        self._pins = [torch.zeros(B, dtype=torch.int32).pin_memory() for _ in range(4)] if self.on_gpu else []
         self._events = [None] * len(self._pins)
         self._slot = 0
         self.lengths = None
         self.fill(plan)
 
-    def fill(self, plan: ProteinPlan):
+    def fill(self, plan):
         import torch
-        if plan.key != self.key:
-            raise ValueError("PlanDev: a plan of shape %s does not fit tables of shape %s" % (plan.key, self.key))
-        if plan.lengths == self.lengths:
+        if isinstance(plan, ProteinPlan):
+            plan = PlanSpec(plan.lengths, plan.S)
+        if (plan.B, plan.S) != (self.B, self.S) or plan.need > self.rows:
+            raise ValueError("PlanDev: a batch of shape (%d, %d) needing %d rows does not fit tables of shape %s"
+                             % (plan.B, plan.S, plan.need, self.key))
+        if self.lengths is not None and np.array_equal(plan.lengths, self.lengths):
             return self
-        o_w, o_rep, o_map, o_per = self._off
-        k = self._slot
-        self._slot = (k + 1) % len(self._pins)
-        if self._events[k] is not None:
-            self._events[k].synchronize()
-        host = self._pins[k].numpy()
-        host[:o_w].view(np.int32)[:] = plan.src
-        host[o_w:o_rep].view(np.float32)[:] = plan.w
-        host[o_rep:o_map].view(np.int32)[:] = plan.rep.reshape(-1)
-        host[o_map:o_per].view(np.int32)[:] = plan.row_of
-        host[o_per:o_per + 4 * plan.B].view(np.int32)[:] = plan.period
-        self.buf.copy_(self._pins[k], non_blocking=True)
-        if self.buf.is_cuda:
+        if not self.on_gpu:
+            host = ProteinPlan(plan.lengths, self.S, bucket=1)
+            pad = self.rows - host.rows
+            self.src.copy_(torch.from_numpy(np.concatenate([host.src, np.full(pad, -1, np.int32)])))
+            self.w.copy_(torch.from_numpy(np.concatenate([host.w, np.full(pad, -1.0, np.float32)])))
+            prep = np.zeros((pad, 3), np.int32)
+            prep[:, 1] = 1
+            self.rep.copy_(torch.from_numpy(np.concatenate([host.rep, prep])))
+            self.row_of.copy_(torch.from_numpy(host.row_of))
+            self.period.copy_(torch.from_numpy(host.period))
+            self.len_dev.copy_(torch.from_numpy(plan.lengths))
+        else:
+            from . import ops
+            k = self._slot
+            self._slot = (k + 1) % len(self._pins)
+            if self._events[k] is not None:
+                self._events[k].synchronize()
+            self._pins[k].numpy()[:] = plan.lengths
+            self.len_dev.copy_(self._pins[k], non_blocking=True)
             self._events[k] = torch.cuda.Event()
             self._events[k].record()
-        self.lengths = plan.lengths
+            ops.protein_plan_build(self)
+        self.lengths = plan.lengths.copy()
         return self
 
 
-_plan_cache: Dict[tuple, ProteinPlan] = {}
-
-
 def plan_of(lengths: Sequence[int], S: int):
-    """The (cached) plan of a batch, or None when the compact layout would not be meaningfully smaller."""
-    key = (tuple(int(v) for v in lengths), int(S))
-    p = _plan_cache.get(key)
-    if p is None:
-        if len(_plan_cache) > 64:
-            _plan_cache.clear()
-        p = _plan_cache[key] = ProteinPlan(key[0], S)
+    """The PlanSpec of a batch, or None when the compact layout would not be meaningfully smaller."""
+    p = PlanSpec(lengths, S)
     return p if p.pays() else None
 
 

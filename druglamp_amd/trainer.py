@@ -244,7 +244,7 @@ class GraphedStep:
       * the weight images are refreshed from the fp32 masters by the dl_weight_prep launch at the head of the graph;
       * BatchNorm running statistics are updated by the in-graph dl_bn_finalize launches."""
 
-    def __init__(self, trainer: "Trainer", batch, kind: str = "cls", meta=None):
+    def __init__(self, trainer: "Trainer", batch, kind: str = "cls", meta=None, caps=None):
         """Capture only records (nothing executes): the caller has already run eager steps of this shape AND kind, so lazy
         allocations (the SimSiam projectors of the first SSL forward), weight-image tables and workspaces exist.
         kind "ssl" (round 3): a step of an SSL epoch without the CM head — forward, BCE (logged only: its backward is dead,
@@ -260,7 +260,13 @@ class GraphedStep:
         self.tr = trainer
         dev = trainer.device
         self.static = self._clone(batch)
-        self.hints = trainer.hints_of(meta, batch, own_tables=True, kind=kind)   # (this graph's own device tables: refilled per replay)
+        # this graph's own device tables (refilled per replay) at the CAPACITIES the capture is made for: caps = (drug-token
+        # block, ProteinCNN table rows), by-value knowledge of the capture — any batch that needs at most that much replays it
+        self.hints = trainer.hints_of(meta, batch, own_tables=True, kind=kind, caps=caps)
+        self.block = self.hints.drug_tokens                    # 0 = every drug-token row computed (serves any batch)
+        self.rows_cap = None if self.hints.protein_plan is None else self.hints.protein_plan.rows
+        self.base = None                                        # (set by the trainer: kind + batch signature + by-value scalars)
+        self.byval = ()
         self.labels = None
         if "cm" in kind:
             from .model.cross_modality import CMCodes, CMLabels
@@ -397,11 +403,11 @@ class GraphedStep:
         return "cm" if "cm" in self.kind else self.kind
 
     def run(self, batch, meta=None):
-        if self.hints.protein_plan is not None:    # this batch's distinct-row tables -> the graph's static tables
-            plan = self.tr.protein_plan_of(meta, batch)
-            if plan is None or plan.key != self.hints.protein_plan.key:
-                raise RuntimeError("GraphedStep: the batch's ProteinCNN row tables do not have the captured shape")
-            self.hints.protein_plan.fill(plan)
+        if self.hints.protein_plan is not None:    # this batch's residue counts -> the graph's static tables (built on the device)
+            spec = self.tr.protein_plan_of(meta, batch, must_pay=False)
+            if spec is None or spec.need > self.hints.protein_plan.rows:
+                raise RuntimeError("GraphedStep: the batch's ProteinCNN row tables do not fit the captured capacity")
+            self.hints.protein_plan.fill(spec)
         if self.labels is not None:                # host label matrix / id codes -> the graph's static tensors
             if hasattr(self.labels, "buf"):
                 self.labels.fill(meta, self.tr.model.cm_model.use_cm)
@@ -424,6 +430,12 @@ class Trainer:
     graph_steps=True: cls, SSL-epoch and CM steps run as hipGraph replays (GraphedStep); the first steps of every new
     (batch shape, step kind), the epoch the CM head starts in and the global-batch CM form stay eager."""
     overlap = None
+    # (drug-token block, ProteinCNN table rows) used for EVERY step, eager or captured, instead of per-batch capacities.
+    # Reductions over rows (BatchNorm statistics, split-K weight gradients) associate by the row count, so an eager trainer
+    # matches a graph-replaying one BIT FOR BIT only at equal capacities: the graph-vs-eager tests pin this on both trainers
+    # when their batches differ (`fixed_caps_for`).  Eager steps otherwise round the needed rows up to 2048, captures use the
+    # geometric classes of protein_plan.row_class (identical up to 16 k rows).
+    fixed_caps = None
     _agreed_sets = None
     grad_bf16 = False
     graph_allreduce = False
@@ -495,6 +507,8 @@ class Trainer:
         self._graphs: Dict[tuple, GraphedStep] = {}
         self._agreed_sets: Dict[str, frozenset] = {}
         self._eager_seen: Dict[tuple, int] = {}
+        self._graph_caps: Dict[tuple, tuple] = {}   # per (kind, batch signature, by-value scalars): the largest capacities asked for
+        self.graph_captures = 0                     # captures made so far (tests / bench: bounded under varying lengths)
         self.graph_warmup = 2            # eager (real) steps of a batch shape before its graph is captured
         self.graph_cache_max = max(1, int(os.environ.get("DL_GRAPH_CACHE_MAX", "6")))     # live GraphedSteps (LRU)
         self._plan_devs: Dict[tuple, object] = {}           # ProteinCNN row tables of eager steps, one set per shape
@@ -602,39 +616,52 @@ class Trainer:
         return ((not compute_ssl) or coll_ok or not self.model_has_global_ntxent()) and \
             ((not compute_cm) or coll_ok or not (cm is not None and cm.global_batch))
 
-    def protein_plan_of(self, meta, batch):
-        """The ProteinCNN distinct-row plan of a batch from the collate's `Prot_Len` records (residue counts after the
+    def protein_plan_of(self, meta, batch, must_pay: bool = True):
+        """The ProteinCNN distinct-row spec (protein_plan.PlanSpec: residue counts + the rows the compact layout needs; no
+        tables — those are built on the device) of a batch from the collate's `Prot_Len` records (residue counts after the
         reference's truncation, handler/dataset.py:36,139), or None (no records / switched off / nothing to save)."""
         if not meta or not getattr(self.model, "compact_cnn", False) or any("Prot_Len" not in m_ for m_ in meta):
             return None
         vp = batch[1]
         if not (torch.is_tensor(vp) and vp.dim() == 2 and vp.shape[0] == len(meta)):
             return None
-        from .protein_plan import plan_of
-        return plan_of([int(m_["Prot_Len"]) for m_ in meta], int(vp.shape[1]))
+        from .protein_plan import PlanSpec
+        spec = PlanSpec([m_["Prot_Len"] for m_ in meta], int(vp.shape[1]))
+        return spec if (spec.pays() or not must_pay) else None
 
-    def hints_of(self, meta, batch, own_tables: bool = False, kind: str = "cls"):
+    def hints_of(self, meta, batch, own_tables: bool = False, kind: str = "cls", caps=None):
         """BatchHints for model(..., hints=...): the drug-token block (padding_hints_of) and the ProteinCNN plan's device
         tables.  Eager steps share one table set per shape (refilled in place, stream-ordered); own_tables=True gives the
-        caller its own (a captured graph keeps pointing at them)."""
+        caller its own (a captured graph keeps pointing at them).  caps = (drug-token block, table rows or None): capacities
+        to use instead of the tightest ones for this batch (the steps around a graph capture run at the capture's sizes)."""
         from .protein_plan import BatchHints, PlanDev
-        plan = self.protein_plan_of(meta, batch)
+        if caps is None:
+            caps = self.fixed_caps
+        plan = self.protein_plan_of(meta, batch, must_pay=caps is None)
+        blk = self.padding_hints_of(meta, batch).get("drug_tokens", 0)
+        rows = 0
+        if caps is not None:
+            blk, rows = caps[0], caps[1]
+            if rows is None:
+                plan = None
         pd = None
         if plan is not None:
+            rows = rows or plan.rows()
+            key = (rows, plan.B, plan.S)
             if own_tables:
-                pd = PlanDev(plan, self.device)
+                pd = PlanDev(plan, self.device, rows=rows)
             else:
-                pd = self._plan_devs.pop(plan.key, None)
+                pd = self._plan_devs.pop(key, None)
                 if pd is None:
                     while len(self._plan_devs) >= 4:
                         del self._plan_devs[next(iter(self._plan_devs))]
-                    pd = PlanDev(plan, self.device)
+                    pd = PlanDev(plan, self.device, rows=rows)
                 else:
                     pd.fill(plan)
-                self._plan_devs[plan.key] = pd           # most recently used last
+                self._plan_devs[key] = pd           # most recently used last
         # side streams for the forward's independent branches on cls steps only (measured; BatchHints.__init__), and never
         # while gradient buckets are reduced from backward hooks (one stream for the collectives)
-        return BatchHints(self.padding_hints_of(meta, batch).get("drug_tokens", 0), pd,
+        return BatchHints(blk, pd,
                           branch_streams=(kind == "cls" and self.overlap is None),
                           raw_attention=False)       # (a training step never reads the PGCA raw-logit maps: reference trainer.py:179-231)
 
@@ -684,6 +711,7 @@ class Trainer:
             m.train()                  # (walks every submodule: 0.7 ms per call)
         compute_ssl = self.use_ssl and (cur_epoch % self.ssl_epoch_step == 0)
         compute_cm = self.use_cm and (cur_epoch >= self.cm_init_epoch)
+        eager_caps = None
         # steps with the CM head replay a graph too (round 3) except: in the epoch the head starts (the cm_weight
         # auto-scale below reads losses on the host), without id records, and in the global-batch form (object collectives)
         # Heads that see the GLOBAL batch issue collectives in their forward and backward (NT-Xent rows, CM token means and
@@ -696,17 +724,27 @@ class Trainer:
         if self.graph_steps and cm_ok and ssl_ok and not self.run_dead_backward and (not compute_ssl or ssl_masks is None):
             kind = (("ssl" if compute_ssl else "") + ("cm" if compute_cm else "")) or "cls"
             byval = (float(m.cm_model.m_sch_loss_fn.margin), float(self.cm_weight)) if compute_cm else ()
-            plan = self.protein_plan_of(meta, batch)
-            byval = (self.padding_hints_of(meta, batch).get("drug_tokens", 0), None if plan is None else plan.key) + byval
-            sig = (kind,) + GraphedStep.signature(batch) + byval
-            if sig in self._graphs or self._eager_seen.get(sig, 0) >= self.graph_warmup:
-                return self._graphed_step(batch, sig, kind, meta)
+            base = (kind,) + GraphedStep.signature(batch) + byval
+            spec = self.protein_plan_of(meta, batch)
+            blk = self.padding_hints_of(meta, batch).get("drug_tokens", 0)
+            g = self._find_graph(base, blk, spec)
+            if g is not None:
+                return self._graphed_step(g, batch, meta)
+            # No captured graph serves this batch.  Capacities of the next capture: size CLASSES (row_class: a geometric
+            # ladder; drug-token blocks of 128), never below what an earlier batch of this shape asked for — so the captures
+            # of a shape form a chain of growing capacities and batches of varying lengths converge on one or two graphs
+            # (round 4 keyed graphs by the exact 2048-row bucket: ~10 keys at batch 256, capture / eviction thrash).
+            # The eager warm-up steps of a capacity run at that capacity (same shapes as the capture).
+            eager_caps = self._capture_caps(base, blk, spec)
+            key = base + eager_caps
+            if self._eager_seen.get(key, 0) >= self.graph_warmup:
+                return self._graphed_step(self._capture(key, base, byval, batch, kind, meta, eager_caps), batch, meta)
             if len(self._eager_seen) > 256:            # bounded bookkeeping (signatures of shapes seen once and never again)
                 self._eager_seen.clear()
-            self._eager_seen[sig] = self._eager_seen.get(sig, 0) + 1
+            self._eager_seen[key] = self._eager_seen.get(key, 0) + 1
         feat_d, feat_p, labels, llm_d, llm_p = batch
         kind_now = "cm" if compute_cm else "ssl" if compute_ssl else "cls"
-        _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p, hints=self.hints_of(meta, batch, kind=kind_now))
+        _, _, ssl_input, cm_input, score = m(feat_d, feat_p, llm_d, llm_p, hints=self.hints_of(meta, batch, kind=kind_now, caps=eager_caps))
         self._zero_grad()
         _, cls_loss = binary_cross_entropy(score, labels) if self.n_class == 1 else cross_entropy_logits(score, labels)
         last = "cm" if compute_cm else "ssl" if compute_ssl else "cls"     # the backward the optimisers consume
@@ -752,22 +790,69 @@ class Trainer:
         self._post_guard()
         return out
 
-    def _graphed_step(self, batch, sig, kind: str = "cls", meta=None) -> Dict[str, float]:
-        g = self._graphs.get(sig)
-        if g is None:
-            if "cm" in kind:
-                # margin / cm_weight are by-value arguments of a capture: EVERY graph with the CM head ("cm" and "sslcm"
-                # kinds, any shape or hint) captured under other values will not be replayed again (the margin moves once
-                # per epoch) — release their pools first
-                for old in [k for k, v in self._graphs.items() if "cm" in v.kind and k[-2:] != sig[-2:]]:
-                    del self._graphs[old]
-            # Every GraphedStep owns a private pool with a whole step's activations (GBs at batch 64-128): keep at most
-            # graph_cache_max of them, least recently replayed first out (real SMILES batches vary the padding hint)
-            while len(self._graphs) >= self.graph_cache_max:
-                del self._graphs[next(iter(self._graphs))]
-            g = self._graphs[sig] = GraphedStep(self, batch, kind, meta)     # records only; the replay below is the step
-        else:
-            self._graphs[sig] = self._graphs.pop(sig)                        # most recently used last
+    # -- captured graphs: lookup by capacity, capture at size classes -------------------------------------------------------
+    _INF = 1 << 60
+
+    def _find_graph(self, base, blk: int, spec):
+        """The tightest captured graph of this (kind, batch signature, by-value scalars) whose capacities hold the batch: a
+        drug-token block >= the batch's (0 = every row computed: holds anything) and ProteinCNN tables with >= the rows the
+        batch needs (no tables = every position computed: holds anything)."""
+        best, best_cost = None, None
+        for g in self._graphs.values():
+            if g.base != base:
+                continue
+            if g.block != 0 and (blk == 0 or g.block < blk):
+                continue
+            if g.rows_cap is not None and (spec is None or spec.need > g.rows_cap):
+                continue
+            cost = (g.rows_cap if g.rows_cap is not None else self._INF, g.block or self._INF)
+            if best is None or cost < best_cost:
+                best, best_cost = g, cost
+        return best
+
+    def fixed_caps_for(self, batches) -> tuple:
+        """Capacities that hold every (batch, meta) of `batches` (for `fixed_caps`)."""
+        from .protein_plan import row_class
+        blks = [self.padding_hints_of(mt, b).get("drug_tokens", 0) for b, mt in batches]
+        specs = [self.protein_plan_of(mt, b) for b, mt in batches]
+        rows = None if any(sp is None for sp in specs) else row_class(max(sp.need for sp in specs))
+        return (0 if 0 in blks else max(blks), rows)
+
+    def _capture_caps(self, base, blk: int, spec) -> tuple:
+        from .protein_plan import row_class
+        if self.fixed_caps is not None:
+            return tuple(self.fixed_caps)
+        rows = None if spec is None else row_class(spec.need)
+        if spec is not None and not spec.pays(rows):
+            rows = None
+        old = self._graph_caps.get(base)
+        if old is not None:
+            blk = 0 if (blk == 0 or old[0] == 0) else max(blk, old[0])
+            rows = None if (rows is None or old[1] is None) else max(rows, old[1])
+        if len(self._graph_caps) > 256:
+            self._graph_caps.clear()
+        self._graph_caps[base] = (blk, rows)
+        return (blk, rows)
+
+    def _capture(self, key, base, byval, batch, kind, meta, caps) -> "GraphedStep":
+        if "cm" in kind:
+            # margin / cm_weight are by-value arguments of a capture: EVERY graph with the CM head ("cm" and "sslcm"
+            # kinds, any shape or hint) captured under other values will not be replayed again (the margin moves once
+            # per epoch) — release their pools first
+            for old in [k for k, v in self._graphs.items() if "cm" in v.kind and v.byval != byval]:
+                del self._graphs[old]
+        # Every GraphedStep owns a private pool with a whole step's activations (GBs at batch 64-128): keep at most
+        # graph_cache_max of them, least recently replayed first out
+        while len(self._graphs) >= self.graph_cache_max:
+            del self._graphs[next(iter(self._graphs))]
+        g = self._graphs[key] = GraphedStep(self, batch, kind, meta, caps)     # records only; the replay that follows is the step
+        g.base, g.byval, g.key = base, byval, key
+        self.graph_captures += 1
+        return g
+
+    def _graphed_step(self, g: "GraphedStep", batch, meta=None) -> Dict[str, float]:
+        kind = g.kind
+        self._graphs[g.key] = self._graphs.pop(g.key)                        # most recently used last
         out, idx = g.run(batch, meta)
         if self.world > 1 and not g.reduced:
             idx = self._agreed(g.last, idx)

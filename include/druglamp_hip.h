@@ -369,12 +369,13 @@ int dl_embed_pad(const int64_t* ids, const void* weight, const void* fill, void*
                  int32_t V, int32_t D, int32_t halo, int32_t dtype, dl_stream s);
 /* Device-side guard flags (sticky bits OR-ed into a caller-owned uint32 word; the trainer polls it):
  * the compact forms below are only valid for inputs with the padding structure of the reference's collate. */
-enum { DL_FLAG_PROT_PERIOD = 1, DL_FLAG_DRUG_TOKEN_PAD = 2, DL_FLAG_GCN_NODE_PAD = 4 };
+enum { DL_FLAG_PROT_PERIOD = 1, DL_FLAG_DRUG_TOKEN_PAD = 2, DL_FLAG_GCN_NODE_PAD = 4, DL_FLAG_PLAN_ROWS = 8 };
 /* ProteinCNN head on distinct rows (round 4; model/basic_model.py:168-171 over a sequence tiled by utils.py:392-412):
  * out[r][:D] = weight[ids[src[r]]], out[r][D] = fill[src[r]] for src[r] >= 0 (a flat index into ids / fill [B * L]), a zero
  * row for src[r] < 0.  weight padded to [V][D + 1] as for dl_embed_pad.  With `period` [B] given the same launch checks
  * every sample's (id, fill bit) sequence: equal at distance period[b] inside the last whole period's end E, constant on
- * [E, L) — what the row tables assume; a violation ORs DL_FLAG_PROT_PERIOD into *flags. */
+ * [E, L) — what the row tables assume; a violation ORs DL_FLAG_PROT_PERIOD into *flags.  period[b] == 0: sample b's tables
+ * keep every position (no periodic claim), nothing is checked for it. */
 int dl_embed_rows(const int64_t* ids, const void* weight, const void* fill, const int32_t* src, void* out, int64_t R,
                   int32_t V, int32_t D, const int32_t* period, int64_t B, int64_t L, uint32_t* flags, int32_t dtype, dl_stream s);
 /* out[i][:] = src[index[i]][:] (zeros where index[i] < 0), rows of row_bytes (a multiple of 16): the compact ProteinCNN
@@ -389,6 +390,17 @@ int dl_rows_sum_strided(const void* x, const int32_t* rep, void* out, int64_t R,
  * else `code` is OR-ed into *flags. */
 int dl_rows_equal_check(const void* x, int64_t B, int64_t N, int64_t row_bytes, int64_t row0, uint32_t code, uint32_t* flags,
                         dl_stream s);
+/* The row tables of the ProteinCNN distinct-row layout, built on the device from the batch's residue counts (round 5).  The
+ * reference tiles a protein of Lr residues with period P = Lr + 2 up to S positions (utils.py:392-412,
+ * repeat_integer_label_protein) and the three 'same' convolutions (model/basic_model.py:155-180) see 7 positions to the left and
+ * 8 to the right, so a sample has ~P + 31 distinct output rows; druglamp_amd/protein_plan.py states which (segments A / B / C,
+ * halo rows, multiplicities) and builds the same tables on the host — the two are compared entry by entry in the tests.
+ * lengths [B] int32 residue counts; R = row capacity of the tables (>= the rows the batch needs: rows behind them become
+ * padding rows; fewer ORs DL_FLAG_PLAN_ROWS into *flags and writes nothing for the samples that do not fit);
+ * src [R] flat input index or -1, w [R] -1 halo / 0 context / multiplicity, rep [R][3] (first, stride, count),
+ * row_of [B * S] representative row of every position, period [B] (0 for samples kept in the plain layout). */
+int dl_protein_plan_build(const int32_t* lengths, int64_t B, int64_t S, int64_t R, int32_t* src, float* w, int32_t* rep,
+                          int32_t* row_of, int32_t* period, uint32_t* flags, dl_stream s);
 /* ProteinCNN tail (model/basic_model.py:176-179 + DrugLAMP.py:39-40): the reference keeps the conv output
  * channel-first (B, C, L), REINTERPRETS that buffer with .view(B, L, C) and then site-pools it
  * (.view(B, site_len, n_site, C).mean(1)).  z is this library's channel-last conv output with `halo` zero rows

@@ -50,6 +50,7 @@ def test_graphed_steps_are_bit_identical_to_eager_steps_without_dropout():
     try:
         for graph in (False, True):
             tr = _make(0.0, graph)
+            tr.fixed_caps = tr.fixed_caps_for(seq)      # (reductions over rows associate by the table capacity: same on both sides)
             losses = [float(tr.training_step(b, meta=mt, cur_epoch=1)["cls"]) for b, mt in seq]
             tr.check_device_flags()
             if graph:
@@ -109,16 +110,17 @@ def test_cm_steps_replay_a_graph_bit_identical_to_eager_steps():
         for graph in (False, True):
             tr = _make(0.0, graph, kind="DrugLAMP2C2P")
             tr.cm_weight = 10.0
+            tr.fixed_caps = tr.fixed_caps_for(seq)
             outs = []
             for b, mt in seq:
                 o = tr.training_step(b, meta=mt, cur_epoch=6)
                 outs.append((float(o["cls"]), float(o["cm"])))
             tr.check_device_flags()
             if graph:
-                # (one graph per ProteinCNN row-table shape: the other batch's row count may fall into another bucket)
+                # (graphs are captured at capacity classes: the other batch replays the first graph when it fits its tables)
                 assert 1 <= len(tr._graphs) <= 2 and sum(g.replays for g in tr._graphs.values()) >= 1
-                for sig, g in tr._graphs.items():
-                    assert g.kind == "cm" and sig[-2:] == (tr.model.cm_model.m_sch_loss_fn.margin, 10.0)
+                for g in tr._graphs.values():
+                    assert g.kind == "cm" and g.byval == (tr.model.cm_model.m_sch_loss_fn.margin, 10.0)
             res[graph] = (outs, _state(tr) + (tr.opt_cm.exp_avg.clone(), tr.opt_cm.exp_avg_sq.clone()))
     finally:
         ops.use_seed_offset(False)
@@ -139,15 +141,15 @@ def test_cm_graphs_follow_the_margin_schedule_and_ssl_epochs():
         tr = _make(0.0, True, kind="DrugLAMP2C2P")
         for _ in range(4):
             tr.training_step(batch, meta=meta, cur_epoch=6)
-        (sig0, g0), = tr._graphs.items()
+        (g0,) = tr._graphs.values()
         assert g0.replays == 2
         tr.on_train_epoch_end(6)                               # margin schedule steps
         m1 = tr.model.cm_model.m_sch_loss_fn.margin
-        assert m1 != sig0[-2]
+        assert m1 != g0.byval[0]
         for _ in range(4):
             out = tr.training_step(batch, meta=meta, cur_epoch=7)
-        (sig1, g1), = tr._graphs.items()                       # the old graph is gone
-        assert sig1[-2] == m1 and g1.replays == 2 and g1 is not g0
+        (g1,) = tr._graphs.values()                            # the old graph is gone
+        assert g1.byval[0] == m1 and g1.replays == 2 and g1 is not g0
         for _ in range(4):
             out = tr.training_step(batch, meta=meta, cur_epoch=10)
             assert set(out) == {"cls", "ssl", "cm"} and all(torch.isfinite(v).all() for v in out.values())

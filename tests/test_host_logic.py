@@ -311,6 +311,37 @@ def test_protein_plan_covers_every_position_with_the_right_multiplicities():
     assert (b_of == np.repeat(np.arange(3), S)).all()
 
 
+def test_plan_spec_row_counts_and_capacity_classes():
+    """What the training thread computes per batch (round 5: the tables themselves are built on the device): the vectorised
+    row count equals the per-sample tables' sizes in every case of the plan, the capacity classes of captured graphs form a
+    monotone ladder that never undershoots, and the CPU form of PlanDev holds the host tables."""
+    import numpy as np
+    from druglamp_amd.protein_plan import PlanDev, PlanSpec, ProteinPlan, ROW_BUCKET, row_class, sample_rows, sample_template
+    for S in (2304, 300, 64):
+        Ls = list(range(1, S + 40))
+        assert [sample_template(L, S)[0].shape[0] for L in Ls] == sample_rows(Ls, S).tolist()
+    prev = 0
+    for need in range(1, 400 * ROW_BUCKET, 997):
+        c = row_class(need)
+        assert c >= need and c % ROW_BUCKET == 0 and c >= prev and c <= max(1.26 * need + ROW_BUCKET, 2 * ROW_BUCKET)
+        prev = c
+    assert len({row_class(n) for n in range(150_000, 183_000, 500)}) <= 2         # batch 256: the lengths' spread is one or two classes
+    rs = np.random.RandomState(0)
+    lengths = rs.randint(100, 1023, 16)
+    spec = PlanSpec(lengths, 2304)
+    host = ProteinPlan(lengths, 2304, bucket=1)
+    assert spec.need == host.rows and spec.pays() and not PlanSpec([1500, 1400], 2304).pays()
+    pd = PlanDev(spec, "cpu", rows=row_class(spec.need))
+    R = host.rows
+    assert np.array_equal(pd.src.numpy()[:R], host.src) and (pd.src.numpy()[R:] == -1).all() and (pd.w.numpy()[R:] == -1).all()
+    assert np.array_equal(pd.rep.numpy()[:R], host.rep) and np.array_equal(pd.row_of.numpy(), host.row_of)
+    assert np.array_equal(pd.period.numpy(), host.period)
+    # a protein whose period exceeds the sequence (reps = 0) keeps the plain layout and makes no periodic claim (ADVICE r4)
+    assert ProteinPlan([98, 400], 300, bucket=1).period.tolist() == [100, 0]
+    with pytest.raises(ValueError):
+        pd.fill(PlanSpec(rs.randint(900, 1023, 16) * 0 + 1022, 2304))              # needs more rows than the tables hold
+
+
 def test_ops_reject_cpu_tensors():
     from druglamp_amd import ops
     x = torch.randn(8, 8)

@@ -202,6 +202,61 @@ def test_whole_model_with_the_plan_against_the_reference_goldens(kind):
     ops.check_guard_flags(DEV)
 
 
+@pytest.mark.parametrize("S", [2304, 9216, 300])
+def test_device_built_row_tables_equal_the_host_tables(S):
+    """dl_protein_plan_build (round 5: the tables come from B residue counts on the device) against protein_plan.ProteinPlan,
+    entry by entry: every case of the plan (three segments, merged tail, plain layout, period beyond the sequence), bucket
+    padding rows, refills with other lengths, and the capacity guard."""
+    from druglamp_amd import ops
+    from druglamp_amd.protein_plan import PlanDev, PlanSpec, ProteinPlan, row_class
+    rs = np.random.RandomState(S)
+    hi = min(S + 30, 4200)
+    sets = [rs.randint(1, hi, 37) for _ in range(3)] + [np.arange(1, 38) * (hi // 38)]
+    sets.append(np.array([S // 2 - 2, S // 2 - 1, S // 2, S // 3 - 2, S // 3 - 1, S - 2, S - 1, S, S + 5] + [97] * 28))
+    cap = row_class(max(PlanSpec(x, S).need for x in sets))
+    pd = None
+    for lengths in sets:
+        spec = PlanSpec(lengths, S)
+        pd = PlanDev(spec, DEV, rows=cap) if pd is None else pd.fill(spec)
+        host = ProteinPlan(lengths, S, bucket=1)
+        R = host.rows
+        assert R == spec.need
+        torch.cuda.synchronize()
+        assert np.array_equal(pd.src.cpu().numpy()[:R], host.src) and bool((pd.src[R:] == -1).all())
+        assert np.array_equal(pd.w.cpu().numpy()[:R], host.w) and bool((pd.w[R:] == -1).all())
+        rep = pd.rep.cpu().numpy()
+        assert np.array_equal(rep[:R], host.rep) and (rep[R:] == np.array([0, 1, 0])).all()
+        assert np.array_equal(pd.row_of.cpu().numpy(), host.row_of)
+        assert np.array_equal(pd.period.cpu().numpy(), host.period)
+    ops.check_guard_flags(DEV)
+    # capacity guard: the kernel is handed fewer rows than the lengths need (the Python layer refuses that earlier)
+    small = PlanDev(PlanSpec([1] * 37, S), DEV, rows=2048)
+    small.len_dev.copy_(torch.from_numpy(np.full(37, S // 2 - 2, np.int32)).to(DEV))
+    ops.protein_plan_build(small)
+    with pytest.raises(RuntimeError, match="fewer rows"):
+        ops.check_guard_flags(DEV)
+
+
+def test_a_protein_longer_than_the_sequence_period_does_not_trip_the_guard():
+    """a sample whose period exceeds the sequence (reps = 0: the reference's all-zero encoding) keeps every position
+    and makes no periodic claim; a batch with one such protein is correct and must not raise."""
+    from druglamp_amd import ops
+    from druglamp_amd.model.basic_model import ProteinCNN
+    from druglamp_amd.protein_plan import PlanDev, PlanSpec
+    S, lengths = 300, [60, 400, 31, 298]
+    ids, fill = _tiled(4, S, [60, 1, 31, 1])
+    ids[1], ids[3] = 0, 0                                             # quot == 0: the reference encodes nothing (utils.py:392-412)
+    fill[1], fill[3] = 1.0, 1.0
+    torch.manual_seed(3)
+    full = ProteinCNN(128, [128] * 3, [3, 6, 9]).to(DEV).eval()
+    pd = PlanDev(PlanSpec(lengths, S), DEV)
+    with torch.no_grad():
+        a = full(ids, fill, plan=pd)
+        b = full(ids, fill)
+    ops.check_guard_flags(DEV)
+    assert relerr(a, b) <= 2e-5
+
+
 def test_periodicity_guard_rejects_a_batch_that_is_not_tiled():
     """the tables assume the collate's tiling; a batch without it must be an ERROR with the checks
     at their defaults, not silently wrong activations."""
@@ -253,6 +308,26 @@ def _trainer(graph, compact, dt=torch.float32, B=8):
     return tr
 
 
+def test_varying_lengths_converge_on_few_captured_graphs():
+    """real batches vary in protein lengths and token counts; round 4 keyed captured graphs by the exact 2048-row
+    bucket and the 128-token block (capture / eviction thrash beyond six keys).  Captures are made at capacity classes and a
+    graph serves every batch that fits it: many distinct batches end up on one or two graphs, almost every step a replay,
+    and the replayed steps train like eager ones (same loss trajectory within bf16 summation noise)."""
+    from druglamp_amd.synthetic import make_batch
+    batches = [make_batch(8, DEV, seed=300 + s, with_graph=True, llm_dtype=torch.bfloat16) for s in range(10)]
+    losses = {}
+    for graph in (False, True):
+        tr = _trainer(graph, True, dt=torch.bfloat16)
+        losses[graph] = [float(tr.training_step(*batches[i % 10][:1], meta=batches[i % 10][1], cur_epoch=1)["cls"]) for i in range(40)]
+        tr.check_device_flags()
+        if graph:
+            replays = sum(g.replays for g in tr._graphs.values())
+            assert tr.graph_captures <= 3 and len(tr._graphs) <= 3, (tr.graph_captures, len(tr._graphs))
+            assert replays >= 40 - 2 * tr.graph_warmup * 3 - 4, replays
+    a, b = np.array(losses[False]), np.array(losses[True])
+    assert np.abs(a - b).max() <= 2e-2, (a, b)
+
+
 def test_training_steps_with_and_without_the_plan_and_as_graph_replays():
     """Four cls steps + an SSL-epoch step on two alternating batches (different protein lengths): (a) eager with the plan
     against eager without it — same parameters up to fp32 summation order; (b) graph replays with the plan against eager
@@ -262,6 +337,8 @@ def test_training_steps_with_and_without_the_plan_and_as_graph_replays():
     arenas = {}
     for name, graph, compact in (("full", False, False), ("plan", False, True), ("graph", True, True)):
         tr = _trainer(graph, compact)
+        if compact:
+            tr.fixed_caps = tr.fixed_caps_for(batches)     # (graph == eager bit for bit needs equal table capacities)
         for step in range(6):
             batch, meta = batches[step % 2]
             tr.training_step(batch, meta=meta, cur_epoch=5 if step == 4 else 1)
