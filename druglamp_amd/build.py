@@ -66,6 +66,8 @@ def _compile(src, force, objdir=OBJDIR, extra=()):
     if force or _stale(obj, [path] + _headers() + [os.path.abspath(__file__)]):
         keep = os.environ.get("DL_BUILD_NOSLP_FILES")           # (A/B builds, tools: comma-separated files that get their FILE_FLAGS)
         ff = FILE_FLAGS.get(src, []) if (keep is None or src in keep.split(",")) else []
+        if src in os.environ.get("DL_BUILD_NOSLP_EXTRA", "").split(","):   # (A/B builds: further files without the SLP vectoriser)
+            ff = ff + ["-fno-slp-vectorize"]
         cmd = [HIPCC] + FLAGS + ff + list(extra) + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -64,12 +64,20 @@ def all_gather_meta(meta: List[dict]) -> List[dict]:
 
 
 def id_code(v) -> int:
-    """A stable 63-bit integer for an entity id (ints map to themselves; strings through blake2b — equal ids give equal
-    codes on every rank and in every process, unlike Python's salted hash())."""
-    if isinstance(v, (int,)) and not isinstance(v, bool) and 0 <= int(v) < (1 << 62):
-        return int(v)
+    """A stable 63-bit integer for an entity id (integers of ANY integral type — int, numpy.int64, pandas scalars — map to
+    themselves, so `5` on one rank and `np.int64(5)` on another are one entity, as they are for the reference's dict keys:
+    hash(np.int64(5)) == hash(5); everything else through blake2b of str(v) — equal ids give equal codes on every rank and
+    in every process, unlike Python's salted hash(), and independent of the numpy version's repr)."""
+    import numbers
+    import operator
+    if isinstance(v, numbers.Integral) and not isinstance(v, bool):
+        v = operator.index(v)
+        if 0 <= v < (1 << 62):
+            return v
+    elif isinstance(v, numbers.Real) and not isinstance(v, bool) and float(v) == int(v) and 0 <= int(v) < (1 << 62):
+        return int(v)                       # (1.0 == 1 as a dict key too)
     import hashlib
-    h = hashlib.blake2b(repr(v).encode() if not isinstance(v, str) else v.encode(), digest_size=8).digest()
+    h = hashlib.blake2b((v if isinstance(v, str) else str(v)).encode(), digest_size=8).digest()
     return (int.from_bytes(h, "little") & ((1 << 62) - 1)) | (1 << 62)       # disjoint from the small-int range
 
 

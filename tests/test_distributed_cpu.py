@@ -70,7 +70,9 @@ def _gather_worker(rank, world, port, q):
     # round 4: the global-batch CM head gathers INTEGER id codes as one tensor collective and builds the label matrix of the
     # gathered batch on the device — equal to the host label matrix of the concatenated records on every rank
     from druglamp_amd.model.cross_modality import DeviceLabels, label_matrix
-    allmeta = [{"Prot_ID": "p%d" % (i % 3), "Drug_ID": (i * 5) % 4, "Y": float(i % 2)} for i in range(8)]
+    # (mixed id types, ADVICE r4: rank 0 holds drug ids as Python ints, rank 1 the same ids as numpy.int64 — one entity each)
+    import numpy as np
+    allmeta = [{"Prot_ID": "p%d" % (i % 3), "Drug_ID": (i * 5) % 4 if i < 4 else np.int64((i * 5) % 4), "Y": float(i % 2)} for i in range(8)]
     mine = allmeta[rank * 4:(rank + 1) * 4]
     codes = dist_ops.all_gather_codes(torch.from_numpy(dist_ops.id_codes(mine)))
     ok &= tuple(codes.shape) == (8, 3)

@@ -373,6 +373,44 @@ def test_gcn_compact_padding_equals_the_512_row_computation(dt, tol):
 
 
 @pytest.mark.gpu
+def test_gcn_full_and_compact_forms_against_the_fp64_oracle():
+    """ADVICE r4 (bn.hip built without the SLP vectoriser failed the compact-vs-full comparison above although every dl_bn_*
+    call agreed between the builds): the two forms are compared here with the TRUTH — the oracle's MolecularGCN in fp64 on the
+    same weights and graphs — instead of with each other.  Most of a molecule's 512 nodes are identical virtual padding
+    nodes, so a BatchNorm column is a constant plus a few real atoms and its backward subtracts the batch mean and the
+    y-hat projection from a gradient that largely consists of them: fp32 rounding of the statistics is amplified, in BOTH
+    forms.  Each form must be within the bound of the fp64 result; their mutual distance is bounded by the sum."""
+    import copy
+    from druglamp_amd.model.basic_model import MolecularGCN
+    from druglamp_amd.synthetic import make_batch
+    from oracle import druglamp_oracle as O
+    torch.manual_seed(1)
+    ref = MolecularGCN(75, 128, True, [128] * 3).to(DEV).train()
+    ref.compute_dtype = torch.float32
+    cmp_ = copy.deepcopy(ref)
+    ref.compact_padding, cmp_.compact_padding = False, True
+    cmp_.compact_min_rows = 0
+    (feat_d, *_), _ = make_batch(6, DEV, seed=9, with_graph=True)
+    h, adj = feat_d
+    cot = torch.randn(6, 512, 128, device=DEV)
+    sd = {"g." + k: v.detach().double().cpu().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+          for k, v in ref.state_dict().items() if v.dtype.is_floating_point}
+    truth = O.molecular_gcn(sd, "g", h.double().cpu(), adj.double().cpu(), True)
+    (truth * cot.double().cpu()).sum().backward()
+    errs = {}
+    for name, m in (("full", ref), ("compact", cmp_)):
+        o = m((h, adj))
+        (o.float() * cot).sum().backward()
+        errs[name] = {"out": relerr(o.double().cpu(), truth.detach())}
+        for n, p_ in m.named_parameters():
+            errs[name][n] = relerr(p_.grad.double().cpu(), sd["g." + n].grad)
+    worst = {k: max(v.values()) for k, v in errs.items()}
+    print("MolecularGCN fp32 forms against fp64: worst relative errors", worst, {k: max(v, key=v.get) for k, v in errs.items()})
+    assert errs["full"]["out"] <= 2e-5 and errs["compact"]["out"] <= 2e-5
+    assert worst["full"] <= 2e-3 and worst["compact"] <= 2e-3, errs
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
 def test_drug_llm_adaptor_compact_padding_equals_the_full_computation(dt, tol):
     """Round 3: with the collate's `drug_tokens` hint the drug LLM adaptor (Linear + GELU, LayerNorm, Linear: all row-wise)

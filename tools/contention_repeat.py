@@ -81,13 +81,16 @@ def rows_pool(B):
     _, meta = synthetic.make_batch(B, "cpu", seed=0, with_graph=False)
     plan = plan_of([m["Prot_Len"] for m in meta], 2304)
     pd = PlanDev(plan, dev); pd.fill(plan)
-    z = torch.randn(plan.rows, 128, device=dev).to(dt); g = torch.randn(B, 256, 128, device=dev).to(dt)
+    z = torch.randn(pd.rows, 128, device=dev).to(dt); g = torch.randn(B, 256, 128, device=dev).to(dt)
     x32 = torch.randn(4096, 640, device=dev)
-    return lambda: (ops.cnn_sitepool_rows_fwd(z, pd.row_of, B, 2304, 9), ops.cnn_sitepool_rows_bwd(g, pd.rep, pd.row_of, 2304, 9),
-                    ops.rows_gather(z, pd.row_of), ops.cast(x32, dt))
+    def run():
+        ops.protein_plan_build(pd)                       # (round 5: the row tables themselves are built on the device)
+        return (pd.buf.clone(), ops.cnn_sitepool_rows_fwd(z, pd.row_of, B, 2304, 9), ops.cnn_sitepool_rows_bwd(g, pd.rep, pd.row_of, 2304, 9),
+                ops.rows_gather(z, pd.row_of), ops.cast(x32, dt))
+    return run
 cases = {"BatchNorm stats+finalize / apply / bwd reduce / bwd apply 300000x128 (wide kernels)": bn(300000, 128, False),
          "BatchNorm with row weights 165888x128": bn(165888, 128, True), "BatchNorm 70000x96 (generic kernels)": bn(70000, 96, False),
-         "site pooling through the row map fwd / bwd, rows_gather, cast": rows_pool(128),
+         "row tables built on the device, site pooling through the row map fwd / bwd, rows_gather, cast": rows_pool(128),
          "attention backward one-pass, paired 384 x 4 x 256^2 (LDS-DMA ring, counted waits)": attn_bwd(384, 4, 2, 256, 3),
          "attention backward one-pass, one segment 300 x 4 x 200^2": attn_bwd(300, 4, 1, 200, 3),
          "tt 2048x512x65536": tt(2048, 512, 65536), "tt 1024x256x65536": tt(1024, 256, 65536), "tt 128x768x591867": tt(128, 768, 591867),

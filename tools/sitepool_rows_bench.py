@@ -33,7 +33,7 @@ def main():
     plan = plan_of([m["Prot_Len"] for m in meta], L)
     pd = PlanDev(plan, dev)
     pd.fill(plan)
-    z = torch.randn(plan.rows, C, device=dev).bfloat16()
+    z = torch.randn(pd.rows, C, device=dev).bfloat16()
     g = torch.randn(B, L // S, C, device=dev).bfloat16()
     fwd_rows = lambda: ops.cnn_sitepool_rows_fwd(z, pd.row_of, B, L, S)
     bwd_rows = lambda: ops.cnn_sitepool_rows_bwd(g, pd.rep, pd.row_of, L, S)
@@ -43,7 +43,7 @@ def main():
     assert torch.equal(a, b_), "forward differs"
     da, db = bwd_rows(), bwd_exp()
     err = (da.float() - db.float()).abs().max().item()
-    print("rows %d of %d positions; bwd max |diff| vs expand form %.3g (bf16 rounding of the dense intermediate)" % (plan.rows, B * L, err))
+    print("rows %d of %d positions; bwd max |diff| vs expand form %.3g (bf16 rounding of the dense intermediate)" % (pd.rows, B * L, err))
     for name, f in (("fwd through map", fwd_rows), ("fwd expand+pool", fwd_exp), ("bwd through map", bwd_rows), ("bwd pool+sum", bwd_exp)):
         print("%-18s %8.1f us" % (name, timed(f)))
 
