@@ -79,6 +79,7 @@ class AttnFwdArgs(C.Structure):
         ("Lq", c_i32), ("Lk", c_i32), ("head_dim", c_i32), ("dtype", c_i32),
         ("scale", c_f32),
         ("algo", c_i32),
+        ("key_tail_rows", c_i32), ("key_tail_weight", c_f32),
     ]
 
 
@@ -99,6 +100,7 @@ class AttnBwdArgs(C.Structure):
         ("Lq", c_i32), ("Lk", c_i32), ("head_dim", c_i32), ("dtype", c_i32),
         ("scale", c_f32),
         ("algo", c_i32),
+        ("key_tail_rows", c_i32), ("key_tail_weight", c_f32),
     ]
 
 

@@ -31,7 +31,26 @@ struct AttnP {
   int P, H, S, shift, Lq, Lk;
   float scale;
   int algo;
+  // key multiplicities (round 5): the keys [tail_start, Lk) each stand for w identical keys of the full attention — their
+  // scores get log(w) added (tail_bias = log(w) / scale, added to the UNSCALED score so that everything downstream — the
+  // running maximum, exp2(s * c - m * c), LSE = m * scale + log(l), the backward's exp2(s * c - lse2) — stays as it is).
+  // tail_start == Lk: no such keys.  Tiles in front of tail_start skip the addition through a wave-uniform branch.
+  int tail_start;
+  float tail_bias;
 };
+
+// scores of a 64-key tile in the transposed layout (lane (il, g) holds keys kt * 16 + 4 g + r of query il)
+template <int QT, int NKT>
+__device__ __forceinline__ void add_tail_bias_t(f32x4 (&s)[QT][NKT], int k0, int g, int tail_start, float tb) {
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (k0 + kt * 16 + 4 * g + r >= tail_start) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[qt][kt][r] += tb;
+      }
+}
 
 __device__ __attribute__((aligned(16))) const uint32_t attn_zero_page[4] = {0u, 0u, 0u, 0u};
 
@@ -131,6 +150,7 @@ __global__ __launch_bounds__(ATT_THREADS, OCC) void attn_fwd_kernel(const AttnP 
         for (int qt = 0; qt < QT; ++qt) s[qt][kt] = Mma<T>::mma(ka, qf[qt][kf], s[qt][kt]);
       }
     }
+    if (k0 + KVB > p.tail_start) add_tail_bias_t<QT, NKT>(s, k0, g, p.tail_start, p.tail_bias);
     // ---- optional raw logits (segment 0 only) + key masking ----
     const bool tail = (k0 + KVB > p.Lk);
     if (p.raw && seg == 0) {
@@ -519,6 +539,7 @@ __global__ __launch_bounds__(ATT_THREADS, (HD == 64 ? 2 : 1)) void attn_bwd_dq_k
           }
         }
       }
+      if constexpr (!RES) { if (k0 + KVB > p.tail_start) add_tail_bias_t<QT, NKT>(s, k0, g, p.tail_start, p.tail_bias); }
       // dS^T = P^T o (dP^T - delta) ; keys beyond Lk give zero K rows, so they add nothing to dQ
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt)
@@ -570,7 +591,7 @@ __device__ __forceinline__ void att_dma16(const char* gsrc, uint32_t lds_off) {
 __device__ __forceinline__ void att_wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void att_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <typename T, int HD, int QT>
+template <typename T, int HD, int QT, bool TAILK = false>      // TAILK: key multiplicities (its own instantiation: the plain form keeps its registers)
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_ring_kernel(const AttnP p) {
   using TL = ATile<T, HD>;
   constexpr int KF = Mma<T>::KF, NKF = HD / KF, NDT = HD / 16, CT = KF / 16;
@@ -665,6 +686,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_ring_kernel(const 
             }
           }
         }
+        if constexpr (TAILK) {
+          if (t * KVB + (kp + 1) * KF > p.tail_start) add_tail_bias_t<QT, CT>(s, t * KVB + kp * KF, g, p.tail_start, p.tail_bias);
+        }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
@@ -738,6 +762,11 @@ __global__ __launch_bounds__(ATT_THREADS, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_
   for (int d = 0; d < NDT; ++d)
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) { dk[d][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // key multiplicities: this lane's keys (key = kw0 + kt * 16 + il); the whole wave skips the addition in front of tail_start
+  const bool has_tail = !RES && kw0 + KT * 16 > p.tail_start;
+  float kbl[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) kbl[kt] = (kw0 + kt * 16 + il >= p.tail_start) ? p.tail_bias : 0.f;
 
   Stager<T, HD, QSB> sq, sdo;
   const int nqb = (p.Lq + QSB - 1) / QSB;
@@ -798,6 +827,10 @@ __global__ __launch_bounds__(ATT_THREADS, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_
         }
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_t + qt * 16 + 4 * g);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_t + qt * 16 + 4 * g);
+        if (has_tail) {
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt) s[kt][qt] += kbl[kt];
+        }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -848,7 +881,7 @@ __global__ __launch_bounds__(ATT_THREADS, (HD == 64 ? 2 : 1)) void attn_bwd_dkv_
 // =================================== backward: dK, dV, LDS-DMA ring ============================
 // Same idea as attn_bwd_dq_ring_kernel for the key side: the 64-row Q / dO blocks arrive by LDS-DMA into a two-stage ring
 // (their LSE / Delta rows through registers one block ahead), and the scores of a block are formed in two 32-row halves.
-template <typename T, int HD, int KT>
+template <typename T, int HD, int KT, bool TAILK = false>
 __global__ __launch_bounds__(ATT_THREADS, 1) void attn_bwd_dkv_ring_kernel(const AttnP p) {
   using TL = ATile<T, HD>;
   constexpr int KF = Mma<T>::KF, NKF = HD / KF, NDT = HD / 16, CT = KF / 16;
@@ -883,6 +916,11 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void attn_bwd_dkv_ring_kernel(const
   for (int d = 0; d < NDT; ++d)
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) { dk[d][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // key multiplicities: this lane's keys (key = kw0 + kt * 16 + il); the whole wave skips the addition in front of tail_start
+  const bool has_tail = TAILK && kw0 + KT * 16 > p.tail_start;
+  float kbl[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) kbl[kt] = (TAILK && kw0 + kt * 16 + il >= p.tail_start) ? p.tail_bias : 0.f;
 
   const int nqb = (p.Lq + QSB - 1) / QSB;
   for (int seg = 0; seg < p.S; ++seg) {
@@ -941,6 +979,10 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void attn_bwd_dkv_ring_kernel(const
           }
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_t + qt * 16 + 4 * g);
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_t + qt * 16 + 4 * g);
+          if (has_tail) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) s[kt][ci] += kbl[kt];
+          }
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -1284,7 +1326,7 @@ int launch_fwd(const AttnP& p, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     // K/V-resident form for short key sequences (algo = DL_ATTN_ALGO_STREAM keeps a call on the streaming form)
     // (measured: at head_dim 128 the 128 KB image leaves one workgroup per CU and ties with the streaming form)
-    if (HD == 64 && p.Lk <= 256 && p.algo != DL_ATTN_ALGO_STREAM) {
+    if (HD == 64 && p.Lk <= 256 && p.algo != DL_ATTN_ALGO_STREAM && p.tail_start >= p.Lk) {
       constexpr int NW = HD == 64 ? 4 : 8;            // 64 KB -> two workgroups per CU; 128 KB -> one of 8 waves
       hipLaunchKernelGGL((attn_fwd_res_kernel<T, HD, 2, NW>), dim3((uint32_t)p.H, (uint32_t)p.P), dim3(64 * NW), 0, s, p);
       return DL_OK;
@@ -1322,13 +1364,13 @@ int launch_bwd(const AttnP& p, hipStream_t s) {
     // per CU: taken when there is at least one workgroup for every CU (measured, paired, Lq = Lk = 256: 256 pairs 361 vs 408 us,
     // 64 pairs 84 vs 108, 32 pairs — half the CUs idle for four serial passes — 73 vs 56), or when asked for
     const int64_t nwg = (int64_t)p.H * (p.S == 2 ? p.shift : p.P);
-    if (p.Lk <= 256 && (p.S == 1 || 2 * p.shift == p.P) &&
+    if (p.Lk <= 256 && (p.S == 1 || 2 * p.shift == p.P) && p.tail_start >= p.Lk &&
         (p.algo == DL_ATTN_ALGO_ONE_PASS || (p.algo == DL_ATTN_ALGO_AUTO && nwg >= 256))) {
       const dim3 gf(1u, (uint32_t)p.H, (uint32_t)(p.S == 2 ? p.shift : p.P));
       hipLaunchKernelGGL((attn_bwd_fused_kernel<T, HD>), gf, dim3(512), 0, s, p);
       return DL_OK;
     }
-    if (p.Lk <= 256 && p.Lq <= 256 && p.algo != DL_ATTN_ALGO_STREAM) {
+    if (p.Lk <= 256 && p.Lq <= 256 && p.algo != DL_ATTN_ALGO_STREAM && p.tail_start >= p.Lk) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, QT, true>), gq, dim3(ATT_THREADS), 0, s, p);
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD, KT, true>), gk, dim3(ATT_THREADS), 0, s, p);
       return DL_OK;
@@ -1339,6 +1381,11 @@ int launch_bwd(const AttnP& p, hipStream_t s) {
     hipLaunchKernelGGL((attn_delta_kernel<T, HD>), dim3((uint32_t)((rows + 15) / 16)), dim3(256), 0, s, p);
   }
   if constexpr (sizeof(T) == 2 && HD == 128) {
+    if (p.tail_start < p.Lk) {              // key multiplicities (PGCA on the distinct drug rows)
+      hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<T, HD, QT, true>), gq, dim3(ATT_THREADS), 0, s, p);
+      hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<T, HD, KT, true>), gk, dim3(ATT_THREADS), 0, s, p);
+      return DL_OK;
+    }
     if (dl_study_env("DL_ATTN_BWD_RING", 3) & 1) hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<T, HD, QT>), gq, dim3(ATT_THREADS), 0, s, p);
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD, QT, false>), gq, dim3(ATT_THREADS), 0, s, p);
     if (dl_study_env("DL_ATTN_BWD_RING", 3) & 2) hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<T, HD, KT>), gk, dim3(ATT_THREADS), 0, s, p);
@@ -1370,6 +1417,11 @@ extern "C" int dl_attn_fwd(const dl_attn_fwd_args* a, dl_stream stream) {
   p.o_ss = a->o_ss;
   p.P = a->n_problems; p.H = a->n_heads; p.S = a->n_segments; p.shift = a->partner_shift;
   p.Lq = a->Lq; p.Lk = a->Lk; p.scale = a->scale; p.algo = a->algo;
+  DL_CHECK_ARG(a->key_tail_rows >= 0 && a->key_tail_rows <= a->Lk && (a->key_tail_rows == 0 || (a->key_tail_weight >= 1.f && a->scale > 0.f)),
+               DL_ERR_ARG, "dl_attn_fwd: key_tail_rows in [0, Lk], key_tail_weight >= 1");
+  DL_CHECK_ARG(a->key_tail_rows == 0 || a->n_segments == 1, DL_ERR_UNSUPPORTED, "dl_attn_fwd: key multiplicities with one segment only");
+  p.tail_start = a->Lk - a->key_tail_rows;
+  p.tail_bias = a->key_tail_rows ? logf(a->key_tail_weight) / a->scale : 0.f;
   dl_prof_before(1, s);
   if (a->dtype == DL_BF16) rc = a->head_dim == 64 ? launch_fwd<bf16_t, 64>(p, s) : launch_fwd<bf16_t, 128>(p, s);
   else rc = a->head_dim == 64 ? launch_fwd<float, 64>(p, s) : launch_fwd<float, 128>(p, s);
@@ -1405,6 +1457,11 @@ extern "C" int dl_attn_bwd(const dl_attn_bwd_args* a, dl_stream stream) {
   p.dk_rs = a->dk_rs; p.dv_ps = a->dv_ps; p.dv_hs = a->dv_hs; p.dv_rs = a->dv_rs;
   p.P = a->n_problems; p.H = a->n_heads; p.S = a->n_segments; p.shift = a->partner_shift;
   p.Lq = a->Lq; p.Lk = a->Lk; p.scale = a->scale; p.algo = a->algo;
+  DL_CHECK_ARG(a->key_tail_rows >= 0 && a->key_tail_rows <= a->Lk && (a->key_tail_rows == 0 || (a->key_tail_weight >= 1.f && a->scale > 0.f)),
+               DL_ERR_ARG, "dl_attn_bwd: key_tail_rows in [0, Lk], key_tail_weight >= 1");
+  DL_CHECK_ARG(a->key_tail_rows == 0 || a->n_segments == 1, DL_ERR_UNSUPPORTED, "dl_attn_bwd: key multiplicities with one segment only");
+  p.tail_start = a->Lk - a->key_tail_rows;
+  p.tail_bias = a->key_tail_rows ? logf(a->key_tail_weight) / a->scale : 0.f;
   dl_prof_before(2, s);
   if (a->dtype == DL_BF16) rc = a->head_dim == 64 ? launch_bwd<bf16_t, 64>(p, s) : launch_bwd<bf16_t, 128>(p, s);
   else rc = a->head_dim == 64 ? launch_bwd<float, 64>(p, s) : launch_bwd<float, 128>(p, s);

@@ -484,10 +484,18 @@ def layer_norm(x, weight, bias, eps):
 # ------------------------------------------------------------------------------------------------
 class GuidedCrossAttentionFn(torch.autograd.Function):
     """query (Lq, B, E), key == value (Lk, B, E), seq-first as the reference passes them.
-    Returns (out (Lq, B, E), raw logits (B, H, Lq, Lk) fp32 or None)."""
+    Returns (out (Lq, B, E), raw logits (B, H, Lq, Lk) fp32 or None).
+    key_tail = (rows, weight) (round 5): `key` holds only the DISTINCT key rows of the reference's 512 — the batch's block of
+    real nodes / tokens followed by `rows` rows that each stand for `weight` identical padding rows (MolecularGCN's and the
+    drug LLM adaptor's compact forms hand them over before their expansion).  The attention adds log(weight) to those keys'
+    logits (dl_attn_fwd_args.key_tail_rows): the same softmax, output and query gradient as over all 512 rows; the key
+    gradient of a tail row is the sum over the rows it stands for — what the expansion's backward would have formed — and
+    the in-projection, its data gradient and weight gradient run over Lk = block + rows rows instead of 512.  The weight
+    gradient of the in-projection needs the multiplicity once more: d(in_w) sums over ALL 512 rows' (dkv_row x key_row)
+    products, and a tail row's dkv is already the sum over its copies, so its product counts once — no extra factor."""
 
     @staticmethod
-    def forward(ctx, query, key, in_w, in_b, out_w, out_b, H, need_raw):
+    def forward(ctx, query, key, in_w, in_b, out_w, out_b, H, need_raw, key_tail=None):
         Lq, B, E = query.shape
         Lk = key.shape[0]
         cdt = query.dtype
@@ -506,11 +514,14 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
         scale = float(hd) ** -0.5
         lse = ops.attn_fwd(qp, kv, kv[:, E:], n_problems=B, n_heads=H, n_segments=1, partner_shift=0, Lq=Lq, Lk=Lk,
                            head_dim=hd, scale=scale, q_strides=(Lq * E, hd, E), k_strides=(Lk * 2 * E, hd, 2 * E),
-                           v_strides=(Lk * 2 * E, hd, 2 * E), out=o, o_strides=(Lq * E, hd, E), o_ss=0, raw_logits=raw)
+                           v_strides=(Lk * 2 * E, hd, 2 * E), out=o, o_strides=(Lq * E, hd, E), o_ss=0, raw_logits=raw,
+                           key_tail=key_tail)
         ow = lowp((out_w,), cdt)
         y = ops.gemm(o, ow, M=B * Lq, N=E, K=E, bias=_f32(out_b))
         ctx.save_for_backward(q2, k2, w, qp, kv, o, lse, ow)
-        ctx.cfg = (Lq, Lk, B, E, H, scale, in_b is not None, out_b is not None)
+        if key_tail is not None and need_raw:
+            raise ValueError("GuidedCrossAttentionFn: the raw logits are those of all key rows; not available with key_tail")
+        ctx.cfg = (Lq, Lk, B, E, H, scale, in_b is not None, out_b is not None, key_tail)
         ctx.mark_non_differentiable(*([raw] if raw is not None else []))
         ctx.set_materialize_grads(False)       # no zero-filled gradients for the non-differentiable outputs
         return y.view(B, Lq, E).transpose(0, 1), raw
@@ -519,7 +530,7 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
     @_deferring
     def backward(ctx, dy, _draw):
         q2, k2, w, qp, kv, o, lse, ow = ctx.saved_tensors
-        Lq, Lk, B, E, H, scale, has_inb, has_outb = ctx.cfg
+        Lq, Lk, B, E, H, scale, has_inb, has_outb, key_tail = ctx.cfg
         hd = E // H
         g = dy.transpose(0, 1).contiguous().view(B * Lq, E)
         dwo, dbo = _wgrad(g, o, E, E, Lq * B, E, E, want_bias=has_outb)
@@ -530,7 +541,7 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
                      Lk=Lk, head_dim=hd, scale=scale, q_strides=(Lq * E, hd, E), k_strides=(Lk * 2 * E, hd, 2 * E),
                      v_strides=(Lk * 2 * E, hd, 2 * E), o_strides=(Lq * E, hd, E), o_ss=0, do_strides=(Lq * E, hd, E),
                      do_ss=0, dq=dqp, dq_strides=(Lq * E, hd, E), dk=dkv, dk_strides=(Lk * 2 * E, hd, 2 * E),
-                     dv=dkv[:, E:], dv_strides=(Lk * 2 * E, hd, 2 * E))
+                     dv=dkv[:, E:], dv_strides=(Lk * 2 * E, hd, 2 * E), key_tail=key_tail)
         # in_proj gradient = [dWq ; dWkv] (guided_cross_attention_model.py:146-161): both products write their rows of it
         din_w = torch.empty((3 * E, E), dtype=torch.float32, device=g.device)
         din_b = torch.empty(3 * E, dtype=torch.float32, device=g.device) if has_inb else None
@@ -538,7 +549,7 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
         _wgrad(dkv, k2, 2 * E, E, Lk * B, 2 * E, E, want_bias=has_inb, out_w=din_w[E:], out_b=None if din_b is None else din_b[E:])
         dquery = ops.gemm(dqp, w[:E], M=Lq * B, N=E, K=E, w_kslow=True, ldw=E).view(B, Lq, E).transpose(0, 1)
         dkey = ops.gemm(dkv, w[E:], M=Lk * B, N=E, K=2 * E, w_kslow=True, ldw=E).view(B, Lk, E).transpose(0, 1)
-        return dquery, dkey, din_w, din_b, dwo, dbo, None, None
+        return dquery, dkey, din_w, din_b, dwo, dbo, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

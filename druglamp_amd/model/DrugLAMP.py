@@ -34,11 +34,13 @@ class DrugLAMP(DrugLAMPBase):
         xp, xd = xps, xdp
         vpc = self.protein_extractor(vp, fill_p, site_pool=self.site_len, plan=self._protein_plan(hints, vp))       # compute dtype
         vdc = Fn.cast(vd, cdt)
+        vtail = getattr(vd, "_dl_tail", None)                                   # (distinct rows, multiplicity) of the compact forms
         xpc, xdc = self._llm_adaptors(xp, xd, hints.drug_tokens if hints is not None else 0)
+        xtail = getattr(xdc, "_dl_tail", None)
         vpf = vpc.float()                                                       # fp32 copies only for the returned tuple
         cp = {"prot": vpf, "aug_prot": xpc.float(), "drug": vd.float(), "aug_drug": xdc.float()} if self.two_c2p else None
-        mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, vdc, raw=(hints is None or hints.raw_attention))
-        mx, self.A_x_gca = self._gca_branch(self.x_gca, self.x_mhla, self.x_gca_norm, xpc, xdc, raw=(hints is None or hints.raw_attention))
+        mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, vdc, raw=(hints is None or hints.raw_attention), tail=vtail)
+        mx, self.A_x_gca = self._gca_branch(self.x_gca, self.x_mhla, self.x_gca_norm, xpc, xdc, raw=(hints is None or hints.raw_attention), tail=xtail)
         f, self.attn, self.guide_attn = self.pmma(mx, mv)
         with self._glue():
             score = self.mlp_classifier(Fn.TokenMeanFn.apply(f))
@@ -66,6 +68,7 @@ class DrugLAMP(DrugLAMPBase):
         with torch.cuda.stream(sa):              # branch a: drug graph -> MolecularGCN
             vd = self.drug_extractor(vd)
             vdc = Fn.cast(vd, cdt)
+            vtail = getattr(vd, "_dl_tail", None)
         fill_p, xps = ops.fill_pool(xp, self.site_len, cdt)
         sb.wait_stream(cur)
         with torch.cuda.stream(sb):              # branch b: protein LLM adaptor
@@ -74,6 +77,7 @@ class DrugLAMP(DrugLAMPBase):
         sc.wait_stream(cur)
         with torch.cuda.stream(sc):              # branch c: drug LLM adaptor
             xdc = self._drug_adaptor(xdp, hints.drug_tokens if hints is not None else 0)
+            xtail = getattr(xdc, "_dl_tail", None)
         ssl = {"vp": vp, "xp": (xp, fill_p), "fill_bit_p": fill_p, "vd": vd, "xd": (xdp, xd.shape[-1] + 1)}
         vpc = self.protein_extractor(vp, fill_p, site_pool=self.site_len, plan=self._protein_plan(hints, vp))   # main stream
         # v branch (needs the CNN and the GCN) continues on stream a; the x branch (needs both adaptors) runs on the main
@@ -81,15 +85,17 @@ class DrugLAMP(DrugLAMPBase):
         # hipStreamEndCapture of the step crash on ROCm 7.2)
         sa.wait_stream(cur)
         with torch.cuda.stream(sa):
-            mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, vdc, raw=(hints is None or hints.raw_attention))
+            mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, vdc, raw=(hints is None or hints.raw_attention), tail=vtail)
         cur.wait_stream(sb)
         cur.wait_stream(sc)
-        mx, self.A_x_gca = self._gca_branch(self.x_gca, self.x_mhla, self.x_gca_norm, xpc, xdc, raw=(hints is None or hints.raw_attention))
+        mx, self.A_x_gca = self._gca_branch(self.x_gca, self.x_mhla, self.x_gca_norm, xpc, xdc, raw=(hints is None or hints.raw_attention), tail=xtail)
         cur.wait_stream(sa)
         # produced on one stream, consumed (or freed) on another: tell the caching allocator
         for t, sts in ((vd, (cur,)), (xpc, (cur,)), (xdc, (cur,)), (mv, (cur,)), (xps, (sb,)), (xdp, (sc,)), (vpc, (sa,))):
             for st in sts:
                 t.record_stream(st)
+        if xtail is not None:
+            xtail[0].record_stream(cur)
         vpf = vpc.float()
         cp = {"prot": vpf, "aug_prot": xpc.float(), "drug": vd.float(), "aug_drug": xdc.float()} if self.two_c2p else None
         f, self.attn, self.guide_attn = self.pmma(mx, mv)

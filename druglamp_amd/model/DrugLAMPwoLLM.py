@@ -20,7 +20,8 @@ class DrugLAMPwoLLM(DrugLAMPBase):
         ssl = {"vp": vp, "xp": None, "fill_bit_p": fill_p, "vd": vd, "xd": None, "p_mode": "vp"}
         vpc = self.protein_extractor(vp, fill_p, site_pool=self.site_len, plan=self._protein_plan(hints, vp))       # compute dtype
         vpf = vpc.float()
-        mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, Fn.cast(vd, self.compute_dtype), raw=(hints is None or hints.raw_attention))
+        mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, Fn.cast(vd, self.compute_dtype), raw=(hints is None or hints.raw_attention),
+                                            tail=getattr(vd, "_dl_tail", None))
         f, self.attn, self.guide_attn = self.pmma(mv, mv)
         with self._glue():
             score = self.mlp_classifier(Fn.TokenMeanFn.apply(f))

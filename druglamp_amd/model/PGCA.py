@@ -38,7 +38,10 @@ class GuidedCrossAttention(nn.Module):
             nn.init.constant_(self.out_proj.bias, 0.)
         self.compute_dtype = torch.float32
 
-    def forward(self, query, key, value, key_padding_mask=None, need_weights=True, need_raw=True, attn_mask=None):
+    def forward(self, query, key, value, key_padding_mask=None, need_weights=True, need_raw=True, attn_mask=None, key_tail=None):
+        """key_tail = (rows, weight) (not in the reference's signature; default None = the reference's call): `key` holds the
+        distinct key rows only, its last `rows` rows each standing for `weight` identical rows of the full key set
+        (functional.GuidedCrossAttentionFn).  The raw logits are those of the full key set and are not produced then."""
         if key_padding_mask is not None or attn_mask is not None:
             raise NotImplementedError("GuidedCrossAttention: masks are not on the DrugLAMP path")
         if not (key is value or (key.data_ptr() == value.data_ptr() and key.shape == value.shape
@@ -49,10 +52,12 @@ class GuidedCrossAttention(nn.Module):
         assert embed_dim == self.embed_dim
         assert key.size(1) == bsz and key.size(2) == embed_dim
         want_raw = bool(need_weights and need_raw)
+        if key_tail is not None and want_raw:
+            raise ValueError("GuidedCrossAttention: raw logits are not available with key_tail (pass need_weights=False)")
         if need_weights and not need_raw:
             raise NotImplementedError("GuidedCrossAttention: head-averaged softmax weights are not implemented")
         q = Fn.cast(query, self.compute_dtype)
         k = Fn.cast(key, self.compute_dtype)
         out, raw = Fn.GuidedCrossAttentionFn.apply(q, k, self.in_proj_weight, self.in_proj_bias, self.out_proj.weight,
-                                                   self.out_proj.bias, self.num_heads, want_raw)
+                                                   self.out_proj.bias, self.num_heads, want_raw, key_tail)
         return Fn.cast(out, query.dtype), raw

@@ -24,6 +24,8 @@ from .self_supervised_learning import SSL
 
 from .._lib import FLAG_DRUG_TOKEN_PAD as _FLAG_TOK, FLAG_GCN_NODE_PAD as _FLAG_GCN   # noqa: E402
 
+_TAIL_ROWS = 8      # rows that stand for the identical padding rows in the compact forms of the drug branch (MolecularGCN, drug LLM adaptor)
+
 CONFIGS = {"LAMP": get_model_defaults}
 
 
@@ -143,7 +145,7 @@ class MolecularGCN(nn.Module):
         # that weight in the BatchNorm statistics and gradients (functional.BatchNormWeightedTailFn), and expanded at the
         # end.  Same values as the 512-row computation (the BatchNorm sums associate differently); with 128-atom blocks the
         # GCN touches 136 rows per molecule instead of 512.
-        TAIL = 8
+        TAIL = _TAIL_ROWS
         w = (N - Nr) // TAIL
         # (measured down to 32 molecules per batch: 4.16 -> 4.10 ms; tiny batches keep the plain form)
         if (self.compact_padding and N - Nr >= 2 * TAIL and (N - Nr) % TAIL == 0 and node_feats.is_cuda and
@@ -158,7 +160,9 @@ class MolecularGCN(nn.Module):
                     raise ValueError("MolecularGCN: the nodes beyond the adjacency block are not identical virtual padding nodes")
             h = Fn.cast(F.pad(node_feats[:, :Nr + TAIL].float(), (0, (-node_feats.shape[-1]) % 8)), cdt)
             y = self.gnn(adj, Fn.dense(h, self.init_transform.weight), tail_weight=w)          # (B, Nr + 8, C)
-            return Fn.ExpandTailFn.apply(y, Nr, w)                                             # row Nr + j <- tail row j % 8
+            out = Fn.ExpandTailFn.apply(y, Nr, w)                                              # row Nr + j <- tail row j % 8
+            out._dl_tail = (y, w)                           # the distinct rows, for consumers that take multiplicities (PGCA)
+            return out
         h = Fn.cast(F.pad(node_feats.float(), (0, (-node_feats.shape[-1]) % 8)), cdt)   # 75 -> 80 columns
         return self.gnn(adj, Fn.dense(h, self.init_transform.weight))
 
@@ -281,6 +285,7 @@ class DrugLAMPBase(nn.Module):
         self.check_padding = os.environ.get("DL_PAD_CHECK", "0") == "1"         # debug: verify the padding rows on the host (sync)
         self.guard_padding = os.environ.get("DL_PAD_GUARD", "1") != "0"         # device-side check of the padding rows (no sync)
         self.compact_cnn = os.environ.get("DL_CNN_COMPACT", "1") != "0"         # A/B switch: ProteinCNN on distinct rows
+        self.compact_keys = os.environ.get("DL_KEY_COMPACT", "1") != "0"        # A/B switch: PGCA over the distinct drug rows (round 5)
         # Independent branches of the forward (MolecularGCN, ProteinCNN, the two LLM adaptors, the v cross-attention branch)
         # on side HIP streams — and, through autograd, their backward passes — when the caller's hints ask for it
         # (BatchHints.branch_streams: the trainer does on cls steps).  DL_BRANCH_STREAMS=0: never.
@@ -356,13 +361,25 @@ class DrugLAMPBase(nn.Module):
         n_site = self.seq_len_q // self.site_len
         return t.view(-1, self.site_len, n_site, t.size(-1)).mean(dim=1)
 
-    def _gca_branch(self, gca, mhla, norm, prot_sites, drug_nodes, raw=True):
+    def _gca_branch(self, gca, mhla, norm, prot_sites, drug_nodes, raw=True, tail=None):
         """PGCA -> concat -> MHLA + residual -> LayerNorm (DrugLAMP.py:55-71).  Returns (m, raw logits).
         raw=False (BatchHints.raw_attention, the trainer's steps): the (B, 1, 256, 512) fp32 pre-softmax logits the reference
         keeps on self.A_*_gca for get_cross_attn_mat (basic_model.py:123-129) are not written — 134 MB per branch and step at
         batch 256 that nothing in a training step reads."""
-        m, raw = gca(prot_sites.permute(1, 0, 2), drug_nodes.permute(1, 0, 2), drug_nodes.permute(1, 0, 2),
-                     need_weights=self.keep_raw_attention and raw, need_raw=True)
+        want_raw = self.keep_raw_attention and raw
+        if tail is not None and not want_raw and self.compact_keys:
+            # Round 5: the drug side arrives from a compact padding form (MolecularGCN / the drug LLM adaptor: a block of
+            # real rows + 8 rows that each stand for w identical padding rows).  The cross-attention runs over those distinct
+            # rows with the multiplicity as a logit bias — the same softmax as over all 512 rows — so its in-projection,
+            # core and gradients touch block + 8 key rows per molecule instead of 512 (`tail` = (rows (B, block + 8, C), w)).
+            keys, w = tail
+            if keys.dtype != drug_nodes.dtype:
+                keys = Fn.cast(keys, drug_nodes.dtype)
+            kt = keys.permute(1, 0, 2)
+            m, raw = gca(prot_sites.permute(1, 0, 2), kt, kt, need_weights=False, need_raw=True, key_tail=(_TAIL_ROWS, w))
+        else:
+            m, raw = gca(prot_sites.permute(1, 0, 2), drug_nodes.permute(1, 0, 2), drug_nodes.permute(1, 0, 2),
+                         need_weights=want_raw, need_raw=True)
         g = m.permute(1, 0, 2)
         if prot_sites.dtype != g.dtype:
             prot_sites = Fn.cast(prot_sites, g.dtype)
@@ -396,7 +413,7 @@ class DrugLAMPBase(nn.Module):
         # drug adaptor is row-wise (Linear, GELU, LayerNorm, Linear).  With the collate's hint `drug_tokens` (a block size that
         # covers every molecule of the batch) the rows beyond it are computed as 8 rows standing for (512 - block) / 8 rows each
         # and expanded; the expansion's backward sums the copies' gradients, which is all a row-wise layer needs.
-        blk, N, TAIL = int(drug_tokens or 0), xd.shape[1], 8
+        blk, N, TAIL = int(drug_tokens or 0), xd.shape[1], _TAIL_ROWS
         if blk and self.compact_padding and N - blk >= 2 * TAIL and (N - blk) % TAIL == 0 and blk % 8 == 0:
             if self.guard_padding:
                 ops.rows_equal_check(xd, blk, _FLAG_TOK)       # device-side guard: a wrong token count is an error, not garbage
@@ -407,7 +424,9 @@ class DrugLAMPBase(nn.Module):
         h = Fn.layer_norm(h, self.d_norm.weight, self.d_norm.bias, self.d_norm.eps)
         xdf = Fn.dense(h, self.lin_d2.weight, self.lin_d2.bias)
         if xdf.shape[1] != N:
-            xdf = Fn.ExpandTailFn.apply(xdf, blk, (N - blk) // TAIL)
+            comp = xdf
+            xdf = Fn.ExpandTailFn.apply(comp, blk, (N - blk) // TAIL)
+            xdf._dl_tail = (comp, (N - blk) // TAIL)        # the distinct rows, for consumers that take multiplicities (PGCA)
         return xdf
 
     def get_cross_attn_mat(self, modality="v"):

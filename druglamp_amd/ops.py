@@ -359,8 +359,9 @@ def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 def attn_fwd(q, k, v, *, n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, scale,
-             q_strides, k_strides, v_strides, out, o_strides, o_ss, need_lse=True, raw_logits=None, algo=0):
-    """Strides are (problem, head, row) in elements.  Returns the LSE tensor (or None)."""
+             q_strides, k_strides, v_strides, out, o_strides, o_ss, need_lse=True, raw_logits=None, algo=0, key_tail=None):
+    """Strides are (problem, head, row) in elements.  Returns the LSE tensor (or None).
+    key_tail = (rows, weight): the last `rows` keys each stand for `weight` identical keys (dl_attn_fwd_args.key_tail_rows)."""
     _need_gpu(q, k, v, out)
     a = AttnFwdArgs()
     a.Q, a.K, a.V, a.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
@@ -378,6 +379,8 @@ def attn_fwd(q, k, v, *, n_problems, n_heads, n_segments, partner_shift, Lq, Lk,
     a.Lq, a.Lk, a.head_dim, a.dtype = Lq, Lk, head_dim, _dt(q)
     a.scale = float(scale)
     a.algo = algo
+    if key_tail is not None:
+        a.key_tail_rows, a.key_tail_weight = int(key_tail[0]), float(key_tail[1])
     check(_lib.lib().dl_attn_fwd(C.byref(a), _stream()), "dl_attn_fwd")
     return lse
 
@@ -387,7 +390,7 @@ _ATTN_BWD_ALGO = int(os.environ.get("DL_ATTN_BWD_ALGO", "0"))    # A/B switch: 2
 
 def attn_bwd(q, k, v, o, do, lse, *, n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, scale,
              q_strides, k_strides, v_strides, o_strides, o_ss, do_strides, do_ss, dq, dq_strides, dk, dk_strides,
-             dv, dv_strides, algo=0):
+             dv, dv_strides, algo=0, key_tail=None):
     _need_gpu(q, k, v, o, do)
     a = AttnBwdArgs()
     delta = torch.empty_like(lse)
@@ -408,6 +411,8 @@ def attn_bwd(q, k, v, o, do, lse, *, n_problems, n_heads, n_segments, partner_sh
     a.Lq, a.Lk, a.head_dim, a.dtype = Lq, Lk, head_dim, _dt(q)
     a.scale = float(scale)
     a.algo = algo if algo else _ATTN_BWD_ALGO
+    if key_tail is not None:
+        a.key_tail_rows, a.key_tail_weight = int(key_tail[0]), float(key_tail[1])
     check(_lib.lib().dl_attn_bwd(C.byref(a), _stream()), "dl_attn_bwd")
 
 

@@ -265,6 +265,14 @@ typedef struct {
   float scale;
   int32_t algo;   /* DL_ATTN_ALGO_AUTO, or DL_ATTN_ALGO_STREAM: key tiles streamed through LDS whatever the lengths
                      (the form every long sequence takes; AUTO keeps K/V LDS-resident when Lk <= 256 at head_dim 64) */
+  /* Key multiplicities (round 5; one segment only).  The last key_tail_rows keys each stand for key_tail_weight identical
+   * keys of the attention the reference computes: PGCA's key / value rows are the 512 drug nodes / tokens of a molecule
+   * (model/DrugLAMP.py:55-56), of which everything beyond the batch's block is one repeated padding row (virtual GCN nodes,
+   * handler/dataset.py:216-221; zero token rows, utils.py:304-312).  softmax over the full key set = softmax over the distinct
+   * keys with log(weight) added to a repeated key's logit; O, LSE and (backward) dQ are those of the full attention, dK / dV of
+   * a tail key are the SUMS over the keys it stands for.  0 rows = plain attention. */
+  int32_t key_tail_rows;
+  float key_tail_weight;
 } dl_attn_fwd_args;
 enum { DL_ATTN_ALGO_AUTO = 0, DL_ATTN_ALGO_STREAM = 1, DL_ATTN_ALGO_TWO_PASS = 2, DL_ATTN_ALGO_ONE_PASS = 3 };
 /* Backward at head_dim 64, bf16, Lk <= 256 (one segment, or two with partner(partner(p)) = p): AUTO takes the one-pass kernel
@@ -286,6 +294,8 @@ typedef struct {
   int32_t n_problems, n_heads, n_segments, partner_shift, Lq, Lk, head_dim, dtype;
   float scale;
   int32_t algo;   /* as in dl_attn_fwd_args */
+  int32_t key_tail_rows;     /* as in dl_attn_fwd_args (must match the forward call) */
+  float key_tail_weight;
 } dl_attn_bwd_args;
 int dl_attn_bwd(const dl_attn_bwd_args* a, dl_stream s);
 

@@ -585,6 +585,66 @@ def test_one_pass_attention_backward_equals_the_kernel_pair(P, H, S, Lq, Lk):
     assert same, "AUTO did not take the form its rule names"
 
 
+@pytest.mark.parametrize("dt,hd,H,P,Lq,lead,tail,w", [(torch.bfloat16, 128, 1, 24, 256, 128, 8, 48),     # PGCA's shape: 512 keys -> 136
+                                                       (torch.bfloat16, 128, 2, 6, 100, 70, 8, 5),       # ragged lengths, two heads
+                                                       (torch.bfloat16, 64, 4, 6, 256, 128, 8, 48),      # head_dim 64 takes the streaming forms
+                                                       (torch.float32, 128, 1, 4, 96, 61, 3, 7),         # fp32 pipeline (delta launch, generic kernels)
+                                                       (torch.float32, 64, 2, 3, 80, 128, 8, 16)])
+def test_attention_with_key_multiplicities_equals_the_attention_over_the_expanded_keys(dt, hd, H, P, Lq, lead, tail, w):
+    """dl_attn_fwd / dl_attn_bwd with key_tail_rows (round 5): the last `tail` keys each stand for `w` identical keys.  Against the
+    attention over the EXPANDED key set (lead + w * tail rows, tail row j repeated as rows lead + j + m * tail) in fp64: same
+    output, LSE and dQ; dK / dV of the lead keys equal, of a tail key the SUM over its copies.  And against the library's own
+    plain attention on the expanded keys (the path the compact form replaces)."""
+    from druglamp_amd import ops
+    dev = "cuda:0"
+    d, Lc, Lf = H * hd, lead + tail, lead + w * tail
+    g = torch.Generator().manual_seed(7)
+    q = (torch.randn(P * Lq, d, generator=g) * 0.7).to(dev, dt)
+    kvc = (torch.randn(P, Lc, 2 * d, generator=g) * 0.7).to(dev, dt)
+    kvf = torch.cat([kvc[:, :lead], kvc[:, lead:].unsqueeze(1).expand(P, w, tail, 2 * d).reshape(P, w * tail, 2 * d)], 1).contiguous()
+    do = (torch.randn(P * Lq, d, generator=g) * 0.2).to(dev, dt)
+    scale = hd ** -0.5
+
+    def run(kv, Lk, key_tail):
+        kv2 = kv.reshape(P * Lk, 2 * d)
+        k, v = kv2[:, :d], kv2[:, d:]
+        common = dict(n_problems=P, n_heads=H, n_segments=1, partner_shift=0, Lq=Lq, Lk=Lk, head_dim=hd, scale=scale,
+                      q_strides=(Lq * d, hd, d), k_strides=(Lk * 2 * d, hd, 2 * d), v_strides=(Lk * 2 * d, hd, 2 * d), key_tail=key_tail)
+        o = torch.full((P * Lq, d), float("nan"), device=dev, dtype=dt)
+        lse = ops.attn_fwd(q, k, v, out=o, o_strides=(Lq * d, hd, d), o_ss=0, **common)
+        dq = torch.full((P * Lq, d), float("nan"), device=dev, dtype=dt)
+        dkv = torch.full((P * Lk, 2 * d), float("nan"), device=dev, dtype=dt)
+        ops.attn_bwd(q, k, v, o, do, lse, o_strides=(Lq * d, hd, d), o_ss=0, do_strides=(Lq * d, hd, d), do_ss=0, dq=dq,
+                     dq_strides=(Lq * d, hd, d), dk=dkv, dk_strides=(Lk * 2 * d, hd, 2 * d), dv=dkv[:, d:], dv_strides=(Lk * 2 * d, hd, 2 * d),
+                     **common)
+        return o.double(), lse.double(), dq.double(), dkv.double().reshape(P, Lk, 2 * d)
+
+    oc, lc, dqc, dkvc = run(kvc, Lc, (tail, float(w)))
+    of, lf, dqf, dkvf = run(kvf, Lf, None)
+    # fp64 truth on the expanded keys
+    qd = q.double().reshape(P, Lq, H, hd).permute(0, 2, 1, 3).requires_grad_(True)
+    kd = kvf.double()[..., :d].reshape(P, Lf, H, hd).permute(0, 2, 1, 3).requires_grad_(True)
+    vd = kvf.double()[..., d:].reshape(P, Lf, H, hd).permute(0, 2, 1, 3).requires_grad_(True)
+    sc = (qd @ kd.transpose(-1, -2)) * scale
+    ot = (torch.softmax(sc, -1) @ vd).permute(0, 2, 1, 3).reshape(P * Lq, d)
+    ot.backward(do.double())
+    lt = torch.logsumexp(sc, -1).detach()                                        # (P, H, Lq)
+
+    def fold(t):                                                                  # (P, H, Lf, hd) gradient -> compact rows (sum over the copies)
+        t = t.permute(0, 2, 1, 3).reshape(P, Lf, d)
+        return torch.cat([t[:, :lead], t[:, lead:].reshape(P, w, tail, d).sum(1)], 1)
+    dk_t, dv_t = fold(kd.grad), fold(vd.grad)
+    dq_t = qd.grad.permute(0, 2, 1, 3).reshape(P * Lq, d)
+    tol = 2e-2 if dt == torch.bfloat16 else 2e-5
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))       # noqa: E731
+    assert rel(oc, ot.detach()) <= tol and rel(lc.reshape(P, H, Lq), lt) <= (2e-3 if dt == torch.bfloat16 else 1e-5)
+    assert rel(dqc, dq_t) <= tol
+    assert rel(dkvc[..., :d], dk_t) <= tol and rel(dkvc[..., d:], dv_t) <= tol
+    # ... and the plain attention over the expanded keys agrees with the compact one to the pipeline's rounding
+    assert rel(oc, of) <= tol and rel(dqc, dqf) <= tol
+    assert rel(dkvc[:, :lead], dkvf[:, :lead]) <= tol
+
+
 @pytest.mark.parametrize("dt,R,C,win", [(torch.bfloat16, 5000, 128, (0, 0, 0)), (torch.bfloat16, 4 * 2312, 128, (2312, 4, 2304)),
                                        (torch.float32, 777, 72, (0, 0, 0)), (torch.bfloat16, 3000, 96, (0, 0, 0)),
                                        (torch.bfloat16, 9000, 256, (0, 0, 0))])

@@ -411,6 +411,59 @@ def test_gcn_full_and_compact_forms_against_the_fp64_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_cross_attention_over_the_distinct_drug_rows_whole_model(dt, tol):
+    """Round 5: in a training step (no raw-logit maps) both PGCA blocks attend over the distinct drug rows the compact
+    padding forms produce (block + 8 rows with multiplicities) instead of the 512 expanded rows.  Whole model, training
+    forward / backward with the hints of a trainer step: scores and every parameter gradient with DL_KEY_COMPACT's switch on
+    and off (off = the round-4 computation over the expanded rows)."""
+    import copy
+    from druglamp_amd.configs import get_cfg_defaults, load_yaml_into
+    from druglamp_amd.model import MInterface
+    from druglamp_amd.protein_plan import BatchHints
+    from druglamp_amd.synthetic import make_batch
+    from druglamp_amd.trainer import Trainer
+    torch.manual_seed(3)
+    cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP")
+    ref = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(DEV).train()
+    ref.pmma.p_drop = 0.0
+    ref.pmma.embeddings.p_drop = 0.0
+    ref.set_compute_dtype(dt)
+    ref.drug_extractor.compact_min_rows = 0           # (a batch of 4: take the compact MolecularGCN form anyway)
+    batch, meta = make_batch(4, DEV, seed=11, with_graph=True, llm_dtype=dt)
+    blk = Trainer.padding_hints_of(meta, batch)["drug_tokens"]
+    cmp_ = copy.deepcopy(ref)
+    ref.compact_keys, cmp_.compact_keys = False, True
+    feat_d, feat_p, labels, llm_d, llm_p = batch
+    outs, calls = [], []
+    import druglamp_amd.ops as ops_mod
+    real = ops_mod.attn_fwd
+    for m in (ref, cmp_):
+        seen = []
+        ops_mod.attn_fwd = lambda *a, **k: (seen.append((k["Lk"], k.get("key_tail"))), real(*a, **k))[1]
+        try:
+            score = m(feat_d, feat_p, llm_d, llm_p, hints=BatchHints(drug_tokens=blk, raw_attention=False))[-1]
+        finally:
+            ops_mod.attn_fwd = real
+        score.float().sum().backward()
+        outs.append(score.float())
+        calls.append([c for c in seen if c[0] != 256])                  # the two PGCA launches (PMMA's have Lk = 256)
+    assert calls[0] == [(512, None), (512, None)]
+    assert sorted(calls[1]) == sorted([(128 + 8, (8, 48)), (blk + 8, (8, (512 - blk) // 8))]), calls[1]
+    assert relerr(outs[1], outs[0]) <= tol
+    for (n, a), (_, b) in zip(ref.named_parameters(), cmp_.named_parameters()):
+        if a.grad is None:
+            assert b.grad is None, n
+            continue
+        if dt == torch.float32:
+            assert relerr(b.grad, a.grad) <= 50 * tol, n
+        else:
+            x, y = b.grad.double().flatten(), a.grad.double().flatten()
+            assert float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)) >= 0.98, n
+    ops_mod.check_guard_flags(DEV)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
 def test_drug_llm_adaptor_compact_padding_equals_the_full_computation(dt, tol):
     """Round 3: with the collate's `drug_tokens` hint the drug LLM adaptor (Linear + GELU, LayerNorm, Linear: all row-wise)

@@ -123,6 +123,41 @@ def test_pgca(tag, shape, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
+def test_pgca_over_distinct_key_rows_equals_the_module_over_all_rows(dtype, tol):
+    """Round 5: GuidedCrossAttention(key_tail=(8, w)) over block + 8 distinct key rows against the same module over the 512 rows
+    the reference attends over (block rows + the 8 tail rows repeated w times): output, query gradient, the key gradient
+    (a tail row's = the sum over its copies) and every parameter gradient.  The weights are the PGCA golden's."""
+    from druglamp_amd.model.PGCA import GuidedCrossAttention
+    Lq, B, blk, tail = 256, 4, 128, 8
+    w = (512 - blk) // tail
+    g = load("pgca_full")
+    ms = []
+    for _ in range(2):
+        m = GuidedCrossAttention(embed_dim=128, num_heads=1)
+        m.load_state_dict(det_state_dict(g), strict=True)
+        m = m.to(_dev()).eval()
+        m.compute_dtype = dtype
+        ms.append(m)
+    q0 = T("pgca_c.q", (Lq, B, 128)).to(_dev())
+    kc0 = T("pgca_c.kv", (blk + tail, B, 128)).to(_dev())
+    G = T("pgca_c.G", (Lq, B, 128)).to(_dev())
+    qa, ka = q0.clone().requires_grad_(True), kc0.clone().requires_grad_(True)
+    out_c, raw_c = ms[0](qa, ka, ka, need_weights=False, key_tail=(tail, w))
+    assert raw_c is None
+    (out_c * G).sum().backward()
+    qb, kb = q0.clone().requires_grad_(True), kc0.clone().requires_grad_(True)
+    kfull = torch.cat([kb[:blk], kb[blk:].unsqueeze(0).expand(w, tail, B, 128).reshape(w * tail, B, 128)], 0)
+    out_f, _ = ms[1](qb, kfull, kfull)
+    (out_f * G).sum().backward()
+    assert relerr(out_c, out_f) <= tol
+    assert relerr(qa.grad, qb.grad) <= tol * 3 and relerr(ka.grad, kb.grad) <= tol * 3
+    for (n, a), (_, b) in zip(ms[0].named_parameters(), ms[1].named_parameters()):
+        assert relerr(a.grad, b.grad) <= tol * 3, n
+    with pytest.raises(ValueError):
+        ms[0](qa, ka, ka, key_tail=(tail, w))              # raw logits are those of all 512 rows
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, F32_TOL), (torch.bfloat16, BF16_TOL)])
 @pytest.mark.parametrize("tag,shape", [("mhla_toy", (32, 64, 2, 5)), ("mhla_full", (256, 1024, 2, 256))])
 def test_mhla(tag, shape, dtype, tol):
     from druglamp_amd.model.PMMA import MultiHeadLinearAttention
