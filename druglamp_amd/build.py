@@ -50,12 +50,15 @@ def _stale(out, deps):
 # always pass 1, lanes 48-63, even elements; 0 of 80 without the packed forms) — a timing-dependent forwarding hazard the
 # compiler does not pad.  Found through the two-rank graph-vs-eager bit-identity test.
 # elementwise.hip carries the same unpack-then-fp32 pattern (251 packed fp32 ops with the vectoriser on) and is HBM-bound: it
-# gets the flag too (same-box step time unchanged).  bn.hip does NOT: built without the vectoriser, the fp32
-# compact-MolecularGCN test (tests/test_model_gpu.py::test_gcn_compact_padding_equals_the_512_row_computation) fails with a
-# 5e-3 gradient error although every dl_bn_* call gives the same result in both builds when issued one at a time
-# (tools/bn_ab.py, tools/bn_ab_model.py) — an unresolved timing- or layout-dependent effect; bn.hip therefore stays on the
-# build that has passed every parity and contention test since round 2 (the contention test runs the BatchNorm statistics /
-# apply / backward kernels, wide and generic, with and without row weights, since round 4).  gemm / attention keep the vectoriser as well
+# gets the flag too (same-box step time unchanged).  bn.hip does NOT need it and stays on the vectoriser.
+# Round 4 recorded that a no-SLP build of bn.hip fails tests/test_model_gpu.py::test_gcn_compact_padding_equals_the_512_row_computation
+# (fp32, 5e-3 gradient error) although every dl_bn_* call agreed between the builds, and left it unexplained.  Round 5 resolved it
+# (tools/bn_bisect.py records every ops call of both builds; profiles/r5_bn_bisect.txt): the builds' BatchNorm outputs differ in
+# the last bit (another FMA contraction), which moves ONE pre-activation of the following ReLU-epilogue GEMM across zero (0 vs
+# 1.7e-7 at a tensor maximum of 10.8); the backward then differs in that one row.  A ReLU kink in the test data, not a kernel
+# fault: against the fp64 oracle both forms of the product build are at 4e-6 ... 1.2e-5 (test_gcn_full_and_compact_forms_
+# against_the_fp64_oracle).  The contention test covers the BatchNorm statistics / apply / backward kernels (wide and generic,
+# with and without row weights) for the packed-fp32 forwarding hazard the flag exists for.  gemm / attention keep the vectoriser as well
 # (their epilogues rely on the packed forms: 15.70 -> 16.36 ms without) and are covered by tests/test_contention_gpu.py.
 FILE_FLAGS = {"norm.hip": ["-fno-slp-vectorize"], "elementwise.hip": ["-fno-slp-vectorize"]}
 

@@ -376,10 +376,15 @@ def test_gcn_compact_padding_equals_the_512_row_computation(dt, tol):
 def test_gcn_full_and_compact_forms_against_the_fp64_oracle():
     """ADVICE r4 (bn.hip built without the SLP vectoriser failed the compact-vs-full comparison above although every dl_bn_*
     call agreed between the builds): the two forms are compared here with the TRUTH — the oracle's MolecularGCN in fp64 on the
-    same weights and graphs — instead of with each other.  Most of a molecule's 512 nodes are identical virtual padding
-    nodes, so a BatchNorm column is a constant plus a few real atoms and its backward subtracts the batch mean and the
-    y-hat projection from a gradient that largely consists of them: fp32 rounding of the statistics is amplified, in BOTH
-    forms.  Each form must be within the bound of the fp64 result; their mutual distance is bounded by the sum."""
+    same weights and graphs — instead of only with each other.  Measured (round 5, product build): full form 1.2e-5, compact
+    form 4.2e-6 at worst over all parameter gradients — both at fp32 rounding, the network is well conditioned.
+    What the no-SLP build of bn.hip does differently (tools/bn_bisect.py, profiles/r5_bn_bisect.txt: every ops call of the two
+    builds recorded and compared): ONE element of the 816 x 128 output of a ReLU-epilogue GEMM in the forward is 0 in one build
+    and 1.7e-7 in the other (tensor maximum 10.8) — a pre-activation within one rounding of the ReLU kink, moved across it by a
+    last-bit difference in the BatchNorm in front of it (other FMA contraction) — and the backward then differs in exactly that
+    row (gradient error 5e-3 ... 3e-2 against either reference).  Both results are correct fp32 evaluations of a function that
+    is not differentiable there; no kernel is at fault.  If a future toolchain moves this seed's activation across the kink in
+    the product build, this test and the compact-vs-full test above fail with that one-row signature: check with the tool."""
     import copy
     from druglamp_amd.model.basic_model import MolecularGCN
     from druglamp_amd.synthetic import make_batch
@@ -411,7 +416,7 @@ def test_gcn_full_and_compact_forms_against_the_fp64_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
 def test_cross_attention_over_the_distinct_drug_rows_whole_model(dt, tol):
     """Round 5: in a training step (no raw-logit maps) both PGCA blocks attend over the distinct drug rows the compact
     padding forms produce (block + 8 rows with multiplicities) instead of the 512 expanded rows.  Whole model, training
@@ -450,13 +455,14 @@ def test_cross_attention_over_the_distinct_drug_rows_whole_model(dt, tol):
         calls.append([c for c in seen if c[0] != 256])                  # the two PGCA launches (PMMA's have Lk = 256)
     assert calls[0] == [(512, None), (512, None)]
     assert sorted(calls[1]) == sorted([(128 + 8, (8, 48)), (blk + 8, (8, (512 - blk) // 8))]), calls[1]
+    # (the softmax over 136 weighted keys and over 512 keys sum in different orders: fp32 rounding, carried through the network)
     assert relerr(outs[1], outs[0]) <= tol
     for (n, a), (_, b) in zip(ref.named_parameters(), cmp_.named_parameters()):
         if a.grad is None:
             assert b.grad is None, n
             continue
         if dt == torch.float32:
-            assert relerr(b.grad, a.grad) <= 50 * tol, n
+            assert relerr(b.grad, a.grad) <= 20 * tol, n
         else:
             x, y = b.grad.double().flatten(), a.grad.double().flatten()
             assert float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)) >= 0.98, n

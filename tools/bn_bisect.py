@@ -13,7 +13,7 @@ import torch
 if sys.argv[1] == "cmp":
     a, b = torch.load(sys.argv[2]), torch.load(sys.argv[3])
     print(len(a), len(b), "recorded calls")
-    shown = 0
+    shown = zeros_shown = 0
     for i, ((na, ta), (nb, tb)) in enumerate(zip(a, b)):
         assert na == nb, (i, na, nb)
         for j, (x, y) in enumerate(zip(ta, tb)):
@@ -21,6 +21,13 @@ if sys.argv[1] == "cmp":
                 print(i, na, j, "SHAPE", x.shape, y.shape)
                 continue
             x, y = x.double(), y.double()
+            # ReLU kinks: elements that are exactly zero in one build and not in the other (a pre-activation within rounding of 0)
+            zm = (x == 0) != (y == 0)
+            if zm.any() and zeros_shown < 12:
+                other = torch.where(x == 0, y, x)[zm].abs()
+                print("call %4d %-22s out %d: %d elements zero in one build only; the other build's values there: max |v| %.3e (tensor max %.3e); "
+                      "first at flat %d" % (i, na, j, int(zm.sum()), float(other.max()), float(x.abs().max()), int(zm.flatten().nonzero()[0])))
+                zeros_shown += 1
             bad = ~(torch.isfinite(x) & torch.isfinite(y))
             d = (x - y).abs()
             d[bad] = 0
@@ -46,7 +53,7 @@ def wrap(name, fn):
         out = fn(*a, **k)
         torch.cuda.synchronize()
         ts = [t for t in (out if isinstance(out, (tuple, list)) else (out,)) if torch.is_tensor(t)]
-        rec.append((name, [t.detach().float().cpu().clone() for t in ts]))
+        rec.append((name + ("[act=%s]" % k["act"] if "act" in k else ""), [t.detach().float().cpu().clone() for t in ts]))
         return out
     return w
 
