@@ -26,5 +26,5 @@ for s, e, n in rows:
     tot[n][1] += 1
 busy = sum(v[0] for v in tot.values())
 print("window %.1f ms, kernel-busy %.1f ms, %d launches" % ((t1 - cut) / 1e6, busy / 1e6, sum(v[1] for v in tot.values())))
-for n, (d, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:45]:
+for n, (d, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 45]:
     print("%8.2f ms %6d x %8.1f us  %5.1f%%  %s" % (d / 1e6, c, d / c / 1e3, 100.0 * d / busy, n))
