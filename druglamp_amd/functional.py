@@ -395,6 +395,7 @@ class LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, K).contiguous()
         M = x2.shape[0]
         w = lowp((weight,), cdt)
+        wT = lowp((weight,), cdt, transpose=True) if (ctx.needs_input_grad[0] and cdt == torch.bfloat16 and N % 8 == 0) else None   # (K-contiguous data gradient)
         p_eff = float(p_drop) if (training and p_drop > 0) else 0.0
         seed = ops.next_seed() if p_eff > 0 else 0
         if pe is None:
@@ -403,18 +404,20 @@ class LinearFn(torch.autograd.Function):
             pe2 = lowp((pe,), cdt).reshape(-1, N)
             y = ops.gemm(x2, w, M=M, N=N, K=K, bias=_f32(bias), residual=pe2, res_row_mod=pe2.shape[0],
                          res_before_dropout=True, dropout_p=p_eff, seed=seed)
-        ctx.save_for_backward(x2, w)
+        ctx.save_for_backward(x2, w, wT)
         ctx.cfg = (x.shape, M, N, K, p_eff, seed, bias is not None, None if pe is None else tuple(pe.shape))
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w = ctx.saved_tensors
+        x2, w, wT = ctx.saved_tensors
         xshape, M, N, K, p_eff, seed, has_bias, pe_shape = ctx.cfg
         g = dy.reshape(M, N).contiguous()
         if p_eff > 0:
             g = ops.dropout_apply(g, p_eff, seed)
-        dx = ops.gemm(g, w, M=M, N=K, K=N, w_kslow=True, ldw=K).reshape(xshape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (ops.gemm(g, wT, M=M, N=K, K=N) if wT is not None else ops.gemm(g, w, M=M, N=K, K=N, w_kslow=True, ldw=K)).reshape(xshape)
         want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw, db = _wgrad(g, x2, N, K, M, N, K, want_bias=want_b)
@@ -518,7 +521,10 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
                            key_tail=key_tail)
         ow = lowp((out_w,), cdt)
         y = ops.gemm(o, ow, M=B * Lq, N=E, K=E, bias=_f32(out_b))
-        ctx.save_for_backward(q2, k2, w, qp, kv, o, lse, ow)
+        # [in][out] images for the data gradients (K-contiguous products; the K-slow forward images otherwise)
+        wT = lowp((in_w,), cdt, transpose=True) if cdt == torch.bfloat16 else None          # [E][3E]
+        owT = lowp((out_w,), cdt, transpose=True) if cdt == torch.bfloat16 else None
+        ctx.save_for_backward(q2, k2, w, qp, kv, o, lse, ow, wT, owT)
         if key_tail is not None and need_raw:
             raise ValueError("GuidedCrossAttentionFn: the raw logits are those of all key rows; not available with key_tail")
         ctx.cfg = (Lq, Lk, B, E, H, scale, in_b is not None, out_b is not None, key_tail)
@@ -529,12 +535,12 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
     @staticmethod
     @_deferring
     def backward(ctx, dy, _draw):
-        q2, k2, w, qp, kv, o, lse, ow = ctx.saved_tensors
+        q2, k2, w, qp, kv, o, lse, ow, wT, owT = ctx.saved_tensors
         Lq, Lk, B, E, H, scale, has_inb, has_outb, key_tail = ctx.cfg
         hd = E // H
         g = dy.transpose(0, 1).contiguous().view(B * Lq, E)
         dwo, dbo = _wgrad(g, o, E, E, Lq * B, E, E, want_bias=has_outb)
-        do = ops.gemm(g, ow, M=Lq * B, N=E, K=E, w_kslow=True, ldw=E)
+        do = ops.gemm(g, owT, M=Lq * B, N=E, K=E) if owT is not None else ops.gemm(g, ow, M=Lq * B, N=E, K=E, w_kslow=True, ldw=E)
         dqp = torch.empty_like(qp)
         dkv = torch.empty_like(kv)
         ops.attn_bwd(qp, kv, kv[:, E:], o, do, lse, n_problems=B, n_heads=H, n_segments=1, partner_shift=0, Lq=Lq,
@@ -547,8 +553,12 @@ class GuidedCrossAttentionFn(torch.autograd.Function):
         din_b = torch.empty(3 * E, dtype=torch.float32, device=g.device) if has_inb else None
         _wgrad(dqp, q2, E, E, Lq * B, E, E, want_bias=has_inb, out_w=din_w[:E], out_b=None if din_b is None else din_b[:E])
         _wgrad(dkv, k2, 2 * E, E, Lk * B, 2 * E, E, want_bias=has_inb, out_w=din_w[E:], out_b=None if din_b is None else din_b[E:])
-        dquery = ops.gemm(dqp, w[:E], M=Lq * B, N=E, K=E, w_kslow=True, ldw=E).view(B, Lq, E).transpose(0, 1)
-        dkey = ops.gemm(dkv, w[E:], M=Lk * B, N=E, K=2 * E, w_kslow=True, ldw=E).view(B, Lk, E).transpose(0, 1)
+        if wT is not None:          # wT[n][k]: input feature n, output feature k of the in-projection (q: k < E; k / v: E <= k < 3E)
+            dquery = ops.gemm(dqp, wT, M=Lq * B, N=E, K=E, ldw=3 * E).view(B, Lq, E).transpose(0, 1)
+            dkey = ops.gemm(dkv, wT[:, E:], M=Lk * B, N=E, K=2 * E, ldw=3 * E).view(B, Lk, E).transpose(0, 1)
+        else:
+            dquery = ops.gemm(dqp, w[:E], M=Lq * B, N=E, K=E, w_kslow=True, ldw=E).view(B, Lq, E).transpose(0, 1)
+            dkey = ops.gemm(dkv, w[E:], M=Lk * B, N=E, K=2 * E, w_kslow=True, ldw=E).view(B, Lk, E).transpose(0, 1)
         return dquery, dkey, din_w, din_b, dwo, dbo, None, None, None
 
 
@@ -950,6 +960,12 @@ class DenseFn(torch.autograd.Function):
         M = x2.shape[0]
         # [Np][Kp] image of the [out][in] matrix (for a [in][out] parameter: its transpose, padded before transposing)
         w = lowp((weight,), cdt, transpose=True, pad=(Kp, Np)) if weight_t else _padded_weight(weight, Np, Kp, cdt)
+        # ... and its [Kp][Np] transpose for the data gradient, so that dx = g W is a K-contiguous product as well (round 5: through
+        # the K-slow forward image these ran on the 128-tile kernel at 35-160 TFLOP/s — 65536 x 648 x 256: 138 us, 65536 x 256 x 128:
+        # 72 us — against 250-750 for the same shapes with both operands K-contiguous)
+        wT = None
+        if ctx.needs_input_grad[0] and cdt == torch.bfloat16:
+            wT = lowp((weight,), cdt, pad=(Kp, Np)) if weight_t else lowp((weight,), cdt, transpose=True, pad=(Np, Kp))
         b = None
         if bias is not None:
             if N == Np and bias.dtype == torch.float32:
@@ -965,13 +981,13 @@ class DenseFn(torch.autograd.Function):
             if residual is not None:
                 raise NotImplementedError("dense: relu with a residual (the mask could not be read off the output)")
             pre = y                                    # relu'(pre) = [y > 0]
-        ctx.save_for_backward(x2, w, pre)
+        ctx.save_for_backward(x2, w, pre, wT)
         ctx.cfg = (x.shape, M, N, K, Np, Kp, bias is not None, residual is not None, act, weight_t)
         return y.reshape(*x.shape[:-1], Np)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, pre = ctx.saved_tensors
+        x2, w, pre, wT = ctx.saved_tensors
         xshape, M, N, K, Np, Kp, has_bias, has_res, act, weight_t = ctx.cfg
         g = dy.reshape(M, Np).contiguous()
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
@@ -979,7 +995,9 @@ class DenseFn(torch.autograd.Function):
             g = torch.ops.aten.threshold_backward(g, pre, 0)
         elif act:
             g = ops.gelu_bwd(g, pre)
-        dx = ops.gemm(g, w, M=M, N=Kp, K=Np, w_kslow=True, ldw=Kp).reshape(xshape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (ops.gemm(g, wT, M=M, N=Kp, K=Np) if wT is not None else ops.gemm(g, w, M=M, N=Kp, K=Np, w_kslow=True, ldw=Kp)).reshape(xshape)
         dw = None
         want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:

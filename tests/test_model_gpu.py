@@ -459,24 +459,21 @@ def test_cross_attention_over_the_distinct_drug_rows_whole_model(dt, tol):
     assert sorted(calls[1]) == sorted([(128 + 8, (8, 48)), (blk + 8, (8, (512 - blk) // 8))]), calls[1]
     # (the softmax over 136 weighted keys and over 512 keys sum in different orders: fp32 rounding, carried through the network)
     assert relerr(outs[1], outs[0]) <= tol
-    gmax = max(float(a.grad.norm()) for a in ref.parameters() if a.grad is not None)
-    checked = 0
-    for (n, a), (_, b) in zip(ref.named_parameters(), cmp_.named_parameters()):
-        if a.grad is None:
-            assert b.grad is None, n
-            continue
-        if float(a.grad.norm()) < 1e-6 * gmax:
-            assert float(b.grad.norm()) < 1e-4 * gmax, n          # (nothing but rounding noise in both forms)
-            continue
-        checked += 1
-        if dt == torch.float32:
-            assert relerr(b.grad, a.grad) <= 20 * tol, n
-        else:
-            # (bf16: the exactness statement is the fp32 case; here the direction — 0.96 at worst, for MolecularGCN's first
-            #  weight, the parameter furthest upstream of the changed summation order)
-            x, y = b.grad.double().flatten(), a.grad.double().flatten()
-            assert float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)) >= 0.9, n
-    assert checked >= 100, checked
+    # Gradients.  Parameters in front of a BatchNorm carry little signal (a bias directly in front of one has none at all:
+    # what arrives there is rounding noise, in either form), so every tensor is compared on the scale of the LARGEST gradient
+    # entries of the model as well as on its own: |a - b| <= tol x max(own largest entry, 1e-3 x model's largest entry).
+    pa = [(n, a.grad, b.grad) for (n, a), (_, b) in zip(ref.named_parameters(), cmp_.named_parameters()) if a.grad is not None]
+    assert all(b is not None for _, _, b in pa) and len(pa) >= 150
+    top = max(float(a.abs().max()) for _, a, _ in pa)
+    if dt == torch.float32:
+        for n, a, b in pa:
+            assert float((a - b).abs().max()) <= 20 * tol * max(float(a.abs().max()), 1e-3 * top), n
+    else:
+        va, vb = torch.cat([a.double().flatten() for _, a, _ in pa]), torch.cat([b.double().flatten() for _, _, b in pa])
+        assert float(torch.dot(va, vb) / (va.norm() * vb.norm())) >= 0.995
+        for n, a, b in sorted(pa, key=lambda t: -float(t[1].norm()))[:40]:
+            x, y = b.double().flatten(), a.double().flatten()
+            assert float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)) >= 0.95, n      # (0.96 at worst: MolecularGCN's first weight)
     ops_mod.check_guard_flags(DEV)
 
 
