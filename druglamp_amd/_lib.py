@@ -140,6 +140,7 @@ SIGNATURES = {
     "dl_attn_bwd": (c_i32, [C.POINTER(AttnBwdArgs), c_vp]),
     "dl_token_gate_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "dl_token_gate_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "dl_gate_dpre": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "dl_add_rowmod_dropout": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_u64, c_vp, c_i32, c_vp]),
     "dl_dropout_apply": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_u64, c_vp, c_i32, c_vp]),
     "dl_fill_pool": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp]),

@@ -137,6 +137,49 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ 
   store4<T>(dx + i * 4, d);
 }
 
+// ---------------- MHLA backward: dpre = gelu'(pre) o (dlogits W2)  (round 5) ----------------------------------------------
+// The gradient of lin2 (d_diff -> H = 8 gate logits, model/PMMA/encoder.py:127-140) with respect to its input: a product
+// with an inner dimension of EIGHT, followed by the derivative of the GELU in front of it.  Through round 4 the 8 columns
+// were zero-padded to one 64-deep k-step (two torch launches) so that dl_gemm could take it with the gelu' epilogue
+// (77 us + 46 us of padding per MHLA block at batch 256); as an elementwise kernel it is one pass over `pre`:
+// a thread keeps its 8 columns of W2 (H x 8 values) in registers for the whole launch and walks rows with a grid stride.
+template <typename T, int H>
+__global__ __launch_bounds__(256) void gate_dpre_kernel(const T* __restrict__ dl, const T* __restrict__ w2, const T* __restrict__ pre,
+                                                         T* __restrict__ out, int64_t M, int dd) {
+  const int cpr = dd >> 3;                                   // 8-column chunks per row
+  const int rpb = 256 / cpr > 0 ? 256 / cpr : 1;             // rows per block and pass (cpr <= 256 is checked by the host)
+  const int ch = threadIdx.x % cpr, rsub = threadIdx.x / cpr;
+  if (rsub >= rpb) return;
+  float w[H][8];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const f32x4 a = load4<T>(w2 + (int64_t)h * dd + ch * 8), b = load4<T>(w2 + (int64_t)h * dd + ch * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { w[h][e] = a[e]; w[h][4 + e] = b[e]; }
+  }
+  for (int64_t r = (int64_t)blockIdx.x * rpb + rsub; r < M; r += (int64_t)gridDim.x * rpb) {
+    float d[H];
+    if constexpr (H % 4 == 0) {
+#pragma unroll
+      for (int h = 0; h < H; h += 4) {
+        const f32x4 v = load4<T>(dl + r * H + h);
+        d[h] = v[0]; d[h + 1] = v[1]; d[h + 2] = v[2]; d[h + 3] = v[3];
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < H; ++h) d[h] = to_f32(dl[r * H + h]);
+    }
+    const f32x4 p0 = load4<T>(pre + r * dd + ch * 8), p1 = load4<T>(pre + r * dd + ch * 8 + 4);
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a0[e] = fmaf(d[h], w[h][e], a0[e]); a1[e] = fmaf(d[h], w[h][4 + e], a1[e]); }
+    store4<T>(out + r * dd + ch * 8, a0 * gelu_grad4<T>(p0));
+    store4<T>(out + r * dd + ch * 8 + 4, a1 * gelu_grad4<T>(p1));
+  }
+}
+
 // ---------------- LLM feature ingest: fill bit + site pooling in ONE pass -------------------------
 // x [B][S][F]; fill[b][s] = (sum_f x[b][s][f] == 0); pooled[b][j][f] = mean_c xcat[b][c*n_site + j][f] for
 // c < site_len, xcat = [x | fill]; pooled is Fp = ceil8(F + 1) wide, zero beyond column F.
@@ -713,6 +756,27 @@ extern "C" int dl_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n,
     hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(nblk(n / 4)), dim3(256), 0, s, (const float*)dy, (const float*)pre,
                        (float*)dx, n / 4);
   DL_CHECK_LAUNCH("dl_gelu_bwd");
+  return DL_OK;
+}
+
+extern "C" int dl_gate_dpre(const void* dlogits, const void* w2, const void* pre, void* dpre, int64_t M, int64_t dd, int32_t H,
+                            int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(dlogits && w2 && pre && dpre && M > 0 && dd > 0, DL_ERR_ARG, "dl_gate_dpre: bad args");
+  DL_CHECK_ARG(H == 8 && dd % 8 == 0 && dd <= 2048, DL_ERR_UNSUPPORTED, "dl_gate_dpre: H = 8 heads, d_diff a multiple of 8 up to 2048");
+  DL_CHECK_ARG(dtype == DL_BF16 || dtype == DL_F32, DL_ERR_ARG, "dl_gate_dpre: bad dtype");
+  DL_CHECK_ARG((((uintptr_t)dlogits | (uintptr_t)w2 | (uintptr_t)pre | (uintptr_t)dpre) & 15) == 0, DL_ERR_ALIGN, "dl_gate_dpre: 16-byte alignment");
+  const int cpr = (int)(dd / 8), rpb = 256 / cpr;
+  int64_t blocks = (M + (int64_t)rpb * 8 - 1) / ((int64_t)rpb * 8);       // ~8 rows per thread: the weight registers are loaded once
+  if (blocks < 1) blocks = 1;
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((gate_dpre_kernel<bf16_t, 8>), dim3((uint32_t)blocks), dim3(256), 0, s, (const bf16_t*)dlogits, (const bf16_t*)w2,
+                       (const bf16_t*)pre, (bf16_t*)dpre, M, (int)dd);
+  else
+    hipLaunchKernelGGL((gate_dpre_kernel<float, 8>), dim3((uint32_t)blocks), dim3(256), 0, s, (const float*)dlogits, (const float*)w2,
+                       (const float*)pre, (float*)dpre, M, (int)dd);
+  DL_CHECK_LAUNCH("dl_gate_dpre");
   return DL_OK;
 }
 

@@ -243,6 +243,7 @@ class _Stream:
 from ._lib import TAG_QKV_OUT as _TAG_QKV_OUT, TAG_FFN as _TAG_FFN, TAG_CONV as _TAG_CONV, TAG_ADAPTOR as _TAG_ADAPTOR  # noqa: E402
 
 PAIR_GEMMS = os.environ.get("DL_PAIR_GEMMS", "1") != "0"     # A/B switch for tools: 0 = one launch per stream
+GATE_DPRE_KERNEL = os.environ.get("DL_GATE_DPRE", "1") != "0"  # A/B switch for tools: 0 = MHLA's lin2 data gradient as a zero-padded GEMM (rounds 1-4)
 
 
 def _gemm_s(xs, ws, **kw):
@@ -595,9 +596,11 @@ class TokenGateFn(torch.autograd.Function):
         dv_gate, dlogits = ops.token_gate_bwd(dout.contiguous(), v2.reshape(B, L, D), gate, H, add_residual)
         dl2 = dlogits.reshape(M, H)
         dw2, db2 = _wgrad(dl2, hid, H, dd, M, H, dd)
-        if cdt == torch.bfloat16 and H <= 64 and dd % 8 == 0:
-            # K = H (8) is far below one k-step: zero-pad the contraction to 64 so that the product takes the
-            # LDS-DMA large-tile kernel with the gelu' epilogue (was 219 us in the register-staged general path)
+        if GATE_DPRE_KERNEL and H == 8 and dd % 8 == 0 and dd <= 2048 and dl2.is_contiguous():
+            # an inner dimension of 8: one elementwise pass (dl_gate_dpre) — rounds 1-4 zero-padded it to a 64-deep k-step for
+            # dl_gemm's gelu' epilogue: 77 us + 46 us of padding launches per MHLA block at batch 256
+            dpre = ops.gate_dpre(dl2, lw2, pre)
+        elif cdt == torch.bfloat16 and H <= 64 and dd % 8 == 0:
             dl2p = torch.zeros((M, 64), dtype=cdt, device=dl2.device)
             dl2p[:, :H] = dl2
             w2t = lowp((ctx.w2,), cdt, transpose=True, pad=(64, dd))           # [dd][64] image of W2^T

@@ -687,6 +687,17 @@ def bn_tail_fix(dy2d, y2d, mean, rstd, gamma, sums, inv_n, w, win, lead):
     return dy2d
 
 
+def gate_dpre(dl2d, w2, pre2d):
+    """dpre = gelu'(pre) o (dl @ w2): dl (M, 8), w2 (8, d_diff), pre (M, d_diff), all in one compute dtype (dl_gate_dpre)."""
+    _need_gpu(dl2d, w2, pre2d)
+    M, H = dl2d.shape
+    dd = pre2d.shape[1]
+    out = torch.empty_like(pre2d)
+    check(_lib.lib().dl_gate_dpre(dl2d.data_ptr(), w2.data_ptr(), pre2d.data_ptr(), out.data_ptr(), M, dd, H, _dt(pre2d), _stream()),
+          "dl_gate_dpre")
+    return out
+
+
 def gelu_bwd(dy2d, pre2d):
     dx = torch.empty_like(dy2d)
     check(_lib.lib().dl_gelu_bwd(dy2d.data_ptr(), pre2d.data_ptr(), dx.data_ptr(), dy2d.numel(), _dt(dy2d), _stream()),

@@ -314,6 +314,11 @@ int dl_token_gate_fwd(const void* v, const void* logits, void* out, float* gate_
 int dl_token_gate_bwd(const void* dout, const void* v, const float* gate, void* dv, void* dlogits,
                       int64_t B, int64_t L, int64_t D, int32_t H, int32_t add_residual,
                       int32_t dtype, dl_stream s);
+/* Gradient of MHLA's lin2 input through the GELU in front of it (encoder.py:127-140: logits = lin2(gelu(lin1 v))):
+ * dpre[m][n] = gelu'(pre[m][n]) * sum_{h < H} dlogits[m][h] * w2[h][n], w2 = lin2.weight [H][d_diff] in the compute dtype.
+ * An inner dimension of H = 8: one elementwise pass over `pre` instead of a zero-padded 64-deep GEMM (round 5). */
+int dl_gate_dpre(const void* dlogits, const void* w2, const void* pre, void* dpre, int64_t M, int64_t d_diff, int32_t H,
+                 int32_t dtype, dl_stream s);
 
 /* ------------------------------------------------------------------------------------------
  * Stream concatenation of the PMMA encoder (model/PMMA/encoder.py:50: `cat((prot, mol), -1)` before

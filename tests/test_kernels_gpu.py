@@ -645,6 +645,24 @@ def test_attention_with_key_multiplicities_equals_the_attention_over_the_expande
     assert rel(dkvc[:, :lead], dkvf[:, :lead]) <= tol
 
 
+@pytest.mark.parametrize("dt,M,dd", [(torch.bfloat16, 65536, 1024), (torch.float32, 1000, 1024), (torch.bfloat16, 777, 64), (torch.float32, 33, 2048)])
+def test_gate_dpre_against_fp64(dt, M, dd):
+    """dl_gate_dpre (round 5: MHLA's lin2 data gradient + the GELU derivative as one elementwise pass) against
+    gelu'(pre) * (dl @ w2) in fp64; bf16 uses the pipeline's rational gelu' (1e-4 absolute)."""
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(5)
+    dl = torch.randn(M, 8, generator=g).to("cuda:0", dt)
+    w2 = (torch.randn(8, dd, generator=g) * 0.2).to("cuda:0", dt)
+    pre = (torch.randn(M, dd, generator=g) * 1.5).to("cuda:0", dt)
+    out = ops.gate_dpre(dl, w2, pre)
+    x = pre.double()
+    gp = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    ref = gp * (dl.double() @ w2.double())
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    assert err <= (1.2e-2 if dt == torch.bfloat16 else 2e-6), err
+    assert torch.equal(out, ops.gate_dpre(dl, w2, pre))
+
+
 @pytest.mark.parametrize("dt,R,C,win", [(torch.bfloat16, 5000, 128, (0, 0, 0)), (torch.bfloat16, 4 * 2312, 128, (2312, 4, 2304)),
                                        (torch.float32, 777, 72, (0, 0, 0)), (torch.bfloat16, 3000, 96, (0, 0, 0)),
                                        (torch.bfloat16, 9000, 256, (0, 0, 0))])
