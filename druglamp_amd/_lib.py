@@ -130,6 +130,8 @@ SIGNATURES = {
     "dl_bn_apply_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "dl_bn_bwd_reduce": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "dl_bn_tail_fix": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "dl_bn_apply_relu_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp]),
+    "dl_bn_relu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_sz, c_vp]),
     "dl_bn_bwd_apply": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64,
                                 c_i32, c_vp]),
     "dl_layernorm_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_f32, c_i32, c_vp]),
@@ -180,6 +182,9 @@ SIGNATURES = {
     "dl_rows_gather": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "dl_rows_sum_strided": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp]),
     "dl_rows_equal_check": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i64, C.c_uint32, c_vp, c_vp]),
+    "dl_ce_rows_workspace_bytes": (c_sz, [c_i64]),
+    "dl_ce_rows_fwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "dl_ce_rows_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "dl_protein_plan_build": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dl_prof_enable": (c_i32, [c_i32, c_i32]),
     "dl_prof_collect": (c_i32, [c_i32, C.POINTER(c_i64), C.POINTER(C.c_double), C.POINTER(C.c_double),

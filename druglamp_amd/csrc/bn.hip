@@ -27,10 +27,13 @@ __device__ __forceinline__ float row_weight(const float* __restrict__ rw, int64_
 }
 
 // grid (ceil(C/256), chunks); lane -> 4 columns; MODE 0: (w y, w y^2); MODE 1: (dz, dz*yhat) over the rows with w >= 0
+// prelu_g / prelu_b (MODE 1 only, round 5): gamma / beta of a BatchNorm whose output went through a ReLU (Linear -> BN -> ReLU of
+// the SimSiam MLPs): the incoming gradient counts only where z = (y - mean) rstd gamma + beta > 0.
 template <typename T, int MODE>
 __global__ void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const float* __restrict__ mean,
                                   const float* __restrict__ rstd, int64_t R, int C, int64_t win, int64_t halo,
-                                  int64_t valid, const float* __restrict__ rw, float* __restrict__ partial, int rows_per_block) {
+                                  int64_t valid, const float* __restrict__ rw, float* __restrict__ partial, int rows_per_block,
+                                  const float* __restrict__ prelu_g = nullptr, const float* __restrict__ prelu_b = nullptr) {
   __shared__ f32x4 red[2][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 256 + lane * 4;
@@ -38,16 +41,23 @@ __global__ void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__
   const int64_t r1 = min(R, r0 + rows_per_block);
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
   if (c < C) {
-    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f};
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f}, pg = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + c); rs = *reinterpret_cast<const f32x4*>(rstd + c); }
+    const bool prelu = MODE == 1 && prelu_g != nullptr;
+    if (prelu) { pg = *reinterpret_cast<const f32x4*>(prelu_g + c); pb = *reinterpret_cast<const f32x4*>(prelu_b + c); }
     for (int64_t r = r0 + wave; r < r1; r += 4) {
       const float wr = row_weight(rw, r, win, halo, valid);
       if (MODE == 0 ? wr <= 0.f : wr < 0.f) continue;
-      const f32x4 v = load4<T>(a + r * C + c);
+      f32x4 v = load4<T>(a + r * C + c);
       if (MODE == 0) { const f32x4 t = v * wr; s0 += t; s1 += t * v; }      // (wr = 1: the plain sums, bit for bit)
       else {
         const f32x4 yv = load4<T>(y + r * C + c);
-        s0 += v; s1 += v * ((yv - mu) * rs);
+        const f32x4 yh = (yv - mu) * rs;
+        if (prelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (yh[e] * pg[e] + pb[e] > 0.f) ? v[e] : 0.f;
+        }
+        s0 += v; s1 += v * yh;
       }
     }
   }
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(256) void bn_partial_wide_kernel(const bf16_t* __re
   }
 }
 
-template <typename T>
+template <typename T, bool RELU = false>
 __global__ void bn_apply_fwd_kernel(const T* __restrict__ y, T* __restrict__ z, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, int64_t R, int C, int64_t win, int64_t halo,
@@ -138,6 +148,10 @@ __global__ void bn_apply_fwd_kernel(const T* __restrict__ y, T* __restrict__ z, 
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
     o = (v - mu) * rs * g + b;
+    if constexpr (RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+    }
   }
   store4<T>(z + r * C + c, o);
 }
@@ -146,7 +160,8 @@ template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const float* __restrict__ sums, float inv_n, int relu_mask, T* __restrict__ dy,
-                                    int64_t R, int C, int64_t win, int64_t halo, int64_t valid, const float* __restrict__ rw) {
+                                    int64_t R, int C, int64_t win, int64_t halo, int64_t valid, const float* __restrict__ rw,
+                                    const float* __restrict__ prelu_b = nullptr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;          // R * C / 4 < 2^32 is checked by the host
   const uint32_t c4 = (uint32_t)C >> 2;
   if (i >= (uint32_t)R * c4) return;
@@ -155,11 +170,17 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restric
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
   const float wr = row_weight(rw, r, win, halo, valid);
   if (wr >= 0.f) {
-    const f32x4 d = load4<T>(dz + r * C + c), yv = load4<T>(y + r * C + c);
+    f32x4 d = load4<T>(dz + r * C + c);
+    const f32x4 yv = load4<T>(y + r * C + c);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
     const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c), s1 = *reinterpret_cast<const f32x4*>(sums + C + c);
     const f32x4 yh = (yv - mu) * rs;
+    if (prelu_b) {                                   // BatchNorm -> ReLU: the incoming gradient counts where the ReLU was open
+      const f32x4 pb = *reinterpret_cast<const f32x4*>(prelu_b + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = (yh[e] * g[e] + pb[e] > 0.f) ? d[e] : 0.f;
+    }
     // a row that stands for wr identical rows takes the mean terms wr times (its dz is the sum over those rows)
     if (rw) o = g * rs * (d - (s0 * inv_n + yh * (s1 * inv_n)) * wr);
     else o = g * rs * (d - s0 * inv_n - yh * (s1 * inv_n));
@@ -565,5 +586,56 @@ extern "C" int dl_bn_stats_finalize(const void* y, int64_t R, int64_t C, int64_t
   hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((uint32_t)((C + 7) / 8)), dim3(1024), 0, s, (const float*)ws, chunks, (int)C,
                      (float)(1.0 / (double)n), unbias, eps, momentum, sums, mean, var, rstd, running_mean, running_var);
   DL_CHECK_LAUNCH("dl_bn_stats_finalize");
+  return DL_OK;
+}
+
+// ---- BatchNorm followed by ReLU (round 5: the Linear -> BatchNorm1d -> ReLU stages of the SimSiam projector / predictor MLPs,
+// model/self_supervised_learning.py:126-166; through round 4 the ReLU and its backward were torch launches over the 131072 x 512
+// activations: 0.77 ms of an SSL-epoch step at batch 256).  z = max(0, BN(y)); the backward passes recompute the ReLU's open set
+// from y (z > 0 <=> (y - mean) rstd gamma + beta > 0), so nothing extra is saved. ----------------------------------------------
+extern "C" int dl_bn_apply_relu_fwd(const void* y, void* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                    int64_t R, int64_t C, int32_t dtype, dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(R < (1ll << 31) && R * (C / 4) < (1ll << 32), DL_ERR_SHAPE, "dl_bn_apply_relu_fwd: R * C / 4 must fit 32 bits");
+  DL_CHECK_ARG(y && z && mean && rstd && gamma && beta && R > 0 && C > 0 && C % 4 == 0, DL_ERR_ARG, "dl_bn_apply_relu_fwd: bad args");
+  const uint32_t blocks = (uint32_t)((R * (C / 4) + 255) / 256);
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((bn_apply_fwd_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)z, mean, rstd, gamma,
+                       beta, R, (int)C, (int64_t)0, (int64_t)0, (int64_t)0, (const float*)nullptr);
+  else if (dtype == DL_F32)
+    hipLaunchKernelGGL((bn_apply_fwd_kernel<float, true>), dim3(blocks), dim3(256), 0, s, (const float*)y, (float*)z, mean, rstd, gamma,
+                       beta, R, (int)C, (int64_t)0, (int64_t)0, (int64_t)0, (const float*)nullptr);
+  else { dl_set_error("dl_bn_apply_relu_fwd: bad dtype"); return DL_ERR_ARG; }
+  DL_CHECK_LAUNCH("dl_bn_apply_relu_fwd");
+  return DL_OK;
+}
+
+extern "C" int dl_bn_relu_bwd(const void* dz, const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              float inv_n, void* dy, float* sums, int64_t R, int64_t C, int32_t dtype, void* ws, size_t ws_bytes,
+                              dl_stream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  DL_CHECK_ARG(dz && y && mean && rstd && gamma && beta && dy && sums && R > 0 && C > 0 && C % 4 == 0, DL_ERR_ARG, "dl_bn_relu_bwd: bad args");
+  DL_CHECK_ARG(R < (1ll << 31) && R * (C / 4) < (1ll << 32), DL_ERR_SHAPE, "dl_bn_relu_bwd: R * C / 4 must fit 32 bits");
+  DL_CHECK_ARG(dtype == DL_BF16 || dtype == DL_F32, DL_ERR_ARG, "dl_bn_relu_bwd: bad dtype");
+  DL_CHECK_ARG(ws && ws_bytes >= dl_bn_workspace_bytes(R, C), DL_ERR_WORKSPACE, "dl_bn_relu_bwd: workspace too small");
+  const int rpb = bn_rows_per_block(R, C);
+  const int chunks = (int)((R + rpb - 1) / rpb);
+  dim3 grid((uint32_t)((C + 255) / 256), (uint32_t)chunks);
+  const uint32_t blocks = (uint32_t)((R * (C / 4) + 255) / 256);
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, mean, rstd, R, (int)C,
+                       (int64_t)0, (int64_t)0, (int64_t)0, (const float*)nullptr, (float*)ws, rpb, gamma, beta);
+  else
+    hipLaunchKernelGGL((bn_partial_kernel<float, 1>), grid, dim3(256), 0, s, (const float*)dz, (const float*)y, mean, rstd, R, (int)C,
+                       (int64_t)0, (int64_t)0, (int64_t)0, (const float*)nullptr, (float*)ws, rpb, gamma, beta);
+  hipLaunchKernelGGL(dl_reduce_partials_kernel, dim3((uint32_t)((2 * C + DL_REDUCE_COLS - 1) / DL_REDUCE_COLS)), dim3(1024), 0, s, (const float*)ws,
+                     chunks, (int64_t)(2 * C), (int)(2 * C), sums, 0);
+  if (dtype == DL_BF16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, mean, rstd, gamma,
+                       (const float*)sums, inv_n, 0, (bf16_t*)dy, R, (int)C, (int64_t)0, (int64_t)0, (int64_t)0, (const float*)nullptr, beta);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)dz, (const float*)y, mean, rstd, gamma,
+                       (const float*)sums, inv_n, 0, (float*)dy, R, (int)C, (int64_t)0, (int64_t)0, (int64_t)0, (const float*)nullptr, beta);
+  DL_CHECK_LAUNCH("dl_bn_relu_bwd");
   return DL_OK;
 }

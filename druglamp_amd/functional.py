@@ -707,6 +707,27 @@ class CosRowLossFn(torch.autograd.Function):
         return dx * drows.unsqueeze(-1), None
 
 
+class CrossEntropyRowsFn(torch.autograd.Function):
+    """F.cross_entropy(logits[:, :C], labels, ignore_index) -> scalar (fp32) over the rows of a 2-d logits tensor whose row may
+    be wider than C (the GEMM in front pads 27 classes to 32 columns: no slice copy).  Mean over the rows whose label is not
+    ignore_index, fixed summation order (dl_ce_rows_*, round 5)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, C, ignore_index):
+        logits = logits if logits.stride(-1) == 1 else logits.contiguous()
+        labels = labels.reshape(-1).contiguous()
+        out2, lse = ops.ce_rows_fwd(logits, labels, C, ignore_index)
+        ctx.save_for_backward(logits, labels, lse, out2)
+        ctx.cfg = (C, ignore_index)
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, lse, out2 = ctx.saved_tensors
+        C, ignore_index = ctx.cfg
+        return ops.ce_rows_bwd(logits, labels, C, ignore_index, lse, out2, g.float().contiguous()), None, None, None
+
+
 class NTXentFn(torch.autograd.Function):
     """nt_xent_loss(q, k, T) (self_supervised_learning.py:168-182), streaming: no (2n)^2 matrix.  Rows keep their dtype
     (bf16 rows run on the bf16 matrix pipe; log-sum-exp, loss and gradients are fp32).
@@ -1221,7 +1242,9 @@ class BatchNormRowsFn(torch.autograd.Function):
     Returns (y, mean, var) with biased variance; running-stat bookkeeping stays with the caller."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, training, eps, momentum):
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, eps, momentum, relu=False):
+        """relu=True (round 5): the ReLU behind the BatchNorm in the same kernels (z = max(0, BN(x)); the backward recomputes the
+        ReLU's open set from x): Linear -> BatchNorm1d -> ReLU of the SimSiam MLPs without torch's clamp / threshold launches."""
         R, C = x.shape
         x = x.contiguous()
         if training:
@@ -1231,24 +1254,27 @@ class BatchNormRowsFn(torch.autograd.Function):
         else:
             mean, var = rmean.detach().float(), rvar.detach().float()
             rstd = torch.rsqrt(var + eps)
-        g = gamma.detach().float()
-        y = ops.bn_apply_fwd(x, mean, rstd, g, beta.detach().float(), 0, 0, 0)
-        ctx.save_for_backward(x, mean, rstd, g)
-        ctx.training = training
+        g, b = gamma.detach().float(), beta.detach().float()
+        y = ops.bn_apply_relu_fwd(x, mean, rstd, g, b) if relu else ops.bn_apply_fwd(x, mean, rstd, g, b, 0, 0, 0)
+        ctx.save_for_backward(x, mean, rstd, g, b if relu else None)
+        ctx.training, ctx.relu = training, relu
         ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)       # no zero-filled gradients for the non-differentiable outputs
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _m, _v):
-        x, mean, rstd, g = ctx.saved_tensors
+        x, mean, rstd, g, b = ctx.saved_tensors
         if not ctx.training:
             raise RuntimeError("BatchNormRowsFn.backward: eval-mode backward is not implemented")
         R, C = x.shape
         dy = dy.contiguous()
-        sums = ops.bn_bwd_reduce(dy, x, mean, rstd, 0, 0, 0)
-        dx = ops.bn_bwd_apply(dy, x, mean, rstd, g, sums, 1.0 / R, False, 0, 0, 0)
-        return dx, sums[C:], sums[:C], None, None, None, None, None
+        if ctx.relu:
+            dx, sums = ops.bn_relu_bwd(dy, x, mean, rstd, g, b, 1.0 / R)
+        else:
+            sums = ops.bn_bwd_reduce(dy, x, mean, rstd, 0, 0, 0)
+            dx = ops.bn_bwd_apply(dy, x, mean, rstd, g, sums, 1.0 / R, False, 0, 0, 0)
+        return dx, sums[C:], sums[:C], None, None, None, None, None, None
 
 
 class BatchNormWeightedTailFn(torch.autograd.Function):
@@ -1356,8 +1382,8 @@ def bn_tick(counter: torch.Tensor) -> None:
             counter += 1
 
 
-def batch_norm_rows(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor) -> torch.Tensor:
-    """nn.BatchNorm1d semantics (incl. running statistics, momentum, unbiased running variance)."""
+def batch_norm_rows(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor, relu: bool = False) -> torch.Tensor:
+    """nn.BatchNorm1d semantics (incl. running statistics, momentum, unbiased running variance); relu: max(0, .) behind it."""
     C = x2d.shape[1]
     if bn.training and x2d.shape[0] <= 1:
         # torch.nn.functional.batch_norm's own check and message: batch statistics of ONE row are meaningless (the
@@ -1366,7 +1392,7 @@ def batch_norm_rows(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor) -> torch.Tensor
     w = bn.weight if bn.weight is not None else torch.ones(C, device=x2d.device)      # affine=False
     b = bn.bias if bn.bias is not None else torch.zeros(C, device=x2d.device)
     y, mean, var = BatchNormRowsFn.apply(x2d, w, b, bn.running_mean, bn.running_var, bn.training, bn.eps,
-                                         bn.momentum if bn.training else None)
+                                         bn.momentum if bn.training else None, relu)
     if bn.training:
         bn_tick(bn.num_batches_tracked)        # running mean / var were updated by dl_bn_finalize
     return y
@@ -1378,7 +1404,10 @@ def run_mlp(seq, x: torch.Tensor) -> torch.Tensor:
     (DenseFn: widths padded to multiples of 8, K' may carry zero padding columns), every BatchNorm1d the dl_bn_*
     kernels incl. the running-statistics update.  The modules stay plain torch parameter holders."""
     import torch.nn as nn
-    for layer in seq:
+    layers = list(seq)
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
         if isinstance(layer, nn.Linear):
             if x.shape[-1] < layer.in_features:
                 raise ValueError("run_mlp: input narrower than the layer")
@@ -1386,9 +1415,12 @@ def run_mlp(seq, x: torch.Tensor) -> torch.Tensor:
         elif isinstance(layer, nn.BatchNorm1d):
             if x.shape[-1] != layer.num_features:
                 x = x[:, :layer.num_features].contiguous()
-            x = batch_norm_rows(layer, x)
+            fuse = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)      # BatchNorm1d -> ReLU: one kernel each way
+            x = batch_norm_rows(layer, x, relu=fuse)
+            i += 1 if fuse else 0
         elif isinstance(layer, nn.ReLU):
             x = torch.relu(x)
         else:
             raise NotImplementedError("run_mlp: %s" % type(layer).__name__)
+        i += 1
     return x

@@ -226,7 +226,10 @@ class ProteinCNN(nn.Module):
             return z
         x = EmbedPadFn.apply(ids, wc, fill_mask, self.embedding.padding_idx)        # (B, L + 2*HALO, C) channel-last
         C = x.shape[-1]
-        fused_pool = int(site_pool) if (site_pool and x.dtype == torch.bfloat16 and L % int(site_pool) == 0) else 0
+        # the reference's `.view(B, L, C)` of the channel-first buffer (+ the caller's site pooling) inside the tail kernel; without
+        # site pooling (the masked-LM pass of the SSL epochs) that is site_len = 1: the reinterpretation alone, one launch each
+        # way (round 5; two 150 MB torch copies per direction before: 0.5 ms of an SSL-epoch step at batch 256)
+        fused_pool = (int(site_pool) or 1) if (x.dtype == torch.bfloat16 and L % (int(site_pool) or 1) == 0) else 0
         outs = ProteinCNNFn.apply(x, self.training, self.bn1.eps, fused_pool, momenta, True, None, 0, *params)
         z = outs[0]
         if self.training:

@@ -139,13 +139,14 @@ class SSL(nn.Module):
 
         def head(lin, h):
             # nn.Linear on the HIP GEMM path (DenseFn: output padded to 32 columns, input may carry zero padding)
-            return Fn.dense(_on_hip(h, "SSL.prot_mlm"), lin.weight, lin.bias)[..., :n_cls]
+            return Fn.dense(_on_hip(h, "SSL.prot_mlm"), lin.weight, lin.bias)
 
         def ce(lg):
             # the reference's F.cross_entropy(logits.transpose(1, 2), labels, ignore_index=0) (:93-99) = mean over the
-            # non-ignored tokens of the batch; taken here over the flattened (B*L, C) rows: same value, but torch's
-            # (B, C, L) form (nll_loss2d) sums with atomics and differs in the last bit from run to run
-            return F.cross_entropy(lg.float().reshape(-1, lg.shape[-1]), labels.reshape(-1), ignore_index=pad_token_id)
+            # non-ignored tokens of the batch, over the flattened (B*L, 32) rows of the padded head output (27 classes):
+            # dl_ce_rows_* (round 5; torch's log_softmax + nll_loss took 0.9 ms per head at batch 256 — nll_loss reduces the
+            # 590 k rows in one workgroup — plus the slice / fp32 copies in front of it), fixed summation order
+            return Fn.CrossEntropyRowsFn.apply(lg.reshape(-1, lg.shape[-1]), labels, n_cls, pad_token_id)
 
         if mode != "xp":
             loss = loss + ce(head(self.to_logits, extractor(masked_seq, fill_bit)))

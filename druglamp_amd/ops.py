@@ -678,6 +678,28 @@ def bn_bwd_apply(dz2d, y2d, mean, rstd, gamma, sums, inv_n, relu_mask, win, halo
     return dy
 
 
+def bn_apply_relu_fwd(y2d, mean, rstd, gamma, beta):
+    """z = max(0, BN(y)) (dl_bn_apply_relu_fwd)."""
+    R, Cc = y2d.shape
+    z = torch.empty_like(y2d)
+    check(_lib.lib().dl_bn_apply_relu_fwd(y2d.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                          R, Cc, _dt(y2d), _stream()), "dl_bn_apply_relu_fwd")
+    return z
+
+
+def bn_relu_bwd(dz2d, y2d, mean, rstd, gamma, beta, inv_n):
+    """Backward of z = max(0, BN(y)): (dy, sums [2C] = (d beta | d gamma)) (dl_bn_relu_bwd)."""
+    R, Cc = y2d.shape
+    L = _lib.lib()
+    dy = torch.empty_like(y2d)
+    sums = torch.empty(2 * Cc, dtype=torch.float32, device=y2d.device)
+    ws = _ws2.get(L.dl_bn_workspace_bytes(R, Cc), y2d.device)
+    check(L.dl_bn_relu_bwd(dz2d.data_ptr(), y2d.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                           float(inv_n), dy.data_ptr(), sums.data_ptr(), R, Cc, _dt(y2d), ws.data_ptr(), ws.numel(), _stream()),
+          "dl_bn_relu_bwd")
+    return dy, sums
+
+
 def bn_tail_fix(dy2d, y2d, mean, rstd, gamma, sums, inv_n, w, win, lead):
     """In place: the tail rows of every `win`-row window take the mean terms of the BatchNorm backward w times (dl_bn_tail_fix)."""
     R, Cc = y2d.shape
@@ -685,6 +707,28 @@ def bn_tail_fix(dy2d, y2d, mean, rstd, gamma, sums, inv_n, w, win, lead):
                                     sums.data_ptr(), float(inv_n), int(w), R, Cc, int(win), int(lead), _dt(y2d), _stream()),
           "dl_bn_tail_fix")
     return dy2d
+
+
+def ce_rows_fwd(logits2d, labels, C: int, ignore_index: int):
+    """Cross entropy over the first C columns of logits2d (N, >= C) (dl_ce_rows_fwd): (out2 = [mean loss, counted rows], lse (N,))."""
+    _need_gpu(logits2d, labels)
+    N, ld = logits2d.shape[0], logits2d.stride(0)
+    L = _lib.lib()
+    lse = torch.empty(N, dtype=torch.float32, device=logits2d.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=logits2d.device)
+    ws = _ws2.get(L.dl_ce_rows_workspace_bytes(N), logits2d.device)
+    check(L.dl_ce_rows_fwd(logits2d.data_ptr(), ld, labels.data_ptr(), N, C, int(ignore_index), _dt(logits2d), lse.data_ptr(),
+                           out2.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dl_ce_rows_fwd")
+    return out2, lse
+
+
+def ce_rows_bwd(logits2d, labels, C: int, ignore_index: int, lse, out2, grad_out):
+    """d(mean loss) / d logits, (N, width of logits2d): zeros in the columns >= C and in ignored rows (dl_ce_rows_bwd)."""
+    N, Cp = logits2d.shape
+    d = torch.empty((N, Cp), dtype=logits2d.dtype, device=logits2d.device)
+    check(_lib.lib().dl_ce_rows_bwd(logits2d.data_ptr(), logits2d.stride(0), labels.data_ptr(), N, C, int(ignore_index), _dt(logits2d),
+                                    lse.data_ptr(), out2.data_ptr(), grad_out.data_ptr(), d.data_ptr(), Cp, Cp, _stream()), "dl_ce_rows_bwd")
+    return d
 
 
 def gate_dpre(dl2d, w2, pre2d):

@@ -213,6 +213,15 @@ int dl_bn_bwd_apply_rw(const void* dz, const void* y, const float* mean, const f
  * w - 1: dy[r] -= (w - 1) gamma rstd (S1 inv_n + xhat[r] S2 inv_n), in place, tail rows only. */
 int dl_bn_tail_fix(void* dy, const void* y, const float* mean, const float* rstd, const float* gamma, const float* sums,
                    float inv_n, int32_t w, int64_t R, int64_t C, int64_t win, int64_t lead, int32_t dtype, dl_stream s);
+/* BatchNorm1d followed by ReLU (round 5; the Linear -> BatchNorm1d -> ReLU stages of the SimSiam MLPs,
+ * model/self_supervised_learning.py:126-166): z = max(0, (y - mean) rstd gamma + beta) over rows of [R][C]; the backward takes
+ * the gradient dz with respect to z, recomputes the ReLU's open set from y, and gives sums [2C] = (d beta, d gamma) and dy
+ * (three launches: masked partial sums, their reduction, the apply pass).  workspace: dl_bn_workspace_bytes(R, C). */
+int dl_bn_apply_relu_fwd(const void* y, void* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         int64_t R, int64_t C, int32_t dtype, dl_stream s);
+int dl_bn_relu_bwd(const void* dz, const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                   float inv_n, void* dy, float* sums, int64_t R, int64_t C, int32_t dtype, void* workspace, size_t workspace_bytes,
+                   dl_stream s);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps 1e-6 inside PMMA: model/PMMA/block.py:23-27,
@@ -471,6 +480,16 @@ int dl_cos_rowloss_fwd(const float* x, const float* y, float* row_loss, float* l
                        int64_t n_rows, int64_t D, dl_stream s);
 int dl_cos_rowloss_bwd(const float* x, const float* y, float grad_scale, float* dx, int64_t n_rows,
                        int64_t D, dl_stream s);
+/* Cross entropy over rows with few classes (round 5): F.cross_entropy(logits (N, C), labels, ignore_index) of the masked-LM
+ * heads (model/self_supervised_learning.py:93-99; N = batch x 2304 tokens, C = 27).  logits [N][ld] (fp32 / bf16; ld >= C: the
+ * GEMM in front pads the row), labels int64 [N].  fwd: lse [N] (log-sum-exp per row, kept for bwd), out2[0] = mean loss over the
+ * rows whose label is not ignore_index (0 if none), out2[1] = their number; fixed summation order.  bwd: dlogits [N][ldd],
+ * columns < Cp written (softmax - onehot) * grad_out[0] / out2[1] for counted rows, zeros elsewhere; grad_out is a DEVICE scalar. */
+size_t dl_ce_rows_workspace_bytes(int64_t N);
+int dl_ce_rows_fwd(const void* logits, int64_t ld, const int64_t* labels, int64_t N, int32_t C, int64_t ignore_index, int32_t dtype,
+                   float* lse, float* out2, void* workspace, size_t workspace_bytes, dl_stream s);
+int dl_ce_rows_bwd(const void* logits, int64_t ld, const int64_t* labels, int64_t N, int32_t C, int64_t ignore_index, int32_t dtype,
+                   const float* lse, const float* out2, const float* grad_out, void* dlogits, int64_t ldd, int32_t Cp, dl_stream s);
 /* General form (round 3): the rows whose loss / gradient a call produces (side `a`, resident) are scored against a second
  * set of rows (side `b`, streamed); each side is [q rows ; k rows], n rows per half, row-major (n x d), dtype DL_F32 or
  * DL_BF16 (bf16 operands on v_mfma_f32_16x16x32_bf16, log-sum-exp / loss / gradients in fp32).  Rows are identified

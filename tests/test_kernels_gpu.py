@@ -170,7 +170,8 @@ def test_weight_images_are_refreshed_in_place_by_one_launch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,L,C,S", [(3, 2304, 128, 9), (2, 96, 64, 3), (2, 160, 128, 5)])
+@pytest.mark.parametrize("B,L,C,S", [(3, 2304, 128, 9), (2, 96, 64, 3), (2, 160, 128, 5),
+                                     (3, 2304, 128, 1), (2, 100, 64, 1)])       # S = 1: the view reinterpretation alone (the masked-LM pass)
 def test_cnn_view_and_site_pool_kernel_matches_reference_formulation(B, L, C, S):
     """dl_cnn_sitepool_fwd/bwd == (channel-first buffer).view(B, L, C).view(B, S, L/S, C).mean(1) and its
     autograd backward (basic_model.py:176-179 + DrugLAMP.py:39-40), incl. the zeroed halo rows of dz."""
@@ -643,6 +644,60 @@ def test_attention_with_key_multiplicities_equals_the_attention_over_the_expande
     # ... and the plain attention over the expanded keys agrees with the compact one to the pipeline's rounding
     assert rel(oc, of) <= tol and rel(dqc, dqf) <= tol
     assert rel(dkvc[:, :lead], dkvf[:, :lead]) <= tol
+
+
+@pytest.mark.parametrize("dt,N,C,ld", [(torch.float32, 5000, 27, 32), (torch.bfloat16, 70001, 27, 32), (torch.float32, 300, 5, 5), (torch.bfloat16, 257, 40, 48)])
+def test_cross_entropy_rows_against_torch(dt, N, C, ld):
+    """dl_ce_rows_fwd / bwd (round 5: the masked-LM heads' F.cross_entropy(logits, labels, ignore_index=0)) against torch in
+    fp64 on the same (rounded) logits: loss, gradient incl. the zero padding columns and ignored rows; all-ignored labels."""
+    from druglamp_amd import functional as Fn
+    g = torch.Generator().manual_seed(12)
+    full = (torch.randn(N, ld, generator=g) * 3).to("cuda:0", dt)
+    labels = torch.randint(0, C, (N,), generator=g).cuda()
+    labels[torch.rand(N, generator=g).cuda() < 0.6] = 0                               # ignore_index = 0, as in the MLM head
+    x = full.clone().requires_grad_(True)
+    loss = Fn.CrossEntropyRowsFn.apply(x, labels, C, 0)
+    (loss * 0.37).backward()
+    xr = full[:, :C].double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, labels, ignore_index=0)
+    (ref * 0.37).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    gtol = 1e-2 if dt == torch.bfloat16 else 2e-6
+    assert float((x.grad[:, :C].double() - xr.grad).abs().max()) <= gtol * float(xr.grad.abs().max())
+    assert torch.count_nonzero(x.grad[:, C:]) == 0 and torch.count_nonzero(x.grad[labels == 0]) == 0
+    assert float(Fn.CrossEntropyRowsFn.apply(full, labels, C, 0)) == float(loss)      # fixed summation order
+    none = Fn.CrossEntropyRowsFn.apply(full.clone().requires_grad_(True), torch.zeros_like(labels), C, 0)
+    assert float(none) == 0.0
+
+
+@pytest.mark.parametrize("dt,R,C", [(torch.float32, 3000, 512), (torch.bfloat16, 20000, 512), (torch.bfloat16, 777, 128), (torch.float32, 65, 36)])
+def test_batch_norm_relu_rows_against_torch(dt, R, C):
+    """BatchNormRowsFn(relu=True) (round 5: BatchNorm1d -> ReLU in one kernel each way) against torch's batch_norm + relu in fp64:
+    output, input / gamma / beta gradients, running statistics."""
+    from druglamp_amd import functional as Fn
+    g = torch.Generator().manual_seed(13)
+    x0 = (torch.randn(R, C, generator=g) * 1.3 + 0.2).to("cuda:0", dt)
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    dz = torch.randn(R, C, generator=g).to("cuda:0", dt)
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(gam); bn.bias.copy_(bet)
+    x = x0.clone().requires_grad_(True)
+    z = Fn.batch_norm_rows(bn, x, relu=True)
+    z.backward(dz)
+    xr = x0.double().requires_grad_(True)
+    gr, br = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    rm, rv = torch.zeros(C, dtype=torch.float64, device="cuda:0"), torch.ones(C, dtype=torch.float64, device="cuda:0")
+    zr = torch.relu(torch.nn.functional.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5))
+    zr.backward(dz.double())
+    tol = 2e-2 if dt == torch.bfloat16 else 2e-5
+    rel = lambda a, b: float((a.double() - b).abs().max() / (b.abs().max() + 1e-30))     # noqa: E731
+    assert rel(z, zr.detach()) <= tol
+    # (an element whose normalised value sits within rounding of the ReLU kink may open on one side only: compare in aggregate)
+    assert float((x.grad.double() - xr.grad).norm() / xr.grad.norm()) <= tol
+    assert rel(bn.weight.grad, gr.grad) <= tol and rel(bn.bias.grad, br.grad) <= tol
+    assert rel(bn.running_mean, rm) <= max(tol, 1e-5) and rel(bn.running_var, rv) <= max(tol, 1e-5)
+    assert bool((z >= 0).all())
 
 
 @pytest.mark.parametrize("dt,M,dd", [(torch.bfloat16, 65536, 1024), (torch.float32, 1000, 1024), (torch.bfloat16, 777, 64), (torch.float32, 33, 2048)])

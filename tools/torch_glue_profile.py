@@ -12,13 +12,14 @@ cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP")
 model = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
 trainer = Trainer(model, cfg, device=dev, compute_dtype=torch.bfloat16)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+EPOCH = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # 5: an SSL-epoch step (cls forward + SSL heads)
 batch, meta = make_batch(B, dev, seed=100, with_graph=True, llm_dtype=torch.bfloat16)
 for _ in range(3):
-    trainer.training_step(batch, meta=meta, cur_epoch=1)
+    trainer.training_step(batch, meta=meta, cur_epoch=EPOCH)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True,
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
-    trainer.training_step(batch, meta=meta, cur_epoch=1)
+    trainer.training_step(batch, meta=meta, cur_epoch=EPOCH)
     torch.cuda.synchronize()
 agg = defaultdict(lambda: [0.0, 0])
 for ev in prof.events():
