@@ -1342,10 +1342,15 @@ class ExpandTailFn(torch.autograd.Function):
 
 
 def batch_norm_rows_weighted_tail(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor, LP: int, lead: int, w: int) -> torch.Tensor:
-    """batch_norm_rows for the compact MolecularGCN layout (training mode; eval mode is row-wise and needs no weights)."""
+    """batch_norm_rows for the compact layouts of the drug branch (MolecularGCN; the SimSiam MLPs of the SSL head): inside every
+    window of LP rows the rows from `lead` on stand for w identical rows each (training mode; eval mode is row-wise and needs no
+    weights)."""
     if not bn.training:
         return batch_norm_rows(bn, x2d)
-    y, _mean, _var = BatchNormWeightedTailFn.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+    C = x2d.shape[1]
+    gam = bn.weight if bn.weight is not None else torch.ones(C, device=x2d.device)      # affine=False
+    bet = bn.bias if bn.bias is not None else torch.zeros(C, device=x2d.device)
+    y, _mean, _var = BatchNormWeightedTailFn.apply(x2d, gam, bet, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
                                                  LP, lead, w)
     bn_tick(bn.num_batches_tracked)
     return y
@@ -1398,11 +1403,14 @@ def batch_norm_rows(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor, relu: bool = Fa
     return y
 
 
-def run_mlp(seq, x: torch.Tensor) -> torch.Tensor:
+def run_mlp(seq, x: torch.Tensor, tail=None) -> torch.Tensor:
     """An nn.Sequential of Linear / BatchNorm1d / ReLU (the SimSiam projector and predictor MLPs,
     self_supervised_learning.py:126-143) applied to rows x [M, K'] on the HIP path: every Linear is a dl_gemm
     (DenseFn: widths padded to multiples of 8, K' may carry zero padding columns), every BatchNorm1d the dl_bn_*
-    kernels incl. the running-statistics update.  The modules stay plain torch parameter holders."""
+    kernels incl. the running-statistics update.  The modules stay plain torch parameter holders.
+    tail = (LP, lead, w) (round 5): x holds the DISTINCT rows of the drug branch — windows of LP rows whose rows from `lead` on
+    stand for w identical rows each; the BatchNorm layers then take their batch statistics (and the mean terms of their
+    backward) with those multiplicities, everything else is row-wise."""
     import torch.nn as nn
     layers = list(seq)
     i = 0
@@ -1415,9 +1423,12 @@ def run_mlp(seq, x: torch.Tensor) -> torch.Tensor:
         elif isinstance(layer, nn.BatchNorm1d):
             if x.shape[-1] != layer.num_features:
                 x = x[:, :layer.num_features].contiguous()
-            fuse = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)      # BatchNorm1d -> ReLU: one kernel each way
-            x = batch_norm_rows(layer, x, relu=fuse)
-            i += 1 if fuse else 0
+            if tail is not None and layer.training:
+                x = batch_norm_rows_weighted_tail(layer, x, *tail)
+            else:
+                fuse = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)      # BatchNorm1d -> ReLU: one kernel each way
+                x = batch_norm_rows(layer, x, relu=fuse)
+                i += 1 if fuse else 0
         elif isinstance(layer, nn.ReLU):
             x = torch.relu(x)
         else:

@@ -37,6 +37,7 @@ class DrugLAMP(DrugLAMPBase):
         vtail = getattr(vd, "_dl_tail", None)                                   # (distinct rows, multiplicity) of the compact forms
         xpc, xdc = self._llm_adaptors(xp, xd, hints.drug_tokens if hints is not None else 0)
         xtail = getattr(xdc, "_dl_tail", None)
+        ssl["drug_rows"] = self._ssl_drug_rows(vtail, xtail)
         vpf = vpc.float()                                                       # fp32 copies only for the returned tuple
         cp = {"prot": vpf, "aug_prot": xpc.float(), "drug": vd.float(), "aug_drug": xdc.float()} if self.two_c2p else None
         mv, self.A_v_gca = self._gca_branch(self.v_gca, self.v_mhla, self.v_gca_norm, vpc, vdc, raw=(hints is None or hints.raw_attention), tail=vtail)
@@ -78,7 +79,8 @@ class DrugLAMP(DrugLAMPBase):
         with torch.cuda.stream(sc):              # branch c: drug LLM adaptor
             xdc = self._drug_adaptor(xdp, hints.drug_tokens if hints is not None else 0)
             xtail = getattr(xdc, "_dl_tail", None)
-        ssl = {"vp": vp, "xp": (xp, fill_p), "fill_bit_p": fill_p, "vd": vd, "xd": (xdp, xd.shape[-1] + 1)}
+        ssl = {"vp": vp, "xp": (xp, fill_p), "fill_bit_p": fill_p, "vd": vd, "xd": (xdp, xd.shape[-1] + 1),
+               "drug_rows": self._ssl_drug_rows(vtail, xtail)}
         vpc = self.protein_extractor(vp, fill_p, site_pool=self.site_len, plan=self._protein_plan(hints, vp))   # main stream
         # v branch (needs the CNN and the GCN) continues on stream a; the x branch (needs both adaptors) runs on the main
         # stream behind the CNN — side streams only ever fork from and join the main stream (a side-to-side dependency made

@@ -393,6 +393,13 @@ class DrugLAMPBase(nn.Module):
         m = Fn.layer_norm(m, norm.weight, norm.bias, norm.eps)
         return m, raw
 
+    def _ssl_drug_rows(self, vtail, xtail):
+        """The block size behind which BOTH drug tensors of the SSL head (MolecularGCN output, fill-augmented LLM features) are
+        identical padding rows — known when both came through the compact padding forms — or None."""
+        if vtail is None or xtail is None or not self.compact_keys:
+            return None
+        return max(vtail[0].shape[1], xtail[0].shape[1]) - _TAIL_ROWS
+
     def _llm_adaptors(self, xp_cat, xd_cat, drug_tokens: int = 0):
         """xp_cat: site-pooled protein LLM features + fill bit, zero-padded (B, 256, 648); xd_cat: drug LLM
         features + fill bit, zero-padded (B, 512, 392) — both straight from ops.fill_pool, compute dtype.

@@ -7,7 +7,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import functional as Fn
 
@@ -61,11 +60,12 @@ class SimProj(nn.Module):
         self.projection_out = projection_out
         self.projection_hidden_size = projection_hidden_size
 
-    def forward(self, x, in_dim=None):
-        """x may carry zero padding columns beyond in_dim (the fill-bit-augmented LLM features are 385 -> 392 wide)."""
+    def forward(self, x, in_dim=None, tail=None):
+        """x may carry zero padding columns beyond in_dim (the fill-bit-augmented LLM features are 385 -> 392 wide).
+        tail: the row multiplicities of the compact drug layout (functional.run_mlp)."""
         if self.projector is None:
             self.projector = _simsiam_mlp(in_dim or x.shape[1], self.projection_out, self.projection_hidden_size).to(x.device)
-        return Fn.run_mlp(self.projector, _on_hip(x, "SimProj"))
+        return Fn.run_mlp(self.projector, _on_hip(x, "SimProj"), tail)
 
 
 class SSL(nn.Module):
@@ -106,8 +106,8 @@ class SSL(nn.Module):
         one, two = Fn.cast(_on_hip(one, "SSL"), self.compute_dtype), Fn.cast(_on_hip(two, "SSL"), self.compute_dtype)
         return one, two, xd_dim
 
-    def _predict(self, x):
-        return Fn.run_mlp(self.predictor, _on_hip(x, "SSL.predictor"))
+    def _predict(self, x, tail=None):
+        return Fn.run_mlp(self.predictor, _on_hip(x, "SSL.predictor"), tail)
 
     def drug_simclr(self, vd, xd):
         one, two, xd_dim = self._rows(vd, xd)
@@ -116,15 +116,33 @@ class SSL(nn.Module):
         # rows stay in the compute dtype: bf16 rows take the bf16 matrix pipe, log-sum-exp / loss / gradients are fp32
         return Fn.NTXentFn.apply(q, k, self.temperature, self.global_batch)
 
-    def drug_simsiam(self, vd, xd):
+    def drug_simsiam(self, vd, xd, drug_rows=None):
+        """drug_rows = lead (round 5, from the model's forward when both drug tensors come from compact padding forms): rows
+        lead .. 511 of every molecule are identical in vd AND in xd (virtual GCN nodes / zero token rows).  The SimSiam MLPs
+        and the row loss then run on rows 0 .. lead + 7 only, the last 8 standing for (512 - lead) / 8 rows each: BatchNorm
+        statistics and the loss mean carry that multiplicity (functional.run_mlp tail; same values as over all 512 rows up
+        to summation order), 136 instead of 512 rows per molecule with 128-row blocks."""
+        tail, wrow = None, None
+        if drug_rows is not None and self.training and isinstance(xd, (tuple, list)) and vd.dim() == 3:
+            N, lead, T = vd.shape[1], int(drug_rows), 8
+            if 0 < lead and lead + 2 * T <= N and (N - lead) % T == 0 and xd[0].shape[1] == N:
+                w = (N - lead) // T
+                tail = (lead + T, lead, w)
+                vd = vd[:, :lead + T]
+                xd = (xd[0][:, :lead + T], xd[1])
+                wrow = torch.ones(lead + T, dtype=torch.float32, device=vd.device)
+                wrow[lead:] = float(w)
         one, two, xd_dim = self._rows(vd, xd)
-        pred_one = self._predict(self.net(one))
-        pred_two = self._predict(self.llm_net(two, xd_dim))
+        pred_one = self._predict(self.net(one, tail=tail), tail)
+        pred_two = self._predict(self.llm_net(two, xd_dim, tail), tail)
         with torch.no_grad():
-            t_one = self.net(one)
-            t_two = self.llm_net(two, xd_dim)
+            t_one = self.net(one, tail=tail)
+            t_two = self.llm_net(two, xd_dim, tail)
         rows = Fn.CosRowLossFn.apply(pred_one.float(), t_two.float()) + Fn.CosRowLossFn.apply(pred_two.float(), t_one.float())
-        return rows.mean()
+        if wrow is None:
+            return rows.mean()
+        B = rows.numel() // wrow.numel()
+        return (rows.view(B, -1) * wrow).sum() / float(B * N)
 
     def prot_mlm(self, seq, extractor, xp, fill_bit, mode, mask_ignore_token_ids=(0,), mask_prob=0.15,
                  replace_prob=0.9, pad_token_id=0, mask_token_id=26, mask=None, replace=None):
@@ -154,7 +172,7 @@ class SSL(nn.Module):
             loss = loss + ce(head(self.llm_to_logits, xp))
         return loss / 2 if mode == "double" else loss
 
-    def forward(self, vp, xp, fill_bit_p, vd, xd, p_mode="double", mask=None, replace=None):
+    def forward(self, vp, xp, fill_bit_p, vd, xd, p_mode="double", mask=None, replace=None, drug_rows=None):
         if isinstance(xp, (tuple, list)):          # (embeddings (B,S,640), fill bit (B,S)) -> (B,S,641)
             # one pass: fill-bit-augmented features, zero-padded to 648 columns, compute dtype
             from .. import ops
@@ -165,7 +183,7 @@ class SSL(nn.Module):
         if vd is None or xd is None:
             drug = 0
         elif self.drug_ssl_type == "simsiam":
-            drug = self.drug_simsiam(vd, xd)
+            drug = self.drug_simsiam(vd, xd, drug_rows)
         else:
             drug = self.drug_simclr(vd, xd)
         return {"prot_ssl": prot, "drug_ssl": drug}

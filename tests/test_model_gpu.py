@@ -479,6 +479,53 @@ def test_cross_attention_over_the_distinct_drug_rows_whole_model(dt, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_simsiam_on_the_distinct_drug_rows_equals_all_rows(dt, tol):
+    """Round 5: SSL.drug_simsiam(drug_rows=lead) — projector / predictor MLPs (BatchNorm statistics with multiplicities) and the
+    row loss over rows 0 .. lead + 7 of every molecule, the last 8 standing for (512 - lead) / 8 identical padding rows each —
+    against the same module over all 512 rows: loss, every parameter gradient, the gradient with respect to vd (a tail
+    row's = the sum over the rows it stands for), the BatchNorm running statistics."""
+    import copy
+    from druglamp_amd.model.self_supervised_learning import SSL
+    torch.manual_seed(2)
+    B, N, lead = 6, 512, 128
+    a = SSL(torch.nn.Identity(), 640, drug_ssl_type="simsiam").to(DEV).train()
+    a.compute_dtype = dt
+    a.build_projectors(128, 385, DEV)
+    b = copy.deepcopy(a)
+    g = torch.Generator().manual_seed(3)
+    vd0 = torch.randn(B, N, 128, generator=g)
+    vd0[:, lead:] = vd0[:, lead:lead + 1]                                   # identical padding rows (per molecule, as the GCN gives them)
+    xd0 = torch.randn(B, N, 392, generator=g)
+    xd0[:, :, 385:] = 0
+    xd0[:, lead:] = xd0[:1, lead:lead + 1]                                  # the same zero + fill-bit row everywhere
+    res = {}
+    for name, m, rows in (("all", a, None), ("distinct", b, lead)):
+        vd = vd0.to(DEV, dt).requires_grad_(True)
+        loss = m.drug_simsiam(vd, (xd0.to(DEV, dt), 385), rows)
+        loss.backward()
+        gv = vd.grad.float()
+        gv_c = torch.cat([gv[:, :lead], gv[:, lead:].reshape(B, -1, 8, 128).sum(1)], 1)       # what reaches the compact rows
+        res[name] = (float(loss), gv_c, {n: p.grad.float() for n, p in m.named_parameters() if p.grad is not None},
+                     {n: t.float().clone() for n, t in m.named_buffers() if "running" in n})
+    assert abs(res["all"][0] - res["distinct"][0]) <= tol * abs(res["all"][0])
+    rel = lambda x, y: float((x - y).abs().max() / (y.abs().max() + 1e-30))                 # noqa: E731
+    assert rel(res["distinct"][1], res["all"][1]) <= 50 * tol if dt == torch.float32 else rel(res["distinct"][1], res["all"][1]) <= 0.1
+    assert set(res["all"][2]) == set(res["distinct"][2]) and len(res["all"][2]) >= 10
+    # (a Linear bias directly in front of a BatchNorm has a mathematically zero gradient — rounding noise in both forms — so every
+    #  tensor is compared on the scale of the largest gradient entries of the head as well as on its own)
+    top = max(float(ga.abs().max()) for ga in res["all"][2].values())
+    for n, ga in res["all"][2].items():
+        gb = res["distinct"][2][n]
+        if dt == torch.float32:
+            assert float((gb - ga).abs().max()) <= 50 * tol * max(float(ga.abs().max()), 1e-3 * top), n
+        elif float(ga.norm()) >= 1e-2 * max(float(t.norm()) for t in res["all"][2].values()):
+            assert float(torch.dot(gb.flatten(), ga.flatten()) / (gb.norm() * ga.norm() + 1e-30)) >= 0.98, n
+    for n, ra in res["all"][3].items():
+        assert rel(res["distinct"][3][n], ra) <= max(tol, 1e-4), n
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
 def test_drug_llm_adaptor_compact_padding_equals_the_full_computation(dt, tol):
     """Round 3: with the collate's `drug_tokens` hint the drug LLM adaptor (Linear + GELU, LayerNorm, Linear: all row-wise)
