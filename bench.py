@@ -309,7 +309,7 @@ def main():
             dt_ev, steps_ev = events_dt, events_steps
             ach = fl / (ms * 1e-3) / 1e12
             traffic, traffic_source = None, None
-            for pmc_name in ("r4_pmc_summary.json",):
+            for pmc_name in ("r5_pmc_summary.json", "r4_pmc_summary.json"):
                 pmc = os.path.join(ROOT, "profiles", pmc_name)
                 if os.path.exists(pmc) and args.batch == 256 and args.dtype == "bf16" and args.model == "DrugLAMP" and kinds == ["cls"] \
                         and args.seq_len == 2304:

@@ -1374,8 +1374,15 @@ class deferred_bn_ticks:
         if self.outer is None:
             ticks, _tick_list = _tick_list, None
             if ticks and exc[0] is None:
+                # (a counter may be queued more than once — the SimSiam projectors run an online and a target pass — and two
+                #  entries of ONE multi-tensor launch must not alias: add each distinct counter its multiplicity)
+                cnt = {}
+                for t in ticks:
+                    e = cnt.setdefault(id(t), [t, 0])
+                    e[1] += 1
                 with torch.no_grad():
-                    torch._foreach_add_(ticks, 1)
+                    for k in sorted({c for _, c in cnt.values()}):
+                        torch._foreach_add_([t for t, c in cnt.values() if c == k], k)
         return False
 
 

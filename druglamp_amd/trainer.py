@@ -369,7 +369,7 @@ class GraphedStep:
         _, cls_loss = binary_cross_entropy(score, labels) if tr.n_class == 1 else cross_entropy_logits(score, labels)
         out = {"cls": cls_loss.detach()}
         if "ssl" in self.kind:
-            with m._glue():
+            with m._glue(), Fn.deferred_bn_ticks():     # (the heads' BatchNorm step counters advance in one launch)
                 d = m.ssl_model(**ssl_input)
             ssl_loss = (d["prot_ssl"] + d["drug_ssl"]) * 0.1
             if self.kind == "ssl":               # with the CM head behind it this backward is dead too
@@ -757,8 +757,8 @@ class Trainer:
             kw = dict(ssl_input)
             if ssl_masks is not None:
                 kw.update(mask=ssl_masks[0], replace=ssl_masks[1])
-            with m._glue():                 # bf16 compute dtype: the heads' torch layers run under bf16 autocast
-                d = m.ssl_model(**kw)
+            with m._glue(), Fn.deferred_bn_ticks():     # bf16 compute dtype: the heads' torch layers run under bf16 autocast; the
+                d = m.ssl_model(**kw)                   # BatchNorm step counters of the heads advance in one launch
             ssl_loss = (d["prot_ssl"] + d["drug_ssl"]) * 0.1
             if last == "ssl" or self.run_dead_backward:
                 self._arm(last, "ssl")

@@ -20,6 +20,8 @@ args = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = load_yaml_into(get_cfg_defaults(), "DrugLAMP")
 model = MInterface("DrugLAMP", cfg).load_model(n_drug_feature=384, n_prot_feature=640).to(dev)
+model.branch_streams = False       # ONE stream: an event pair on a side stream brackets whatever else shares the chip with the launch
+                                   # (round 4's table showed the adaptors' 40-us products at 110-140 us for that reason)
 trainer = Trainer(model, cfg, device=dev, compute_dtype=torch.bfloat16)
 batch, meta = make_batch(args.batch, dev, seed=100, with_graph=True, llm_dtype=torch.bfloat16)
 for _ in range(3):

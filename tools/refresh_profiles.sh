@@ -32,19 +32,22 @@ T=$(find "$OUT/trace" -name '*kernel_trace.csv' | head -1); S=$(find "$OUT/trace
 cp "$S" "$OUT/bench_kernel_stats.csv"
 python3 "$ROOT/tools/prof_summary.py" "$T" 0.25 > "$OUT/bench_timed_window_summary.txt" 2>&1
 export DL_BRANCH_STREAMS=0      # (counter collection serialises the kernels anyway; one stream keeps the dispatch order that of the step)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o f -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pmc_f.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > "$OUT/pmc_w.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o f -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --distinct-batches 2 --no-cpu-baseline --no-kernel-timing > "$OUT/pmc_f.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o w -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --distinct-batches 2 --no-cpu-baseline --no-kernel-timing > "$OUT/pmc_w.log" 2>&1
 F=$(find "$OUT/pmc_f" -name '*counter_collection.csv' | head -1); W=$(find "$OUT/pmc_w" -name '*counter_collection.csv' | head -1)
 unset DL_BRANCH_STREAMS
 python3 "$ROOT/tools/pmc_summary.py" "$F" "$W" "$OUT/pmc_summary.json" > "$OUT/pmc_summary.txt" 2>&1
 python3 "$ROOT/bench.py" --graph on --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_batch256_graph.json"
 DL_BRANCH_STREAMS=0 python3 "$ROOT/bench.py" --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_one_stream.json"
 DL_CNN_COMPACT=0 python3 "$ROOT/bench.py" --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_cnn_every_position.json"
-DL_ATTN_BWD_ALGO=2 python3 "$ROOT/bench.py" --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_attn_bwd_kernel_pair.json"
-DL_POOL_THROUGH_MAP=0 python3 "$ROOT/bench.py" --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_sitepool_by_expansion.json"
+# round 5 A/B lines (same box, same run): PGCA over all 512 drug rows; ONE static batch instead of eight distinct ones
+DL_KEY_COMPACT=0 python3 "$ROOT/bench.py" --steps 100 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_pgca_all_drug_rows.json"
+python3 "$ROOT/bench.py" --steps 100 --distinct-batches 1 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_one_static_batch.json"
+python3 "$ROOT/bench.py" --batch 32 --steps 200 --distinct-batches 1 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 > "$OUT/bench_line_batch32_one_static_batch.json"
 python3 "$ROOT/bench.py" --seq-len 9216 --batch 32 --steps 50 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_line_config5_seq9216_batch32.json"
-python3 "$ROOT/tools/attn_bwd_onepass.py" 256 128 64 32 > "$OUT/attn_bwd_onepass.txt" 2>/dev/null
-python3 "$ROOT/tools/sitepool_rows_bench.py" 256 > "$OUT/sitepool_rows.txt" 2>/dev/null; python3 "$ROOT/tools/sitepool_rows_bench.py" 32 >> "$OUT/sitepool_rows.txt" 2>/dev/null
+python3 "$ROOT/tools/dgrad_layout_bench.py" 2>/dev/null | grep -v amdgpu > "$OUT/dgrad_layout.txt"
+python3 "$ROOT/tools/torch_glue_profile.py" 256 1 2>/dev/null | grep -v amdgpu | head -40 > "$OUT/torch_glue_cls_step.txt"
+python3 "$ROOT/tools/torch_glue_profile.py" 256 5 2>/dev/null | grep -v amdgpu | head -40 > "$OUT/torch_glue_ssl_step.txt"
 python3 "$ROOT/tools/gemm_shapes.py" > "$OUT/gemm_shapes.txt" 2>&1
 python3 "$ROOT/tools/gemm_shapes.py" --batch 32 > "$OUT/gemm_shapes_batch32.txt" 2>&1
 python3 "$ROOT/tools/cpu_baseline_sweep.py" > "$OUT/cpu_baseline_sweep.jsonl" 2>/dev/null
