@@ -192,9 +192,12 @@ def main():
             it[0] += 1
             trainer.training_step(batch, meta=meta, cur_epoch=ep)
 
-        # (graph mode: every distinct batch is seen once more than the warm-up count, so the captures the capacity classes
-        #  need have all been made before the timed region starts)
-        for _ in range(max(warmup, (trainer.graph_warmup + 1) * len(pairs) if graphed else 0)):
+        # Untimed, before the W warm-up steps: every distinct batch is stepped once (its row-bucket shapes reach the caching
+        # allocator for the first time there, a hipMalloc each) — in graph mode graph_warmup + 1 times, so that the captures the
+        # capacity classes need have all been made before the timed region starts.  Reported as config.first_touch_steps.
+        first_touch = (trainer.graph_warmup + 1) * len(pairs) if graphed else (len(pairs) if len(pairs) > 1 else 0)
+        measure.first_touch_steps = first_touch
+        for _ in range(first_touch + warmup):
             step()
         sync()
         if with_events:
@@ -246,6 +249,7 @@ def main():
     # kernels — or is a node of a replayed graph — has no duration of its own to bracket.
     dt, fam_stats = measure(args.batch, args.steps, args.warmup, False, busy=True)
     timed_captures, live_graphs = getattr(measure, "captures_in_timed_region", 0), len(trainer._graphs)
+    first_touch_steps = getattr(measure, "first_touch_steps", 0)
     events_steps, events_dt, events_note = args.steps, dt, None
     if timing:
         saved = (trainer.graph_steps, model.branch_streams)
@@ -287,6 +291,7 @@ def main():
                        # the timed steps cycle through this many distinct batches (other lengths / token counts / ids each);
                        # graph mode: graphs live after the run and captures that fell INTO the timed region (0 = none)
                        "distinct_batches": max(args.distinct_batches, 1),
+                       "first_touch_steps": first_touch_steps,      # untimed steps in front of the W warm-up steps (one per distinct batch)
                        "hip_graphs_live": live_graphs if graphed else None,
                        "hip_graph_captures_in_timed_region": timed_captures if graphed else None,
                        # identical padding rows of the drug branch (virtual GCN nodes beyond the adjacency block, zero token rows

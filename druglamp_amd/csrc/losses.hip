@@ -142,6 +142,71 @@ __global__ __launch_bounds__(256) void ce_rows_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// Fast forms for the model's shape (bf16 rows of exactly 32 columns = 64 bytes, C <= 32): the row travels as four 16-byte
+// accesses per thread instead of 3 x C two-byte loads (the generic kernels above ran at 0.6 TB/s on the 590 k x 32 logits).
+__device__ __forceinline__ void ce_load32(const bf16_t* row, float (&v)[32]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const u32x4 w = reinterpret_cast<const u32x4*>(row)[q];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[q * 8 + 2 * i] = bf16lo(w[i]); v[q * 8 + 2 * i + 1] = bf16hi(w[i]); }
+  }
+}
+__global__ __launch_bounds__(256) void ce_rows32_fwd_kernel(const bf16_t* __restrict__ logits, const int64_t* __restrict__ labels, int64_t N,
+                                                             int C, int64_t ignore, float* __restrict__ lse, float* __restrict__ partial) {
+  __shared__ float red[2][4];
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float loss = 0.f, cnt = 0.f;
+  if (r < N) {
+    float v[32];
+    ce_load32(logits + r * 32, v);
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) m = fmaxf(m, c < C ? v[c] : -INFINITY);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) sum += c < C ? __expf(v[c] - m) : 0.f;
+    const float l = m + __logf(sum);
+    lse[r] = l;
+    const int64_t y = labels[r];
+    if (y != ignore && y >= 0 && y < C) {
+      float ly = 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) ly = c == (int)y ? v[c] : ly;
+      loss = l - ly; cnt = 1.f;
+    }
+  }
+  loss = wave_sum(loss); cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = loss; red[1][threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * (int64_t)blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partial[2 * (int64_t)blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+__global__ __launch_bounds__(256) void ce_rows32_bwd_kernel(const bf16_t* __restrict__ logits, const int64_t* __restrict__ labels, int64_t N,
+                                                             int C, int64_t ignore, const float* __restrict__ lse, const float* __restrict__ stat,
+                                                             const float* __restrict__ gout, bf16_t* __restrict__ dlogits) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= N) return;
+  const int64_t y = labels[r];
+  const bool on = y != ignore && y >= 0 && y < C && stat[1] > 0.f;
+  u32x4 o[4] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+  if (on) {
+    const float g = gout[0] / stat[1], l = lse[r];
+    float v[32];
+    ce_load32(logits + r * 32, v);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = c < C ? g * (__expf(v[c] - l) - (c == (int)y ? 1.f : 0.f)) : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[q][i] = pack_bf16x2(v[q * 8 + 2 * i], v[q * 8 + 2 * i + 1]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) reinterpret_cast<u32x4*>(dlogits + r * 32)[q] = o[q];
+}
+
 // ------------------------------------------------------------------------------------------
 // triplet loss with D = 1 - sigmoid(cos).  nn.CosineSimilarity eps = 1e-8 (clamps each norm).
 // ------------------------------------------------------------------------------------------
@@ -391,7 +456,10 @@ extern "C" int dl_ce_rows_fwd(const void* logits, int64_t ld, const int64_t* lab
   DL_CHECK_ARG(dtype == DL_F32 || dtype == DL_BF16, DL_ERR_ARG, "dl_ce_rows_fwd: bad dtype");
   DL_CHECK_ARG(workspace && workspace_bytes >= dl_ce_rows_workspace_bytes(N), DL_ERR_WORKSPACE, "dl_ce_rows_fwd: workspace too small");
   const int64_t nb = (N + 255) / 256;
-  if (dtype == DL_BF16)
+  if (dtype == DL_BF16 && ld == 32 && C <= 32 && ((uintptr_t)logits & 15) == 0)
+    hipLaunchKernelGGL(ce_rows32_fwd_kernel, dim3((uint32_t)nb), dim3(256), 0, s, (const bf16_t*)logits, labels, N, (int)C, ignore_index, lse,
+                       (float*)workspace);
+  else if (dtype == DL_BF16)
     hipLaunchKernelGGL((ce_rows_fwd_kernel<bf16_t>), dim3((uint32_t)nb), dim3(256), 0, s, (const bf16_t*)logits, ld, labels, N, (int)C,
                        ignore_index, lse, (float*)workspace);
   else
@@ -410,7 +478,10 @@ extern "C" int dl_ce_rows_bwd(const void* logits, int64_t ld, const int64_t* lab
                DL_ERR_ARG, "dl_ce_rows_bwd: bad args");
   DL_CHECK_ARG(dtype == DL_F32 || dtype == DL_BF16, DL_ERR_ARG, "dl_ce_rows_bwd: bad dtype");
   const int64_t nb = (N + 255) / 256;
-  if (dtype == DL_BF16)
+  if (dtype == DL_BF16 && ld == 32 && ldd == 32 && Cp == 32 && C <= 32 && (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0)
+    hipLaunchKernelGGL(ce_rows32_bwd_kernel, dim3((uint32_t)nb), dim3(256), 0, s, (const bf16_t*)logits, labels, N, (int)C, ignore_index, lse,
+                       out2, grad_out, (bf16_t*)dlogits);
+  else if (dtype == DL_BF16)
     hipLaunchKernelGGL((ce_rows_bwd_kernel<bf16_t>), dim3((uint32_t)nb), dim3(256), 0, s, (const bf16_t*)logits, ld, labels, N, (int)C,
                        ignore_index, lse, out2, grad_out, (bf16_t*)dlogits, ldd, (int)Cp);
   else

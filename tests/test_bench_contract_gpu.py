@@ -32,6 +32,8 @@ def test_default_line_has_the_contract_keys():
     assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
     assert d["config"]["global_batch"] == 256 and d["config"]["per_gpu_batch"] == 256 and "workload" in d["config"]
     assert "model" not in d["config"] and d["config"]["hip_graph"] is False
+    # the timed steps cycle through distinct batches; each is stepped once, untimed, in front of the W warm-up steps
+    assert d["config"]["distinct_batches"] == 8 and d["config"]["first_touch_steps"] == 8
     assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "timing_source"):
@@ -49,6 +51,8 @@ def test_small_batch_line_replays_a_graph_and_says_so():
     assert d["config"]["hip_graph"] is True and d["scaling"] == "weak" and d["config"]["per_gpu_batch"] == 32
     assert "eager one-stream steps" in d["roofline"]["timing_source"] and "replays a hipGraph" in d["roofline"]["timing_source"]
     assert "cpu_baseline" not in d
+    # varying lengths / token counts: captures happen in the untimed first-touch steps, few graphs serve all eight batches
+    assert d["config"]["hip_graph_captures_in_timed_region"] == 0 and 1 <= d["config"]["hip_graphs_live"] <= 3
 
 
 def test_two_rank_launch_line_over_gloo_on_one_gpu():
