@@ -63,7 +63,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-FLAG_PROT_PERIOD, FLAG_DRUG_TOKEN_PAD, FLAG_GCN_NODE_PAD, FLAG_PLAN_ROWS, FLAG_MLM_MASK = 1, 2, 4, 8, 16
+FLAG_PROT_PERIOD, FLAG_DRUG_TOKEN_PAD, FLAG_GCN_NODE_PAD, FLAG_PLAN_ROWS = 1, 2, 4, 8
 TAG_OTHER, TAG_QKV_OUT, TAG_FFN, TAG_CONV, TAG_WGRAD, TAG_ADAPTOR = 0, 1, 2, 3, 4, 5
 TAG_NAMES = {0: "other", 1: "qkv_out", 2: "ffn", 3: "conv", 4: "wgrad", 5: "adaptor"}
 

@@ -32,16 +32,6 @@ def get_mask_subset_with_prob(mask, prob):
     return new_mask[:, 1:].bool()
 
 
-def _masked_positions(m, K):
-    """(B, K) int64: the positions of the first K True entries of every row of the boolean (B, S) matrix m, -1 behind them —
-    static shapes, no host sync (cumulative count -> target column; entries beyond K and False entries go to a dump column)."""
-    B, S = m.shape
-    col = torch.where(m, m.cumsum(dim=1) - 1, torch.full((1, 1), K, dtype=torch.int64, device=m.device)).clamp(max=K)
-    out = torch.full((B, K + 1), -1, dtype=torch.int64, device=m.device)
-    out.scatter_(1, col, torch.arange(S, device=m.device).unsqueeze(0).expand(B, S))
-    return out[:, :K]
-
-
 def prob_mask_like(t, prob):
     return torch.zeros_like(t).float().uniform_(0, 1) < prob
 
@@ -105,8 +95,6 @@ class SSL(nn.Module):
                 proj.projector = _simsiam_mlp(dim, proj.projection_out, proj.projection_hidden_size).to(device)
 
     compute_dtype = torch.float32
-    import os as _os
-    gather_masked = _os.environ.get("DL_MLM_GATHER", "1") != "0"      # A/B switch: 0 = the LLM masked-LM head over all B x S rows
 
     def _rows(self, vd, xd):
         """(vd rows, xd rows, xd feature width).  xd is either the reference's (B, L, 385) tensor or the
@@ -181,36 +169,12 @@ class SSL(nn.Module):
         if mode != "xp":
             loss = loss + ce(head(self.to_logits, extractor(masked_seq, fill_bit)))
         if mode != "vp":
-            if isinstance(xp, (tuple, list)):
-                # Round 5: only the masked tokens count (labels elsewhere are ignore_index) and the LLM embeddings carry no
-                # gradient, so the head, its weight gradient and the cross entropy run over the <= ceil(0.15 S) masked rows of
-                # every protein — gathered from the RAW (B, S, 640) embeddings (dl_rows_gather; the fill bit is formed on the
-                # gathered rows) — instead of all B x S rows of a fill-augmented (B, S, 648) copy: 88 k instead of 590 k rows
-                # at batch 256, and no 765 MB copy.  Same loss (a mean over the same rows, other summation order).
-                from .. import ops
-                raw = _on_hip(xp[0], "SSL.prot_mlm")
-                Bq, S = labels.shape
-                K = math.ceil(mask_prob * S)
-                counted = labels != pad_token_id
-                idx = _masked_positions(counted, K)                                     # (B, K) positions, -1 = none
-                # (a mask with more than K positions in a row — never from the reference's sampler — would lose rows: guard bit)
-                from .._lib import FLAG_MLM_MASK
-                ops.guard_flags(raw.device).bitwise_or_((counted.sum(dim=1) > K).any().to(torch.int32) * FLAG_MLM_MASK)
-                flat = torch.where(idx >= 0, idx + torch.arange(Bq, device=idx.device).unsqueeze(1) * S, idx).to(torch.int32)
-                rows = ops.rows_gather(raw.reshape(Bq * S, raw.shape[-1]), flat.reshape(-1))
-                xg = ops.fill_pool(rows.view(1, Bq * K, raw.shape[-1]), 1, self.compute_dtype)[1]
-                lab_g = torch.where(idx >= 0, labels.gather(1, idx.clamp(min=0)), torch.zeros_like(idx))
-                lg = head(self.llm_to_logits, xg)
-                loss = loss + Fn.CrossEntropyRowsFn.apply(lg.reshape(-1, lg.shape[-1]), lab_g, n_cls, pad_token_id)
-            else:
-                loss = loss + ce(head(self.llm_to_logits, xp))
+            loss = loss + ce(head(self.llm_to_logits, xp))
         return loss / 2 if mode == "double" else loss
 
     def forward(self, vp, xp, fill_bit_p, vd, xd, p_mode="double", mask=None, replace=None, drug_rows=None):
-        if isinstance(xp, (tuple, list)) and not (self.gather_masked and p_mode != "vp" and xp[0].is_cuda
-                                                  and xp[0].dtype == self.compute_dtype == torch.bfloat16):
-            # (embeddings (B,S,640), fill bit (B,S)) -> (B,S,641): one pass, fill-bit-augmented features, zero-padded to 648
-            # columns, compute dtype.  (The bf16 pipeline does not build it: prot_mlm gathers the masked rows from the raw tensor.)
+        if isinstance(xp, (tuple, list)):          # (embeddings (B,S,640), fill bit (B,S)) -> (B,S,641)
+            # one pass: fill-bit-augmented features, zero-padded to 648 columns, compute dtype
             from .. import ops
             xp = ops.fill_pool(_on_hip(xp[0], "SSL"), 1, self.compute_dtype)[1]
         if isinstance(xd, (tuple, list)) and not isinstance(xd[1], int):

@@ -855,9 +855,7 @@ FLAG_TEXT = {_lib.FLAG_PROT_PERIOD: "a protein's residue codes / fill bits are n
              _lib.FLAG_GCN_NODE_PAD: "drug graph nodes beyond the adjacency block are not identical virtual padding nodes "
                                      "(handler/dataset.py:216-221); disable with DL_GCN_COMPACT=0",
              _lib.FLAG_PLAN_ROWS: "the ProteinCNN row tables were built with fewer rows than the batch's residue counts need "
-                                  "(dl_protein_plan_build capacity)",
-             _lib.FLAG_MLM_MASK: "a masked-LM mask holds more than ceil(mask_prob * seq_len) positions in a row (the sampler of "
-                                 "utils.py:537-551 never does); disable the gathered head with DL_MLM_GATHER=0"}
+                                  "(dl_protein_plan_build capacity)"}
 
 
 def guard_flags(device) -> torch.Tensor:

@@ -393,8 +393,7 @@ int dl_embed_pad(const int64_t* ids, const void* weight, const void* fill, void*
                  int32_t V, int32_t D, int32_t halo, int32_t dtype, dl_stream s);
 /* Device-side guard flags (sticky bits OR-ed into a caller-owned uint32 word; the trainer polls it):
  * the compact forms below are only valid for inputs with the padding structure of the reference's collate. */
-enum { DL_FLAG_PROT_PERIOD = 1, DL_FLAG_DRUG_TOKEN_PAD = 2, DL_FLAG_GCN_NODE_PAD = 4, DL_FLAG_PLAN_ROWS = 8,
-       DL_FLAG_MLM_MASK = 16 /* (set by the Python layer: a masked-LM mask with more than ceil(mask_prob * S) positions in a row) */ };
+enum { DL_FLAG_PROT_PERIOD = 1, DL_FLAG_DRUG_TOKEN_PAD = 2, DL_FLAG_GCN_NODE_PAD = 4, DL_FLAG_PLAN_ROWS = 8 };
 /* ProteinCNN head on distinct rows (round 4; model/basic_model.py:168-171 over a sequence tiled by utils.py:392-412):
  * out[r][:D] = weight[ids[src[r]]], out[r][D] = fill[src[r]] for src[r] >= 0 (a flat index into ids / fill [B * L]), a zero
  * row for src[r] < 0.  weight padded to [V][D + 1] as for dl_embed_pad.  With `period` [B] given the same launch checks
