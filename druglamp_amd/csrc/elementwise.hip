@@ -491,6 +491,46 @@ __global__ __launch_bounds__(256) void cnn_sitepool_bwd_kernel(const T* __restri
   }
 }
 
+// site_len 1 (the masked-LM pass of the SSL epochs: the view reinterpretation alone, no pooling): pooled[b][L*q + r] =
+// z[b][halo + r][q] is a plain matrix transpose per sample, and so is its gradient.  64 x 64 tiles through LDS, 16-byte
+// accesses on both sides (the general kernels above write 2-byte elements in 32-byte runs there: 1.6 TB/s).
+//   dst[b][j][i] = src[b][i][j],  i < rows, j < cols; rows % 64 == cols % 64 == 0; row strides in elements.
+constexpr int TV_PITCH = 66;      // elements per LDS row (33 dwords: the column gather of 8 x 8 lanes lands on distinct banks)
+__global__ __launch_bounds__(256) void transpose_view_kernel(const bf16_t* __restrict__ src, int64_t src_bs, int64_t src_rs,
+                                                              bf16_t* __restrict__ dst, int64_t dst_bs, int64_t dst_rs,
+                                                              bf16_t* __restrict__ halo_base, int64_t halo_bs, int halo_rows, int64_t body_rows,
+                                                              int row_chunks) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[64 * TV_PITCH];
+  const int b = blockIdx.z, i0 = blockIdx.x * 64, j0 = blockIdx.y * 64, tid = threadIdx.x;
+  const bf16_t* sb = src + (int64_t)b * src_bs + (int64_t)i0 * src_rs + j0;
+#pragma unroll
+  for (int c = tid; c < 512; c += 256) {
+    const int i = c >> 3, jc = c & 7;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(sb + (int64_t)i * src_rs + jc * 8);
+    uint32_t* t = reinterpret_cast<uint32_t*>(tile + i * TV_PITCH + jc * 8);      // (4-byte aligned: the pitch is even)
+    t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+  }
+  __syncthreads();
+  bf16_t* db = dst + (int64_t)b * dst_bs + (int64_t)j0 * dst_rs + i0;
+#pragma unroll
+  for (int c = tid; c < 512; c += 256) {
+    const int j = c >> 3, ic = c & 7;
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      w[e] = (uint32_t)tile[(ic * 8 + 2 * e) * TV_PITCH + j] | ((uint32_t)tile[(ic * 8 + 2 * e + 1) * TV_PITCH + j] << 16);
+    *reinterpret_cast<u32x4*>(db + (int64_t)j * dst_rs + ic * 8) = u32x4{w[0], w[1], w[2], w[3]};
+  }
+  if (halo_base && blockIdx.x == 0 && blockIdx.y == 0) {      // backward: the zero rows around this sample's gradient
+    bf16_t* hb = halo_base + (int64_t)b * halo_bs;
+    for (int c = tid; c < 2 * halo_rows * row_chunks; c += 256) {
+      const int hr = c / row_chunks, ch = c % row_chunks;
+      const int64_t row = hr < halo_rows ? hr : body_rows + hr;
+      *reinterpret_cast<u32x4*>(hb + (row * row_chunks + ch) * 8) = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+}
+
 template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
   const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -910,6 +950,16 @@ extern "C" int dl_cnn_sitepool_fwd(const void* z, void* pooled, int64_t B, int64
   int rc = sitepool_check("dl_cnn_sitepool_fwd", z, pooled, B, L, C, halo, site_len, dtype);
   if (rc != DL_OK) return rc;
   const int n_site = (int)(L / site_len);
+#ifndef DL_NO_TRANSPOSE_VIEW      /* (variant builds of tools/: same-box A/B against the general kernel) */
+  if (site_len == 1 && L % 64 == 0 && C % 64 == 0 && ((uintptr_t)z & 15) == 0 && ((uintptr_t)pooled & 15) == 0) {
+    // the view reinterpretation alone: pooled[b] as [C][L] is the transpose of z[b]'s L body rows
+    hipLaunchKernelGGL(transpose_view_kernel, dim3((uint32_t)(L / 64), (uint32_t)(C / 64), (uint32_t)B), dim3(256), 0, s,
+                       (const bf16_t*)z + (int64_t)halo * C, (int64_t)(L + 2 * halo) * C, (int64_t)C, (bf16_t*)pooled, (int64_t)L * C, (int64_t)L,
+                       (bf16_t*)nullptr, (int64_t)0, 0, (int64_t)0, 0);
+    DL_CHECK_LAUNCH("dl_cnn_sitepool_fwd");
+    return DL_OK;
+  }
+#endif
   const size_t lds = (size_t)site_len * C * SP_PITCH * 2;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)cnn_sitepool_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
@@ -1081,6 +1131,15 @@ extern "C" int dl_cnn_sitepool_bwd(const void* dpooled, void* dz, int64_t B, int
   int rc = sitepool_check("dl_cnn_sitepool_bwd", dpooled, dz, B, L, C, halo, site_len, dtype);
   if (rc != DL_OK) return rc;
   const int n_site = (int)(L / site_len);
+#ifndef DL_NO_TRANSPOSE_VIEW
+  if (site_len == 1 && L % 64 == 0 && C % 64 == 0 && ((uintptr_t)dz & 15) == 0 && ((uintptr_t)dpooled & 15) == 0) {
+    hipLaunchKernelGGL(transpose_view_kernel, dim3((uint32_t)(C / 64), (uint32_t)(L / 64), (uint32_t)B), dim3(256), 0, s,
+                       (const bf16_t*)dpooled, (int64_t)L * C, (int64_t)L, (bf16_t*)dz + (int64_t)halo * C, (int64_t)(L + 2 * halo) * C, (int64_t)C,
+                       halo > 0 ? (bf16_t*)dz : (bf16_t*)nullptr, (int64_t)(L + 2 * halo) * C, (int)halo, (int64_t)L, (int)(C / 8));
+    DL_CHECK_LAUNCH("dl_cnn_sitepool_bwd");
+    return DL_OK;
+  }
+#endif
   const size_t lds = (size_t)C * SP_RR * sizeof(float);
   hipLaunchKernelGGL((cnn_sitepool_bwd_kernel<bf16_t>), dim3((uint32_t)((n_site + SP_RR - 1) / SP_RR), (uint32_t)B), dim3(256), lds, s,
                      (const bf16_t*)dpooled, (bf16_t*)dz, (int)L, (int)C, (int)halo, (int)site_len);

@@ -1286,7 +1286,9 @@ class BatchNormWeightedTailFn(torch.autograd.Function):
     mean terms w times.  Returns (y, mean, var)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, eps, momentum, LP, lead, w):
+    def forward(ctx, x, gamma, beta, rmean, rvar, eps, momentum, LP, lead, w, relu=False):
+        """relu=True: max(0, .) behind the BatchNorm in the same kernels (as BatchNormRowsFn; the mask is a row's own, so the
+        multiplicities only enter through the sums, exactly as without it)."""
         R, C = x.shape
         x = x.contiguous()
         tail = LP - lead
@@ -1296,25 +1298,29 @@ class BatchNormWeightedTailFn(torch.autograd.Function):
         upd = momentum is not None and rmean is not None and rmean.dtype == torch.float32
         mean, var, rstd = ops.bn_finalize(sums, n, eps, momentum if upd else 0.0, rmean.detach() if upd else None,
                                           rvar.detach() if upd else None)
-        g = gamma.detach().float()
-        y = ops.bn_apply_fwd(x, mean, rstd, g, beta.detach().float(), 0, 0, 0)
-        ctx.save_for_backward(x, mean, rstd, g)
-        ctx.cfg = (LP, lead, w, n)
+        g, b = gamma.detach().float(), beta.detach().float()
+        y = ops.bn_apply_relu_fwd(x, mean, rstd, g, b) if relu else ops.bn_apply_fwd(x, mean, rstd, g, b, 0, 0, 0)
+        ctx.save_for_backward(x, mean, rstd, g, b if relu else None)
+        ctx.cfg = (LP, lead, w, n, relu)
         ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _m, _v):
-        x, mean, rstd, g = ctx.saved_tensors
-        LP, lead, w, n = ctx.cfg
+        x, mean, rstd, g, b = ctx.saved_tensors
+        LP, lead, w, n, relu = ctx.cfg
         R, C = x.shape
         dy = dy.contiguous()
-        sums = ops.bn_bwd_reduce(dy, x, mean, rstd, 0, 0, 0)          # tail rows of dy already hold the sums over their copies
-        dx = ops.bn_bwd_apply(dy, x, mean, rstd, g, sums, 1.0 / n, False, 0, 0, 0)
+        # (tail rows of dy already hold the sums over their copies; a row and its copies share the ReLU mask)
+        if relu:
+            dx, sums = ops.bn_relu_bwd(dy, x, mean, rstd, g, b, 1.0 / n)
+        else:
+            sums = ops.bn_bwd_reduce(dy, x, mean, rstd, 0, 0, 0)
+            dx = ops.bn_bwd_apply(dy, x, mean, rstd, g, sums, 1.0 / n, False, 0, 0, 0)
         # tail rows: dx = sum over the w copies of g rstd (dy_copy - mean_dy - xhat mean_dyxhat): the mean terms w times
         ops.bn_tail_fix(dx, x, mean, rstd, g, sums, 1.0 / n, w, LP, lead)
-        return dx, sums[C:], sums[:C], None, None, None, None, None, None, None
+        return dx, sums[C:], sums[:C], None, None, None, None, None, None, None, None
 
 
 class ExpandTailFn(torch.autograd.Function):
@@ -1341,17 +1347,17 @@ class ExpandTailFn(torch.autograd.Function):
         return dy, None, None
 
 
-def batch_norm_rows_weighted_tail(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor, LP: int, lead: int, w: int) -> torch.Tensor:
+def batch_norm_rows_weighted_tail(bn: torch.nn.BatchNorm1d, x2d: torch.Tensor, LP: int, lead: int, w: int, relu: bool = False) -> torch.Tensor:
     """batch_norm_rows for the compact layouts of the drug branch (MolecularGCN; the SimSiam MLPs of the SSL head): inside every
     window of LP rows the rows from `lead` on stand for w identical rows each (training mode; eval mode is row-wise and needs no
     weights)."""
     if not bn.training:
-        return batch_norm_rows(bn, x2d)
+        return batch_norm_rows(bn, x2d, relu=relu)
     C = x2d.shape[1]
     gam = bn.weight if bn.weight is not None else torch.ones(C, device=x2d.device)      # affine=False
     bet = bn.bias if bn.bias is not None else torch.zeros(C, device=x2d.device)
     y, _mean, _var = BatchNormWeightedTailFn.apply(x2d, gam, bet, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
-                                                 LP, lead, w)
+                                                 LP, lead, w, relu)
     bn_tick(bn.num_batches_tracked)
     return y
 
@@ -1430,12 +1436,12 @@ def run_mlp(seq, x: torch.Tensor, tail=None) -> torch.Tensor:
         elif isinstance(layer, nn.BatchNorm1d):
             if x.shape[-1] != layer.num_features:
                 x = x[:, :layer.num_features].contiguous()
+            fuse = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)          # BatchNorm1d -> ReLU: one kernel each way
             if tail is not None and layer.training:
-                x = batch_norm_rows_weighted_tail(layer, x, *tail)
+                x = batch_norm_rows_weighted_tail(layer, x, *tail, relu=fuse)
             else:
-                fuse = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)      # BatchNorm1d -> ReLU: one kernel each way
                 x = batch_norm_rows(layer, x, relu=fuse)
-                i += 1 if fuse else 0
+            i += 1 if fuse else 0
         elif isinstance(layer, nn.ReLU):
             x = torch.relu(x)
         else:

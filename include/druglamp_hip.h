@@ -429,7 +429,9 @@ int dl_protein_plan_build(const int32_t* lengths, int64_t B, int64_t S, int64_t 
  * channel-first (B, C, L), REINTERPRETS that buffer with .view(B, L, C) and then site-pools it
  * (.view(B, site_len, n_site, C).mean(1)).  z is this library's channel-last conv output with `halo` zero rows
  * around every sample, [B][L + 2*halo][C]; pooled is [B][L / site_len][C].  fwd reproduces view + mean exactly in
- * one pass over z; bwd writes the full padded gradient dz (halo rows zeroed) from dpooled.  bf16 only. */
+ * one pass over z; bwd writes the full padded gradient dz (halo rows zeroed) from dpooled.  bf16 only.
+ * site_len 1 (the masked-LM pass, model/self_supervised_learning.py:67-101: the reinterpretation alone) is a per-sample matrix
+ * transpose and runs as one (64 x 64 tiles through LDS) when L and C are multiples of 64. */
 int dl_cnn_sitepool_fwd(const void* z, void* pooled, int64_t B, int64_t L, int64_t C, int32_t halo,
                         int32_t site_len, int32_t dtype, dl_stream s);
 int dl_cnn_sitepool_bwd(const void* dpooled, void* dz, int64_t B, int64_t L, int64_t C, int32_t halo,
