@@ -15,7 +15,8 @@ measurement (256 pairs per GPU, the reference DDP's "fixed SOLVER.BATCH_SIZE per
 gating gives (trainer.py:192-221: SSL heads every RS.EPOCH_STEP-th epoch, CM head from RS.INIT_EPOCH) and
 `--global-batch-heads` turns on RS.GLOBAL_BATCH (cross-modal triplets and, with `--drug-ssl simclr`, the NT-Xent denominator
 over the all-gathered global batch: config C3).
-Per-GPU batches <= 128 replay the cls step as a hipGraph (`--graph auto`; the eager step is host-enqueue bound there).
+`--graph auto` (Trainer(graph_steps="auto")): per-GPU batches <= 128 replay the step as a hipGraph (the eager step is host-enqueue
+bound there), and so do the steps with the cross-modality head at any batch (600+ small launches); the rest runs eager.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -92,7 +93,7 @@ def main():
     ap.add_argument("--global-batch-cm", "--global-batch-heads", dest="global_batch_cm", action="store_true",
                     help="RS.GLOBAL_BATCH: the batch-level heads see the all-gathered global batch (CM latents; NT-Xent rows)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay cls steps as a hipGraph (auto: per-GPU batch <= 128)")
+                    help="replay steps as a hipGraph (auto: per-GPU batch <= 128, and steps with the CM head at any batch)")
     ap.add_argument("--no-weak", action="store_true", help="skip the extra weak-scaling measurement at N > 1")
     ap.add_argument("--seq-len", type=int, default=2304, help="PROTEIN.SEQ_LEN (9216 = 1024 sites: BASELINE config 5, long proteins)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -145,7 +146,7 @@ def main():
     if args.batch <= 0:
         assert args.global_batch % world == 0, "--global-batch must be divisible by --gpus"
         args.batch = args.global_batch // world
-    use_graph = args.graph == "on" or (args.graph == "auto" and args.batch <= 128)
+    use_graph = {"on": True, "off": False, "auto": "auto"}[args.graph]     # auto: Trainer.wants_graph (batch <= 128, or a CM step)
     torch.manual_seed(1234)                       # identical initial weights on every rank
     ops.manual_seed(1000 + rank)                  # ... but rank-specific dropout streams
     cfg = load_yaml_into(get_cfg_defaults(), args.model)
@@ -162,7 +163,8 @@ def main():
         (["cm"] if trainer.use_cm and ep >= trainer.cm_init_epoch else [])
     # cls, SSL-epoch and CM steps replay a hipGraph; eager: the epoch the CM head starts in (its loss weight is scaled on
     # the host there) and the global-batch CM form at N > 1 (object collectives)
-    graphed = use_graph and ("cm" not in kinds or ep > trainer.cm_init_epoch) and trainer.graphed_kind_ok("ssl" in kinds, "cm" in kinds)
+    graphed = trainer.wants_graph(args.batch, "cm" in kinds) and ("cm" not in kinds or ep > trainer.cm_init_epoch) and \
+        trainer.graphed_kind_ok("ssl" in kinds, "cm" in kinds)
 
     def sync():
         if world > 1:

@@ -428,7 +428,11 @@ class GraphedStep:
 class Trainer:
     """ExpModule restated (trainer.py:39-292).  `cfg` is the merged config tree.
     graph_steps=True: cls, SSL-epoch and CM steps run as hipGraph replays (GraphedStep); the first steps of every new
-    (batch shape, step kind), the epoch the CM head starts in and the global-batch CM form stay eager."""
+    (batch shape, step kind), the epoch the CM head starts in and the global-batch CM form stay eager.
+    graph_steps="auto" (round 5): a replay where it was measured to pay (`wants_graph`): every kind at per-GPU batches <= 128
+    (the eager step is host-enqueue bound there) and, at any batch, the kinds with the cross-modality head (600+ launches per
+    step, many of them 3 us: eager 9.2-10.4 / 12.5-14.8 ms against 8.76 / 11.5 ms replayed at batch 256, same box); the cls and
+    SSL-epoch steps at batch 256 stay eager (12.4 / 10.6 ms against 12.6 / 11.0 replayed)."""
     overlap = None
     # (drug-token block, ProteinCNN table rows) used for EVERY step, eager or captured, instead of per-batch capacities.
     # Reductions over rows (BatchNorm statistics, split-K weight gradients) associate by the row count, so an eager trainer
@@ -503,7 +507,7 @@ class Trainer:
             ops.reset_tickets()
             # (bucket all-reduces are issued from backward hooks: hints_of keeps the forward on one stream then)
         # hook-driven collectives cannot be launched from inside a graph replay: graphed steps reduce after the replay
-        self.graph_steps = bool(graph_steps) and self.overlap is None
+        self.graph_steps = ("auto" if graph_steps == "auto" else bool(graph_steps)) if self.overlap is None else False
         self._graphs: Dict[tuple, GraphedStep] = {}
         self._agreed_sets: Dict[str, frozenset] = {}
         self._eager_seen: Dict[tuple, int] = {}
@@ -608,6 +612,14 @@ class Trainer:
     def model_has_global_ntxent(self) -> bool:
         ssl = getattr(self.model, "ssl_model", None)
         return bool(ssl is not None and getattr(ssl, "global_batch", False) and getattr(ssl, "drug_ssl_type", "") == "simclr")
+
+    GRAPH_AUTO_MAX_BATCH = 128
+
+    def wants_graph(self, batch_size: int, compute_cm: bool) -> bool:
+        """graph_steps as a per-step decision (True / False / "auto": see the class docstring)."""
+        if self.graph_steps == "auto":
+            return batch_size <= self.GRAPH_AUTO_MAX_BATCH or bool(compute_cm)
+        return bool(self.graph_steps)
 
     def graphed_kind_ok(self, compute_ssl: bool, compute_cm: bool) -> bool:
         """Whether a step kind may replay a graph at this world size (bench.py reports `hip_graph` from it)."""
@@ -721,7 +733,8 @@ class Trainer:
         cm_ok = (not compute_cm) or (cur_epoch > self.cm_init_epoch and meta is not None and
                                      (coll_ok or not m.cm_model.global_batch))
         ssl_ok = (not compute_ssl) or coll_ok or not self.model_has_global_ntxent()
-        if self.graph_steps and cm_ok and ssl_ok and not self.run_dead_backward and (not compute_ssl or ssl_masks is None):
+        if self.wants_graph(int(batch[2].shape[0]), compute_cm) and cm_ok and ssl_ok and not self.run_dead_backward and \
+                (not compute_ssl or ssl_masks is None):
             kind = (("ssl" if compute_ssl else "") + ("cm" if compute_cm else "")) or "cls"
             byval = (float(m.cm_model.m_sch_loss_fn.margin), float(self.cm_weight)) if compute_cm else ()
             base = (kind,) + GraphedStep.signature(batch) + byval

@@ -386,3 +386,14 @@ def test_batchnorm_over_one_row_raises_like_torch():
         torch.nn.functional.batch_norm(torch.zeros(1, 4), bn.running_mean, bn.running_var, bn.weight, bn.bias, True)
     with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
         Fn.batch_norm_rows(bn, torch.zeros(1, 4))
+
+
+def test_graph_auto_policy_is_per_step_kind_and_batch():
+    """Trainer(graph_steps="auto"): replay at per-GPU batches <= 128 for every kind, and the CM kinds at any batch."""
+    from types import SimpleNamespace
+    from druglamp_amd.trainer import Trainer
+    auto = SimpleNamespace(graph_steps="auto", GRAPH_AUTO_MAX_BATCH=Trainer.GRAPH_AUTO_MAX_BATCH)
+    assert Trainer.wants_graph(auto, 32, False) and Trainer.wants_graph(auto, 128, False)
+    assert not Trainer.wants_graph(auto, 256, False) and Trainer.wants_graph(auto, 256, True)
+    on, off = SimpleNamespace(graph_steps=True), SimpleNamespace(graph_steps=False)
+    assert Trainer.wants_graph(on, 256, False) and not Trainer.wants_graph(off, 32, True)

@@ -193,6 +193,25 @@ def test_cnn_view_and_site_pool_kernel_matches_reference_formulation(B, L, C, S)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,L,C,halo", [(2, 128, 64, 0), (3, 2304, 128, 0), (2, 192, 128, 7), (1, 64, 192, 1)])
+def test_view_reinterpretation_without_pooling_is_an_exact_transpose(B, L, C, halo):
+    """site_len 1 with L and C multiples of 64 takes transpose_view_kernel: pooled[b].view(C, L) == z[b, halo:halo+L].T bit for
+    bit (basic_model.py:176-179: the (B, C, L) buffer read as (B, L, C)), the gradient is the transpose back, halo rows zero."""
+    from druglamp_amd import ops
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(B, L + 2 * halo, C, generator=g).to(torch.bfloat16).cuda()
+    got = ops.cnn_sitepool_fwd(z, L, halo, 1)
+    want = z[:, halo:halo + L].transpose(1, 2).contiguous().view(B, L, C)
+    assert torch.equal(got, want)
+    dout = torch.randn(B, L, C, generator=g).to(torch.bfloat16).cuda()
+    dz = ops.cnn_sitepool_bwd(dout, L, halo, 1)
+    assert dz.shape == (B, L + 2 * halo, C)
+    assert torch.equal(dz[:, halo:halo + L], dout.view(B, C, L).transpose(1, 2))
+    if halo:
+        assert torch.count_nonzero(dz[:, :halo]) == 0 and torch.count_nonzero(dz[:, halo + L:]) == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_embed_pad_matches_embedding_cat_pad_and_its_gradient(dt):
     """EmbedPadFn == pad(cat(embedding(ids), fill)) with the embedding gradient of nn.Embedding(padding_idx=0); the
