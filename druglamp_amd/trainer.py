@@ -716,7 +716,8 @@ class Trainer:
     # -- the step ---------------------------------------------------------------------------------------
     def training_step(self, batch, meta=None, cur_epoch: int = 1, ssl_masks=None) -> Dict[str, float]:
         """batch = (feat_d, feat_p, labels, llm_d, llm_p) as the reference's collate yields them.
-        cur_epoch is 1-based (trainer.py:180).  Returns python floats of the losses (one host sync)."""
+        cur_epoch is 1-based (trainer.py:180).  Returns the losses as detached DEVICE scalars ({'cls': ..., 'ssl': ..., 'cm': ...}): the
+        step itself never synchronises with the host (reading a value does), so steps are enqueued back to back."""
         m = self.model
         self._poll_guard()
         if not m.training:
