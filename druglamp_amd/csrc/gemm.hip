@@ -177,6 +177,7 @@ __device__ __forceinline__ u32x4 read_frag(const char* lds, int rb, int kf, int 
 template <typename T, typename TO, bool XS, bool WS, bool SPLIT, bool DMA, int EPI, int TW, bool CS = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p0) {
   GemmP p = p0;            // (local copy: a paired launch re-points the epilogue fields per tile, see below)
+  const uint64_t seed_off_v = (p0.drop_thr16 && p0.seed_off) ? *p0.seed_off : 0;   // the device-side step offset, read once per launch (see gemm_big_kernel)
   constexpr bool SIMPLE = (EPI == 0);
   constexpr int BM = 32 * TW, BN = 32 * TW;
   constexpr bool XD = DMA, WD = DMA;                 // operands staged by LDS-DMA (both layouts)
@@ -376,8 +377,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p0) {
         a0 *= gelu_grad4<T>(q0); a1 *= gelu_grad4<T>(q1);
       }
       if (EPI != 5 && p.drop_thr16) {
-        a0 = dl_dropout4(a0, dl_eff_seed(p.seed, p.seed_off), (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
-        a1 = dl_dropout4(a1, dl_eff_seed(p.seed, p.seed_off), (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+        a0 = dl_dropout4(a0, p.seed + seed_off_v, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+        a1 = dl_dropout4(a1, p.seed + seed_off_v, (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
       }
       if constexpr (EPI == 3) {
         const T* src = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n;
@@ -463,8 +464,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p0) {
       }
       if (p.drop_thr16) {
         f32x4 d0 = {v[0], v[1], v[2], v[3]}, d1 = {v[4], v[5], v[6], v[7]};
-        d0 = dl_dropout4(d0, dl_eff_seed(p.seed, p.seed_off), (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
-        d1 = dl_dropout4(d1, dl_eff_seed(p.seed, p.seed_off), (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+        d0 = dl_dropout4(d0, p.seed + seed_off_v, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+        d1 = dl_dropout4(d1, p.seed + seed_off_v, (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[r] = d0[r]; v[4 + r] = d1[r]; }
       }

@@ -21,7 +21,7 @@
 // tile); ext: the residual (EPI 3) or the saved pre-activation (EPI 4) for this piece, requested several pieces
 // ahead by the caller so that its HBM latency is not paid once per piece.
 template <int EPI>
-__device__ __forceinline__ void big_epilogue8(const GemmP& p, int m, int n, f32x4 a0, f32x4 a1, f32x4 b0, f32x4 b1, u32x4 ext) {
+__device__ __forceinline__ void big_epilogue8(const GemmP& p, uint64_t seed_eff, int m, int n, f32x4 a0, f32x4 a1, f32x4 b0, f32x4 b1, u32x4 ext) {
   typedef bf16_t T;
   if constexpr (EPI != 4) { a0 += b0; a1 += b1; }
   if constexpr (EPI == 2) {
@@ -38,8 +38,8 @@ __device__ __forceinline__ void big_epilogue8(const GemmP& p, int m, int n, f32x
     a1 *= gelu_grad4<T>(f32x4{bf16lo(ext[2]), bf16hi(ext[2]), bf16lo(ext[3]), bf16hi(ext[3])});
   }
   if (EPI != 5 && EPI != 0 && p.drop_thr16) {
-    a0 = dl_dropout4(a0, dl_eff_seed(p.seed, p.seed_off), (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
-    a1 = dl_dropout4(a1, dl_eff_seed(p.seed, p.seed_off), (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+    a0 = dl_dropout4(a0, seed_eff, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+    a1 = dl_dropout4(a1, seed_eff, (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
   }
   if constexpr (EPI == 3) {
     a0 += f32x4{bf16lo(ext[0]), bf16hi(ext[0]), bf16lo(ext[1]), bf16hi(ext[1])};
@@ -102,6 +102,11 @@ void gemm_big_kernel(const GemmP p) {
   const int swz = (ROWB == 128) ? (il & 7) : ((il >> 1) & 3);
   const int xoff = (wm * 16 * XF + il) * ROWB, woff = XB + (wn * 16 * WF + il) * ROWB;
 
+  // the dropout seed of this launch: by-value seed + the device-side step offset, read ONCE here (round 5, late: the
+  // epilogue read *seed_off per 8-column piece — behind its own stores, which the load could not be hoisted over: a
+  // dependent memory round trip per piece, +0.26 ms per batch-256 step whenever the offset regime was on, i.e. in every
+  // graph-replaying trainer)
+  const uint64_t seed_eff = (EPI != 5 && EPI != 0 && p.drop_thr16) ? dl_eff_seed(p.seed, p.seed_off) : 0;
   const uint32_t ntiles = (uint32_t)p.mt * p.nt;
   const uint32_t G = gridDim.x;
   const bool dyn = p.tickets != nullptr;
@@ -273,7 +278,7 @@ void gemm_big_kernel(const GemmP p) {
           const f32x4 a0 = __builtin_bit_cast(f32x4, lds_read16(st, r * 256 + (((2 * c8) ^ r) << 4)));
           const f32x4 a1 = __builtin_bit_cast(f32x4, lds_read16(st, r * 256 + (((2 * c8 + 1) ^ r) << 4)));
           const int m = m_of(item);
-          if (m < p.M && n_ok && !(DL_DBG(p) & 1)) big_epilogue8<EPI>(p, m, n_lane, a0, a1, b0, b1, ext[item]);
+          if (m < p.M && n_ok && !(DL_DBG(p) & 1)) big_epilogue8<EPI>(p, seed_eff, m, n_lane, a0, a1, b0, b1, ext[item]);
         }
         wave_sync();
       }
