@@ -331,6 +331,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p0) {
       *reinterpret_cast<f32x4*>(smem + (wm * 16 * TW + i * 16 + il) * EP + (wn * 16 * TW + j * 16 + 4 * g) * 4) = acc[i][j];
   __syncthreads();
   const bool vec_ok = (p.N & 7) == 0;
+  // this lane's 8 columns are the same in every piece of the tile (NTHREADS is a multiple of the BN / 8 pieces of a row): its
+  // bias values are read ONCE per tile here.  (Round 5, late: read per piece they sat behind the previous piece's stores — the
+  // wait for the load is a wait for those stores as well, vmcnt counts both in order: a store round trip per piece.)
+  static_assert(NTHREADS % (BN / 8) == 0, "a lane keeps its columns across the pieces of a tile");
+  const int n_lane = cn0 + (tid % (BN / 8)) * 8;
+  f32x4 hb0 = {0.f, 0.f, 0.f, 0.f}, hb1 = hb0;
+  const bool hb_ok = p.bias != nullptr && vec_ok && n_lane + 8 <= p.N;
+  if (hb_ok) { hb0 = *reinterpret_cast<const f32x4*>(p.bias + n_lane); hb1 = *reinterpret_cast<const f32x4*>(p.bias + n_lane + 4); }
 #pragma unroll 2
   for (int it = 0; it < TW * TW / 2; ++it) {
     const int c = tid + it * NTHREADS;
@@ -342,10 +350,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p0) {
       // bias-only epilogue, N % 8 == 0: straight LDS -> (bias) -> convert -> one 16-byte store
       f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4);
       f32x4 a1 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4 + 16);
-      if (p.bias) {
-        a0 += *reinterpret_cast<const f32x4*>(p.bias + n);
-        a1 += *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-      }
+      a0 += hb0; a1 += hb1;                        // (zeros without a bias; N % 8 == 0 here: every piece is full)
       TO* dst = reinterpret_cast<TO*>(p.C) + (int64_t)m * p.ldc + n;
       if constexpr (sizeof(TO) == 2) {
         u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
@@ -360,10 +365,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p0) {
     if constexpr (!SPLIT && EPI >= 2) {
       f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4);
       f32x4 a1 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4 + 16);
-      if (EPI != 4 && p.bias) {
-        a0 += *reinterpret_cast<const f32x4*>(p.bias + n);
-        a1 += *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-      }
+      if (EPI != 4) { a0 += hb0; a1 += hb1; }
       if constexpr (EPI == 2) {
         T* pd = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
         store4<T>(pd, a0); store4<T>(pd + 4, a1);
@@ -414,9 +416,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p0) {
     } else {
       if (p.bias) {
         if (full) {
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
+          for (int r = 0; r < 4; ++r) { v[r] += hb0[r]; v[4 + r] += hb1[r]; }
         } else {
           for (int r = 0; r < nvalid; ++r) v[r] += p.bias[n + r];
         }
