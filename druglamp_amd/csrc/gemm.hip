@@ -656,6 +656,7 @@ void launch_lat(const GemmP& p, hipStream_t s, int cfg) {
 }
 void launch_big(const GemmP& p, hipStream_t s) {
   const uint32_t ntiles = (uint32_t)p.mt * p.nt;
+#ifdef DL_STUDY        // (the three rejected tile forms are instantiated in the study library only: 15 kernels the product never launches)
   const int cfg = big_cfg();
   // tile studies (DL_GEMM_BIGCFG): 1 = 256x128 tiles, 64-byte rows, 3 stages, two 4-wave workgroups per CU;
   // 2 = 256x256 tiles, 64-byte rows, 4 stages
@@ -672,7 +673,9 @@ void launch_big(const GemmP& p, hipStream_t s) {
 #undef DL_BIG
     return;
   }
+#endif
   const uint32_t nblocks = ntiles < 256u ? ntiles : 256u;       // one 128 KB workgroup per CU
+#ifdef DL_STUDY
   if (cfg == 3) {               // 16 waves of 64x64 (four per SIMD) on the same 256x256 tile and stage ring
 #define DL_BIG(E) hipLaunchKernelGGL((gemm_big_kernel<4, 4, 4, 128, 2, E>), dim3(nblocks), dim3(1024), 0, s, p)
     switch (pick_epi(p, false)) {
@@ -697,6 +700,7 @@ void launch_big(const GemmP& p, hipStream_t s) {
 #undef DL_BIG
     return;
   }
+#endif
 #define DL_BIG(E) hipLaunchKernelGGL((gemm_big_kernel<8, 2, 4, 128, 2, E>), dim3(nblocks), dim3(512), 0, s, p)
   switch (pick_epi(p, false)) {
     case 0: DL_BIG(0); break;
