@@ -36,6 +36,21 @@ def _headers():
     return hs
 
 
+def csrc_hash() -> str:
+    """sha1 over the kernel sources (csrc/*.hip, *.cuh and the C-ABI header), by name and content: what a recorded counter
+    measurement (profiles/r*_pmc_summary.json) belongs to — bench.py reports `traffic` only from a summary taken at the same
+    sources (measurement hygiene: .git does not travel to the GPU box, so this is a content hash)."""
+    import hashlib
+    h = hashlib.sha1()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cuh"))]
+    files.append(os.path.join(os.path.dirname(HERE), "include", "druglamp_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True

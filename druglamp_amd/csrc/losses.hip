@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void ce_rows_fwd_kernel(const T* __restrict__ 
     lse[r] = l;
     const int64_t y = labels[r];
     if (y != ignore && y >= 0 && y < C) { loss = l - to_f32(row[y]); cnt = 1.f; }
+    else if (y != ignore) { loss = __builtin_nanf(""); cnt = 1.f; }     // a label outside [0, C): torch asserts on the device; here the loss is NaN
   }
   loss = wave_sum(loss); cnt = wave_sum(cnt);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = loss; red[1][threadIdx.x >> 6] = cnt; }
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(256) void ce_rows_fwd_kernel(const T* __restrict__ 
     partial[2 * (int64_t)blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
 }
-// out[0] = mean loss over the counted rows (0 when there are none), out[1] = their number
+// out[0] = mean loss over the counted rows, out[1] = their number.  No counted row: NaN (0 / 0), as F.cross_entropy(reduction
+// = 'mean') gives when every label is ignore_index; a label outside [0, C) that is not ignore_index makes the loss NaN (torch
+// raises a device-side assert there: both are loud, neither skips the row silently — ADVICE r5)
 __global__ __launch_bounds__(256) void ce_rows_final_kernel(const float* __restrict__ partial, int64_t nblocks, float* __restrict__ out) {
   __shared__ float red[2][4];
   float a = 0.f, b = 0.f;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void ce_rows_final_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x == 0) {
     const float s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), n = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    out[0] = n > 0.f ? s / n : 0.f;
+    out[0] = n > 0.f ? s / n : __builtin_nanf("");
     out[1] = n;
   }
 }
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void ce_rows32_fwd_kernel(const bf16_t* __rest
 #pragma unroll
       for (int c = 0; c < 32; ++c) ly = c == (int)y ? v[c] : ly;
       loss = l - ly; cnt = 1.f;
-    }
+    } else if (y != ignore) { loss = __builtin_nanf(""); cnt = 1.f; }
   }
   loss = wave_sum(loss); cnt = wave_sum(cnt);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = loss; red[1][threadIdx.x >> 6] = cnt; }

@@ -74,8 +74,13 @@ def id_code(v) -> int:
         v = operator.index(v)
         if 0 <= v < (1 << 62):
             return v
-    elif isinstance(v, numbers.Real) and not isinstance(v, bool) and float(v) == int(v) and 0 <= int(v) < (1 << 62):
-        return int(v)                       # (1.0 == 1 as a dict key too)
+    elif isinstance(v, numbers.Real) and not isinstance(v, bool):
+        import math
+        f = float(v)
+        # non-finite ids (a pandas missing id is NaN; int(nan) / int(inf) raise opaque errors) take the hash path below:
+        # every missing id is then ONE entity named 'nan', on every rank
+        if math.isfinite(f) and f == int(f) and 0 <= int(f) < (1 << 62):
+            return int(f)                   # (1.0 == 1 as a dict key too)
     import hashlib
     h = hashlib.blake2b((v if isinstance(v, str) else str(v)).encode(), digest_size=8).digest()
     return (int.from_bytes(h, "little") & ((1 << 62) - 1)) | (1 << 62)       # disjoint from the small-int range

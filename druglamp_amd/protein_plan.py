@@ -65,8 +65,9 @@ def sample_rows(lengths, S: int) -> np.ndarray:
 
 
 def row_class(rows: int, unit: int = ROW_BUCKET) -> int:
-    """Row capacity of a captured graph's tables: the next value of a geometric ladder of `unit` multiples (ratio ~1.25:
-    2048 x {1, 2, 3, 4, 5, 7, 9, 12, 15, 19, 24, 30, ...}).  Batches whose random lengths differ by a few buckets land in
+    """Row capacity of a captured graph's tables: the next value of a geometric ladder of `unit` multiples (ratio ~1.25 once the
+    integer step exceeds one: 2048 x {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 15, 18, 22, 27, 33, 41, ...} — identical to the plain
+    2048-row bucket up to 16 k rows).  Batches whose random lengths differ by a few buckets land in
     one class; a graph captured for a class serves every batch that needs at most that many rows."""
     k = -(-max(int(rows), 1) // unit)
     c = 1

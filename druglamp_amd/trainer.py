@@ -515,7 +515,21 @@ class Trainer:
         self.graph_captures = 0                     # captures made so far (tests / bench: bounded under varying lengths)
         self.graph_warmup = 2            # eager (real) steps of a batch shape before its graph is captured
         self.graph_cache_max = max(1, int(os.environ.get("DL_GRAPH_CACHE_MAX", "6")))     # live GraphedSteps (LRU)
+        # A device synchronisation every `graph_sync_every` replays (0 = never).  Round 5 saw ONE hardware exception after
+        # ~300 replays that no host call separated (an experimental head, since removed); every shipped step
+        # kind soaks clean for 2000+ unsynchronised replays (tools/graph_nosync_soak.py), but the mechanism was never found,
+        # so the replay queue is bounded: one stream synchronise per 256 steps costs < 0.1 % of a training loop that does not
+        # read its losses (one that does synchronises every step anyway).
+        self.graph_sync_every = max(0, int(os.environ.get("DL_GRAPH_SYNC_EVERY", "256")))
+        self._replays_since_sync = 0
         self._plan_devs: Dict[tuple, object] = {}           # ProteinCNN row tables of eager steps, one set per shape
+        # DL_FIXED_CAPS="<drug-token block>,<ProteinCNN table rows | none>": one capacity for every step of this trainer (the
+        # deterministic mode: row reductions associate by capacity, so bits otherwise depend on which graph / bucket serves a
+        # batch — INTEGRATION.md "Reproducibility"); the attribute `fixed_caps` is the programmatic form.
+        fc = os.environ.get("DL_FIXED_CAPS", "")
+        if fc:
+            a, b = (fc.split(",") + ["none"])[:2]
+            self.fixed_caps = (int(a), None if b.strip().lower() in ("", "none") else int(b))
         on_gpu = torch.device(self.device).type == "cuda"
         self._guard_pin = torch.zeros(1, dtype=torch.int32).pin_memory() if on_gpu else None
         self._guard_event = None
@@ -739,11 +753,14 @@ class Trainer:
             kind = (("ssl" if compute_ssl else "") + ("cm" if compute_cm else "")) or "cls"
             byval = (float(m.cm_model.m_sch_loss_fn.margin), float(self.cm_weight)) if compute_cm else ()
             base = (kind,) + GraphedStep.signature(batch) + byval
-            spec = self.protein_plan_of(meta, batch)
+            # (must_pay=False for the LOOKUP: a batch whose compact layout would not pay on its own still fits — and replays —
+            #  a graph that holds tables of its size; GraphedStep.run builds its spec the same way)
+            spec_any = self.protein_plan_of(meta, batch, must_pay=False)
             blk = self.padding_hints_of(meta, batch).get("drug_tokens", 0)
-            g = self._find_graph(base, blk, spec)
+            g = self._find_graph(base, blk, spec_any)
             if g is not None:
                 return self._graphed_step(g, batch, meta)
+            spec = spec_any if (spec_any is not None and spec_any.pays()) else None
             # No captured graph serves this batch.  Capacities of the next capture: size CLASSES (row_class: a geometric
             # ladder; drug-token blocks of 128), never below what an earlier batch of this shape asked for — so the captures
             # of a shape form a chain of growing capacities and batches of varying lengths converge on one or two graphs
@@ -839,13 +856,23 @@ class Trainer:
         rows = None if spec is None else row_class(spec.need)
         if spec is not None and not spec.pays(rows):
             rows = None
+        # The chain of growing capacities per shape.  A batch WITHOUT a usable plan (no Prot_Len records, or a compact layout
+        # that does not pay) is served by the full layout for that batch only: it must not erase what earlier batches asked for
+        # (round 5 made rows=None sticky: one such batch and every later capture of the shape used ~3.5x the rows).
         old = self._graph_caps.get(base)
+        keep_blk, keep_rows = blk, rows
         if old is not None:
-            blk = 0 if (blk == 0 or old[0] == 0) else max(blk, old[0])
-            rows = None if (rows is None or old[1] is None) else max(rows, old[1])
+            if blk != 0 and old[0] != 0:
+                blk = keep_blk = max(blk, old[0])
+            elif blk == 0:
+                keep_blk = old[0]               # (0 = every drug row computed: this batch has no token records)
+            if rows is not None and old[1] is not None:
+                rows = keep_rows = max(rows, old[1])
+            elif rows is None:
+                keep_rows = old[1]
         if len(self._graph_caps) > 256:
             self._graph_caps.clear()
-        self._graph_caps[base] = (blk, rows)
+        self._graph_caps[base] = (keep_blk, keep_rows)
         return (blk, rows)
 
     def _capture(self, key, base, byval, batch, kind, meta, caps) -> "GraphedStep":
@@ -878,6 +905,10 @@ class Trainer:
             self.opt_cm.step(idx, 1.0 / self.world)
         Fn.bump_param_epoch()
         self._post_guard()
+        self._replays_since_sync += 1
+        if self.graph_sync_every and self._replays_since_sync >= self.graph_sync_every:
+            torch.cuda.current_stream(self.device).synchronize()
+            self._replays_since_sync = 0
         return out
 
     def static_batch(self, batch):

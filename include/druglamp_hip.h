@@ -485,7 +485,8 @@ int dl_cos_rowloss_bwd(const float* x, const float* y, float grad_scale, float* 
 /* Cross entropy over rows with few classes (round 5): F.cross_entropy(logits (N, C), labels, ignore_index) of the masked-LM
  * heads (model/self_supervised_learning.py:93-99; N = batch x 2304 tokens, C = 27).  logits [N][ld] (fp32 / bf16; ld >= C: the
  * GEMM in front pads the row), labels int64 [N].  fwd: lse [N] (log-sum-exp per row, kept for bwd), out2[0] = mean loss over the
- * rows whose label is not ignore_index (0 if none), out2[1] = their number; fixed summation order.  bwd: dlogits [N][ldd],
+ * rows whose label is not ignore_index, out2[1] = their number; fixed summation order.  As torch: NaN when no row is counted
+ * (0 / 0); a label outside [0, C) other than ignore_index (torch: device-side assert) poisons the loss with NaN — never skipped silently.  bwd: dlogits [N][ldd],
  * columns < Cp written (softmax - onehot) * grad_out[0] / out2[1] for counted rows, zeros elsewhere; grad_out is a DEVICE scalar. */
 size_t dl_ce_rows_workspace_bytes(int64_t N);
 int dl_ce_rows_fwd(const void* logits, int64_t ld, const int64_t* labels, int64_t N, int32_t C, int64_t ignore_index, int32_t dtype,

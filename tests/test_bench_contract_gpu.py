@@ -41,7 +41,17 @@ def test_default_line_has_the_contract_keys():
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3 and 0 < r["frac"] < 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == "pairs/s"
-    assert [r["batch"] for r in c["sweep"]] == [16, 32, 64] and c["value"] == max(r["value"] for r in c["sweep"])
+    # a thread sweep at the reference's batch 16, then the other batch sizes (as far as the time budget reaches) at the best count
+    assert c["sweep"][0]["batch"] == 16 and c["value"] == max(r["value"] for r in c["sweep"]) and len(c["thread_sweep"]) >= 1
+    assert c["cores"] == c["sweep"][0]["threads"] <= c["host_cores"] and abs(c["pairs_per_s_per_core"] - c["value"] / c["cores"]) < 1e-2
+    assert c["vs_reference_probe"]["reference_pairs_per_s_8_cores"] == [8.4, 9.3]
+    # traffic comes from a committed counter summary taken at THESE kernel sources, or is null and says why
+    assert (r["traffic"] is None) == ("not reported" in r["traffic_source"])
+    # one-GPU projection of the strong-scaling curve: the step at per-GPU batch 128 / 64 / 32 as hipGraph replays
+    p = d["projected_strong_scaling"]
+    assert [p[k]["per_gpu_batch"] for k in ("2", "4", "8")] == [128, 64, 32] and all(p[k]["hip_graph"] for k in ("2", "4", "8"))
+    assert all(p[k]["hip_graph_captures_in_timed_region"] == 0 for k in ("2", "4", "8"))
+    assert 1.0 < p["2"]["speedup_ceiling"] < p["4"]["speedup_ceiling"] < p["8"]["speedup_ceiling"] < 8.0
     for name in ("attn_fwd", "attn_bwd"):
         assert 0 < r[name]["hbm_frac"] < 1 and 0 < r[name]["mfma_frac"] < 1
 

@@ -397,3 +397,35 @@ def test_graph_auto_policy_is_per_step_kind_and_batch():
     assert not Trainer.wants_graph(auto, 256, False) and Trainer.wants_graph(auto, 256, True)
     on, off = SimpleNamespace(graph_steps=True), SimpleNamespace(graph_steps=False)
     assert Trainer.wants_graph(on, 256, False) and not Trainer.wants_graph(off, 32, True)
+
+
+def test_capture_capacities_are_not_erased_by_a_batch_without_a_plan():
+    """a batch whose compact ProteinCNN layout does not pay (or that has no Prot_Len / Drug_Tokens records) is
+    served by the full layout FOR THAT BATCH; the capacities earlier batches of the shape asked for stay on record, and
+    the next capture is never below them."""
+    from types import SimpleNamespace
+    from druglamp_amd.protein_plan import PlanSpec, row_class
+    from druglamp_amd.trainer import Trainer
+    tr = SimpleNamespace(fixed_caps=None, _graph_caps={})
+    base = ("cls", 16)
+    rs = np.random.RandomState(0)
+    small, big = PlanSpec(rs.randint(100, 300, 16), 2304), PlanSpec(rs.randint(600, 900, 16), 2304)
+    assert Trainer._capture_caps(tr, base, 128, big) == (128, row_class(big.need))
+    assert Trainer._capture_caps(tr, base, 0, None) == (0, None)                 # no records: every row, this batch only
+    assert tr._graph_caps[base] == (128, row_class(big.need))
+    assert Trainer._capture_caps(tr, base, 128, small) == (128, row_class(big.need))   # never below an earlier request
+    assert Trainer._capture_caps(tr, base, 256, small) == (256, row_class(big.need))
+    nopay = PlanSpec([1500] * 16, 2304)
+    assert not nopay.pays() and Trainer._capture_caps(tr, base, 256, nopay) == (256, None)
+    assert tr._graph_caps[base] == (256, row_class(big.need))
+    tr.fixed_caps = (384, 40960)
+    assert Trainer._capture_caps(tr, base, 128, small) == (384, 40960)
+
+
+def test_id_code_of_missing_and_mixed_ids():
+    """NaN / inf ids (a pandas missing id) hash like any other non-integral id instead of raising from int()."""
+    from druglamp_amd.dist_ops import id_code
+    assert id_code(float("nan")) == id_code(np.float64("nan")) >= (1 << 62)
+    assert id_code(float("inf")) >= (1 << 62) and id_code(float("inf")) != id_code(float("-inf"))
+    assert id_code(5) == id_code(np.int64(5)) == id_code(5.0) == 5 and id_code(True) != 1
+    assert id_code("P12345") == id_code("P12345") >= (1 << 62)

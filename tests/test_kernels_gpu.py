@@ -2,6 +2,7 @@
 tools/gpu_probe.py): GEMM layouts/epilogues, LayerNorm, attention fwd/bwd incl. paired segments and
 masked tails, MHLA gate, elementwise, AdamW, loss kernels."""
 import importlib.util
+import math
 import os
 
 import pytest
@@ -685,8 +686,13 @@ def test_cross_entropy_rows_against_torch(dt, N, C, ld):
     assert float((x.grad[:, :C].double() - xr.grad).abs().max()) <= gtol * float(xr.grad.abs().max())
     assert torch.count_nonzero(x.grad[:, C:]) == 0 and torch.count_nonzero(x.grad[labels == 0]) == 0
     assert float(Fn.CrossEntropyRowsFn.apply(full, labels, C, 0)) == float(loss)      # fixed summation order
+    # as torch: every label ignored -> NaN (0 / 0); a label outside [0, C) that is not ignore_index (torch: device
+    # assert) poisons the loss instead of being skipped
     none = Fn.CrossEntropyRowsFn.apply(full.clone().requires_grad_(True), torch.zeros_like(labels), C, 0)
-    assert float(none) == 0.0
+    assert math.isnan(float(none)) and math.isnan(float(torch.nn.functional.cross_entropy(xr.detach(), torch.zeros_like(labels), ignore_index=0)))
+    bad = labels.clone()
+    bad[N // 2] = C
+    assert math.isnan(float(Fn.CrossEntropyRowsFn.apply(full, bad, C, 0)))
 
 
 @pytest.mark.parametrize("dt,R,C", [(torch.float32, 3000, 512), (torch.bfloat16, 20000, 512), (torch.bfloat16, 777, 128), (torch.float32, 65, 36)])
