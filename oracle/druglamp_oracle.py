@@ -75,18 +75,33 @@ def pmma_attention_self(sd: SD, p: str, x: torch.Tensor, H: int):
     return _lin(sd, p + ".out", a), w
 
 
-def _mlp(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
-    return _lin(sd, p + ".fc2", F.gelu(_lin(sd, p + ".fc1", x)))       # mlp.py:44-50 (eval: no dropout)
+def _mlp(sd: SD, p: str, x: torch.Tensor, m1: Optional[torch.Tensor] = None, m2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mlp.py:44-50: fc1 -> GELU (erf) -> dropout -> fc2 -> dropout.  m1 / m2: the two dropout draws as multiplicative keep
+    masks (0 or 1 / (1 - p)); None = eval mode / p = 0."""
+    h = F.gelu(_lin(sd, p + ".fc1", x))
+    if m1 is not None:
+        h = h * m1
+    y = _lin(sd, p + ".fc2", h)
+    return y if m2 is None else y * m2
 
 
 def pmma_forward(sd: SD, prot: torch.Tensor, mol: torch.Tensor, prefix: str = "", num_heads: int = 4,
-                 n_layers: int = 4, return_maps: bool = False):
-    """PairedMultimodelAttention.forward in eval mode (paired_multi_model_attention_model.py:22-29,
+                 n_layers: int = 4, return_maps: bool = False, dropout_masks: Optional[Dict[str, torch.Tensor]] = None):
+    """PairedMultimodelAttention.forward (paired_multi_model_attention_model.py:22-29,
     embed.py:38-54, encoder.py:41-56, block.py:33-62).  The `embedding(prot)` Linear of embed.py:50
-    is computed and discarded by the reference and is skipped here."""
+    is computed and discarded by the reference and is skipped here.
+    dropout_masks=None: eval mode.  Training mode takes the Bernoulli draws of every dropout site as DATA — multiplicative
+    keep masks keyed emb_mol / emb_prot (embed.py:42,52: after the positional add) and l{i}.s{s}.fc1 / .fc2 (mlp.py:47,49;
+    s = 0: prot / the single stream, 1: mol); pinned by tests/golden/pmma_drop.npz (the reference in train mode with its
+    nn.Dropout modules fed the same masks)."""
+    dm = dropout_masks or {}
     e = prefix + "embeddings."
     mol = _lin(sd, e + "mol_embeddings", mol) + sd[e + "pe_mol"]
     prot = prot + sd[e + "pe_prot"]
+    if "emb_mol" in dm:
+        mol = mol * dm["emb_mol"]
+    if "emb_prot" in dm:
+        prot = prot * dm["emb_prot"]
     maps = []
     x = None
     for i in range(n_layers):
@@ -96,15 +111,15 @@ def pmma_forward(sd: SD, prot: torch.Tensor, mol: torch.Tensor, prefix: str = ""
             ap, am, w, gw = pmma_attention_paired(sd, p + ".attn", _ln(sd, p + ".attention_norm", prot, 1e-6),
                                                   _ln(sd, p + ".att_norm_mol", mol, 1e-6), num_heads)
             prot, mol = ap + h, am + hm
-            prot = _mlp(sd, p + ".ffn", _ln(sd, p + ".ffn_norm", prot, 1e-6)) + prot
-            mol = _mlp(sd, p + ".ffn_mol", _ln(sd, p + ".ffn_norm_mol", mol, 1e-6)) + mol
+            prot = _mlp(sd, p + ".ffn", _ln(sd, p + ".ffn_norm", prot, 1e-6), dm.get("l%d.s0.fc1" % i), dm.get("l%d.s0.fc2" % i)) + prot
+            mol = _mlp(sd, p + ".ffn_mol", _ln(sd, p + ".ffn_norm_mol", mol, 1e-6), dm.get("l%d.s1.fc1" % i), dm.get("l%d.s1.fc2" % i)) + mol
             maps.append((w, gw))
         else:
             if i == 2:
                 x = torch.cat((prot, mol), dim=-1)
             a, w = pmma_attention_self(sd, p + ".attn", _ln(sd, p + ".attention_norm", x, 1e-6), num_heads)
             x = a + x
-            x = _mlp(sd, p + ".ffn", _ln(sd, p + ".ffn_norm", x, 1e-6)) + x
+            x = _mlp(sd, p + ".ffn", _ln(sd, p + ".ffn_norm", x, 1e-6), dm.get("l%d.s0.fc1" % i), dm.get("l%d.s0.fc2" % i)) + x
             maps.append((w, None))
     out = _ln(sd, prefix + "encoder.encoder_norm", x, 1e-6)
     return (out, maps) if return_maps else out

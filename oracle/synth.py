@@ -36,3 +36,23 @@ def model_inputs(tag: str, B: int, salt: int = 0, seq_len: int = 2304, lp_range=
     return vd, vp, xd, xp, y
 
 
+
+
+def pmma_dropout_masks(tag: str, B: int, L: int, d: int, p: float, n_layers: int = 4):
+    """Deterministic keep masks (1 / (1 - p) where kept, 0 where dropped; float32 numpy) for every dropout site of a
+    training-mode PMMA forward, keyed like druglamp_oracle.pmma_forward(dropout_masks=...): emb_mol / emb_prot (embed.py:42,52),
+    l{i}.s{s}.fc1 / .fc2 (mlp.py:47,49; s = 0 prot / the single stream, 1 mol).  The golden generator feeds the same masks to
+    the reference's nn.Dropout modules (tests/golden/make_golden.py::gen_pmma_dropout)."""
+    out = {}
+
+    def mk(name, shape):
+        u = detgen.uniform(tag + ".mask." + name, shape, 0.0, 1.0)
+        out[name] = (u >= p).astype(np.float32) / np.float32(1.0 - p)
+    mk("emb_mol", (B, L, d))
+    mk("emb_prot", (B, L, d))
+    for i in range(n_layers):
+        w = d if i < 2 else 2 * d
+        for s_ in range(2 if i < 2 else 1):
+            mk("l%d.s%d.fc1" % (i, s_), (B, L, 4 * w))
+            mk("l%d.s%d.fc2" % (i, s_), (B, L, w))
+    return out

@@ -96,6 +96,48 @@ def gen_pmma():
         save(tag, **out)
 
 
+class _MaskDropout(torch.nn.Module):
+    """Stand-in for ONE nn.Dropout instance of the reference: multiplies by the given masks, one per call in call order —
+    F.dropout's arithmetic (x * keep / (1 - p)) with the Bernoulli draw replaced by recorded data."""
+
+    def __init__(self, masks):
+        super().__init__()
+        self.masks, self.calls = masks, 0
+
+    def forward(self, x):
+        m = self.masks[self.calls % len(self.masks)]
+        self.calls += 1
+        return x * m
+
+
+def gen_pmma_dropout():
+    """The reference's PMMA in TRAINING mode (dropout_rate 0.1, the shipped value: default_config.py:67-89) with its Dropout
+    modules fed recorded masks: pins WHERE dropout acts (after the positional adds, after GELU and after fc2) and the
+    gradients through it.  The GPU test replays the HIP kernels' own masks through the oracle pinned by this fixture."""
+    from model.PMMA import PairedMultimodelAttention
+    tag, L, B, pdrop = "pmma_drop", 64, 2, 0.1
+    cfg = pmma_config(L)
+    cfg.transformer.dropout_rate = pdrop
+    m = fill_module(PairedMultimodelAttention(cfg, vis=False)).train()
+    masks = {k: torch.from_numpy(v) for k, v in synth.pmma_dropout_masks(tag, B, L, 256, pdrop).items()}
+    m.embeddings.dropout_mol = _MaskDropout([masks["emb_mol"]])
+    m.embeddings.dropout = _MaskDropout([masks["emb_prot"]])
+    for i, blk in enumerate(m.encoder.layer_with_mol):
+        blk.ffn.dropout = _MaskDropout([masks["l%d.s0.fc1" % i], masks["l%d.s0.fc2" % i]])
+        if i < 2:
+            blk.ffn_mol.dropout = _MaskDropout([masks["l%d.s1.fc1" % i], masks["l%d.s1.fc2" % i]])
+    prot = T(tag + ".prot", (B, L, 256)).requires_grad_(True)
+    mol = T(tag + ".mol", (B, L, 256)).requires_grad_(True)
+    enc, _, _ = m(prot, mol)
+    G = T(tag + ".G", tuple(enc.shape))
+    (enc * G).sum().backward()
+    save(tag, sd=sd_spec(m), p=np.float32(pdrop), encoded=enc, dprot=prot.grad, dmol=mol.grad, gradnorm=grad_norms(m),
+         dW_l0_fc1=m.encoder.layer_with_mol[0].ffn.fc1.weight.grad[:8, :16],
+         dW_l1_fc2_mol=m.encoder.layer_with_mol[1].ffn_mol.fc2.weight.grad[:8, :16],
+         dW_l3_fc2=m.encoder.layer_with_mol[3].ffn.fc2.weight.grad[:8, :16],
+         dpe_prot=m.embeddings.pe_prot.grad[0, :4, :16])
+
+
 def gen_pmma_long():
     """BASELINE config 5 (long proteins: 1024 sites).  The reference's PMMA accepts any feat_len (embed.py:32-33)."""
     from model.PMMA import PairedMultimodelAttention
@@ -512,8 +554,8 @@ def gen_gcn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pmma", "pgca", "mhla", "losses", "models", "sslcm", "train", "pmma_long", "model_long", "gcn"]
+    which = sys.argv[1:] or ["pmma", "pgca", "mhla", "losses", "models", "sslcm", "train", "pmma_long", "model_long", "gcn", "pmma_drop"]
     table = dict(pmma=gen_pmma, pgca=gen_pgca, mhla=gen_mhla, losses=gen_losses, models=gen_models, sslcm=gen_ssl_cm,
-                 train=gen_train_steps, pmma_long=gen_pmma_long, model_long=gen_model_long, gcn=gen_gcn)
+                 train=gen_train_steps, pmma_long=gen_pmma_long, model_long=gen_model_long, gcn=gen_gcn, pmma_drop=gen_pmma_dropout)
     for w in which:
         table[w]()

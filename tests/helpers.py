@@ -38,10 +38,47 @@ def model_inputs(tag, B, salt=0, **kw):
     return tuple(torch.from_numpy(a) for a in synth.model_inputs(tag, B, salt, **kw))
 
 
+def _log_margin(kind, value, a, b):
+    """DL_PARITY_LOG=<file>: every relerr / elemerr evaluation of a test run is appended as one JSON line (test id, call site,
+    both measures) — tools/parity_margins.py turns the file into the per-test margin table under profiles/."""
+    path = os.environ.get("DL_PARITY_LOG")
+    if not path:
+        return
+    import inspect
+    test, line = "?", 0
+    for fr in inspect.stack()[2:]:
+        if fr.function.startswith("test_"):
+            test, line = fr.function, fr.lineno
+            break
+    d = (a - b).abs()
+    rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", test).split(" ")[0], "line": line, "kind": kind, "value": value,
+           "relerr": float(d.max() / (b.abs().max() + 1e-30)),
+           "elemerr": float((d / (b.abs() + 1e-2 * b.abs().max() + 1e-30)).max()), "numel": int(b.numel())}
+    with open(path, "a") as f:
+        f.write(json.dumps(rec) + "\n")
+
+
 def relerr(a, b):
-    a = torch.as_tensor(np.asarray(a) if not isinstance(a, torch.Tensor) else a).double().cpu()
-    b = torch.as_tensor(np.asarray(b) if not isinstance(b, torch.Tensor) else b).double().cpu()
-    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    a = torch.as_tensor(np.asarray(a) if not isinstance(a, torch.Tensor) else a).detach().double().cpu()
+    b = torch.as_tensor(np.asarray(b) if not isinstance(b, torch.Tensor) else b).detach().double().cpu()
+    v = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    _log_margin("relerr", v, a, b)
+    return v
+
+
+def elemerr(a, b, floor=1e-2):
+    """Element-wise relative error with an absolute floor: max_i |a_i - b_i| / (|b_i| + floor * max|b|).  `relerr` divides every
+    difference by the LARGEST reference element, so one large element hides relative error on the small ones (VERDICT r5);
+    here an element is judged against its own magnitude down to `floor` (1 %) of the largest."""
+    a = torch.as_tensor(np.asarray(a) if not isinstance(a, torch.Tensor) else a).detach().double().cpu()
+    b = torch.as_tensor(np.asarray(b) if not isinstance(b, torch.Tensor) else b).detach().double().cpu()
+    v = float(((a - b).abs() / (b.abs() + floor * b.abs().max() + 1e-30)).max())
+    _log_margin("elemerr", v, a, b)
+    return v
+
+
+def pmma_dropout_masks(tag, B, L, d, p):
+    return {k: torch.from_numpy(v) for k, v in synth.pmma_dropout_masks(tag, B, L, d, p).items()}
 
 
 def check_sub(x, g, key, tol):

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import druglamp_oracle as O
-from tests.helpers import T, check_sub, det_state_dict, gradnorms, load, model_inputs, relerr
+from tests.helpers import T, check_sub, det_state_dict, elemerr, gradnorms, load, model_inputs, pmma_dropout_masks, relerr
 
 TOL = 2e-5
 
@@ -38,6 +38,33 @@ def test_pmma_mid_forward_backward():
         assert abs(float(sd[k].grad.double().norm()) - n) <= 1e-4 * max(n, 1e-6), k
     # the reference never produces a gradient for the dead `embeddings.embedding` Linear
     assert "embeddings.embedding.weight" not in gradnorms(g)
+
+
+def test_pmma_training_mode_with_recorded_dropout_masks():
+    """The oracle's training-mode PMMA (dropout draws as data) against the reference in train mode with its nn.Dropout modules
+    fed the same masks (tests/golden/pmma_drop.npz): output, input gradients, weight-gradient samples on both sides of every
+    dropout site, every parameter's gradient norm — element-wise as well as max-norm."""
+    g = load("pmma_drop")
+    sd = det_state_dict(g)
+    for v in sd.values():
+        v.requires_grad_(True)
+    B, L = 2, 64
+    prot = T("pmma_drop.prot", (B, L, 256)).requires_grad_(True)
+    mol = T("pmma_drop.mol", (B, L, 256)).requires_grad_(True)
+    masks = pmma_dropout_masks("pmma_drop", B, L, 256, float(g["p"]))
+    assert 0.08 < float((masks["l0.s0.fc1"] == 0).float().mean()) < 0.12
+    enc = O.pmma_forward(sd, prot, mol, dropout_masks=masks)
+    assert relerr(enc, g["encoded"]) <= TOL and elemerr(enc, g["encoded"]) <= 10 * TOL
+    assert relerr(O.pmma_forward(sd, prot, mol), g["encoded"]) > 1e-2        # (the masks matter: eval mode is far away)
+    (enc * T("pmma_drop.G", tuple(enc.shape))).sum().backward()
+    for got, key in ((prot.grad, "dprot"), (mol.grad, "dmol"),
+                     (sd["encoder.layer_with_mol.0.ffn.fc1.weight"].grad[:8, :16], "dW_l0_fc1"),
+                     (sd["encoder.layer_with_mol.1.ffn_mol.fc2.weight"].grad[:8, :16], "dW_l1_fc2_mol"),
+                     (sd["encoder.layer_with_mol.3.ffn.fc2.weight"].grad[:8, :16], "dW_l3_fc2"),
+                     (sd["embeddings.pe_prot"].grad[0, :4, :16], "dpe_prot")):
+        assert relerr(got, g[key]) <= TOL and elemerr(got, g[key]) <= 10 * TOL, key
+    for k, n in gradnorms(g).items():
+        assert abs(float(sd[k].grad.double().norm()) - n) <= 1e-4 * max(n, 1e-6), k
 
 
 def test_pmma_full_forward():

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import T, check_sub, det_state_dict, gradnorms, load, relerr
+from tests.helpers import T, check_sub, det_state_dict, elemerr, gradnorms, load, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -72,6 +72,64 @@ def test_pmma_mid_forward_backward(dtype, tol):
     assert relerr(sd["embeddings.pe_mol"].grad[0, :4, :16], g["dpe_mol"]) <= tol * 3
     check_gradnorms(m.named_parameters(), g, tol)
     assert sd["embeddings.embedding.weight"].grad is None     # dead Linear, as in the reference
+
+
+def test_pmma_dropout_on_against_the_oracle_fed_the_kernels_own_masks():
+    """Dropout-ON arithmetic against the oracle (it had property tests only).  The HIP path never stores a mask: it
+    is a counter hash of (site seed, element index) evaluated inside the GEMM epilogues / dl_add_rowmod_dropout and again in
+    backward.  Here the fp32 PMMA runs in TRAINING mode (p = 0.1, the shipped value); the masks it used are then replayed
+    site by site through dl_dropout_apply on a tensor of ones (same seeds, in the order the forward drew them) and handed to
+    the oracle's training-mode PMMA, itself pinned to the reference in train mode by tests/golden/pmma_drop.npz.  Output and
+    gradients must agree at the fp32 tolerance: a mask applied at the wrong place (before GELU, before the positional add),
+    with the wrong scale, or differently in forward and backward fails here."""
+    from druglamp_amd import ops
+    from druglamp_amd.model.PMMA import PairedMultimodelAttention
+    from oracle import druglamp_oracle as O
+    g = load("pmma_drop")
+    B, L, d, p = 2, 64, 256, float(g["p"])
+    m = PairedMultimodelAttention(pmma_config(L, dropout=p), vis=False)
+    m.load_state_dict(det_state_dict(g), strict=True)
+    m = m.to(_dev()).train()
+    m.compute_dtype = torch.float32
+    prot = T("pmma_drop.prot", (B, L, d)).to(_dev()).requires_grad_(True)
+    mol = T("pmma_drop.mol", (B, L, d)).to(_dev()).requires_grad_(True)
+    ops.manual_seed(77)
+    enc, _, _ = m(prot, mol)
+    (enc * T("pmma_drop.G", tuple(enc.shape)).to(_dev())).sum().backward()
+    # replay the masks: one seed per site, drawn in the forward's order (PMMA.py: mol embedding, prot embedding; per block and
+    # stream (fc1, fc2) — functional.TransformerBlockFn)
+    ops.manual_seed(77)
+
+    def mask(width):
+        one = torch.ones((B * L, width), dtype=torch.float32, device=_dev())
+        return ops.dropout_apply(one, p, ops.next_seed()).reshape(B, L, width).cpu()
+    masks = {"emb_mol": mask(d), "emb_prot": mask(d)}
+    for i in range(4):
+        w = d if i < 2 else 2 * d
+        for s_ in range(2 if i < 2 else 1):
+            masks["l%d.s%d.fc1" % (i, s_)] = mask(4 * w)
+            masks["l%d.s%d.fc2" % (i, s_)] = mask(w)
+    for k, v in masks.items():
+        vals = torch.unique(v)
+        assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1.0 / (1.0 - p)) <= 1e-4, (k, vals)
+        assert 0.07 < float((v == 0).float().mean()) < 0.13, k
+    assert not torch.equal(masks["l0.s0.fc2"], masks["l0.s1.fc2"]) and not torch.equal(masks["emb_mol"], masks["emb_prot"])
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    pc = prot.detach().cpu().requires_grad_(True)
+    mc = mol.detach().cpu().requires_grad_(True)
+    ref = O.pmma_forward(sd, pc, mc, dropout_masks=masks)
+    (ref * T("pmma_drop.G", tuple(ref.shape))).sum().backward()
+    assert relerr(O.pmma_forward(sd, pc, mc).detach(), ref.detach()) > 1e-2            # (the masks matter)
+    assert relerr(enc, ref.detach()) <= F32_TOL and elemerr(enc, ref.detach()) <= 10 * F32_TOL
+    assert relerr(prot.grad, pc.grad) <= 3 * F32_TOL and relerr(mol.grad, mc.grad) <= 3 * F32_TOL
+    named = dict(m.named_parameters())
+    for k in ("encoder.layer_with_mol.0.ffn.fc1.weight", "encoder.layer_with_mol.1.ffn_mol.fc2.weight", "encoder.layer_with_mol.3.ffn.fc2.weight",
+              "encoder.layer_with_mol.2.ffn.fc1.bias", "embeddings.pe_prot", "embeddings.pe_mol", "embeddings.mol_embeddings.weight",
+              "encoder.layer_with_mol.0.attn.query_mol.weight"):
+        assert relerr(named[k].grad, sd[k].grad) <= 3 * F32_TOL, k
+    # a second forward draws fresh masks
+    enc2, _, _ = m(prot, mol)
+    assert relerr(enc2, enc) > 1e-2
 
 
 def test_pmma_vis_maps():
