@@ -81,12 +81,15 @@ def pmma_dropout_masks(tag, B, L, d, p):
     return {k: torch.from_numpy(v) for k, v in synth.pmma_dropout_masks(tag, B, L, d, p).items()}
 
 
-def check_sub(x, g, key, tol):
-    """compare a big tensor against its stored sub-sample (head/tail rows, row norms, checksum)."""
+def check_sub(x, g, key, tol, elem_tol=None):
+    """compare a big tensor against its stored sub-sample (head/tail rows, row norms, checksum); elem_tol: also element by
+    element (elemerr) on the stored rows."""
     x = x.detach().double().cpu()
     assert relerr(x[:, :4], g[key + "/head"]) <= tol, key + " head"
     assert relerr(x[:, -4:], g[key + "/tail"]) <= tol, key + " tail"
     assert relerr(x.norm(dim=-1), g[key + "/rownorm"]) <= tol, key + " rownorm"
+    if elem_tol is not None:
+        assert elemerr(x[:, :4], g[key + "/head"]) <= elem_tol and elemerr(x[:, -4:], g[key + "/tail"]) <= elem_tol, key + " element-wise"
 
 
 def gradnorms(g, prefix="gradnorm"):

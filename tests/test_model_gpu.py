@@ -191,11 +191,14 @@ def test_training_step_sequence():
             mi += 1
         rec = tr.training_step((vd, vp, y, xd, xp), meta=meta, cur_epoch=ep, ssl_masks=masks)
         after = snapshot()
-        assert abs(float(rec["cls"]) - g["cls"][step]) <= 3e-4 * abs(g["cls"][step]), (step, float(rec["cls"]))
+        # (scalar losses through relerr so that DL_PARITY_LOG records the margins: profiles/r6_parity_margins.txt)
+        assert relerr(torch.tensor([float(rec["cls"])]), torch.tensor([float(g["cls"][step])])) <= 3e-4, (step, float(rec["cls"]))
         if "ssl" in rec:
-            assert abs(float(rec["ssl"]) - g["ssl"][step]) <= 3e-4 * abs(g["ssl"][step]), (step, float(rec["ssl"]))
+            assert relerr(torch.tensor([float(rec["ssl"])]), torch.tensor([float(g["ssl"][step])])) <= 3e-4, (step, float(rec["ssl"]))
         if "cm" in rec:
-            assert abs(float(rec["cm"]) - g["cm"][step]) <= 3e-3 * max(abs(g["cm"][step]), 1e-6), (step, float(rec["cm"]))
+            # (round 5 allowed 3e-3 here; the triplet loss is a hinge sum over ~40 triplets of this batch and agrees to
+            #  the same few 1e-5 as the other losses)
+            assert relerr(torch.tensor([float(rec["cm"])]), torch.tensor([float(g["cm"][step])])) <= 1e-3, (step, float(rec["cm"]), float(g["cm"][step]))
         assert tr.cm_weight == g["cm_weight"][step]
         delta = float((after - before).norm())
         assert abs(delta - g["delta"][step]) <= 3e-2 * g["delta"][step], (step, delta, g["delta"][step])
