@@ -95,6 +95,21 @@ __device__ __forceinline__ float bf16hi(uint32_t w) {
   return __builtin_bit_cast(float, w & 0xffff0000u);
 }
 
+// An fp32 quad rounded to the pipeline's storage type and back: the value a consumer of the STORED tensor would read.
+// STUDY BUILDS ONLY (round 6, tools/trickle_bench.py): gemm_trickle_kernel parks its finished tile in LDS as bf16, so its GELU /
+// gelu' / dropout / residual epilogues act on the rounded pre-activation; in a -DDL_STUDY build gemm_kernel and gemm_big_kernel
+// round at the same point so that the three kernels can be compared bit for bit.  The product library keeps the fp32 value
+// (one rounding per output): there dl_round_store is the identity.
+template <typename T> __device__ __forceinline__ f32x4 dl_round_store(f32x4 v) {
+#ifdef DL_STUDY
+  if constexpr (sizeof(T) == 2) {
+    const uint32_t a = pack_bf16x2(v[0], v[1]), b = pack_bf16x2(v[2], v[3]);
+    return f32x4{bf16lo(a), bf16hi(a), bf16lo(b), bf16hi(b)};
+  }
+#endif
+  return v;
+}
+
 // 4 consecutive elements of T <-> f32x4 (global memory, vector access)
 template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
 template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) {

@@ -366,6 +366,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p0) {
       f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4);
       f32x4 a1 = *reinterpret_cast<const f32x4*>(smem + row * EP + cc * 4 + 16);
       if (EPI != 4) { a0 += hb0; a1 += hb1; }
+      if constexpr ((EPI == 2 || EPI == 3 || EPI == 4) && sizeof(T) == 2 && sizeof(TO) == 2) {       // (common.cuh: as the large-tile kernels)
+        a0 = dl_round_store<T>(a0); a1 = dl_round_store<T>(a1);
+      }
       if constexpr (EPI == 2) {
         T* pd = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
         store4<T>(pd, a0); store4<T>(pd + 4, a1);
@@ -504,6 +507,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmP p0) {
 }
 
 #include "gemm_big.cuh"
+#ifdef DL_STUDY          // (round 6 study kernel: measured and NOT adopted — tools/trickle_bench.py, profiles/r6_trickle_study.txt)
+#include "gemm_trickle.cuh"
+#endif
 
 // out[idx] (+)= sum_z slabs[z][idx]
 template <typename TO>
@@ -616,6 +622,43 @@ bool big_eligible(const dl_gemm_args* a, const GemmP& p, int sp) {
   return tiles >= 192;
 }
 int big_cfg() { return dl_study_env("DL_GEMM_BIGCFG", 0); }
+#ifdef DL_STUDY
+// Trickle form (gemm_trickle.cuh; STUDY LIBRARY ONLY, opt-in through DL_GEMM_TRICKLE=1): 256x128 tiles whose epilogue drains from
+// LDS inside the next tile's main loop.  Returns the pieces per k-step (0 = not eligible).  Needs whole tiles (M % 256, N % 128),
+// K = 256 or a multiple of 512 (the piece schedule), static tile order, one of the epilogues {plain / bias, bias + GELU +
+// pre-activation, bias + residual, gelu'}.
+int trickle_ppk(const dl_gemm_args* a, const GemmP& p, int sp) {
+  if (dl_study_env("DL_GEMM_TRICKLE", 0) == 0) return 0;
+  if (!big_eligible(a, p, sp) || p.tickets) return 0;
+  const int epi = pick_epi(p, false);
+  if (!(epi == 0 || epi == 2 || epi == 3 || epi == 4)) return 0;
+  if (a->N % 128 != 0 || a->N / 128 > 256 || a->M % 256 != 0) return 0;
+  const int64_t kmax = dl_study_env("DL_GEMM_TRICKLE_MAXK", 2048);
+  if (a->K > kmax) return 0;
+  if (a->K == 256) return 2;
+  return a->K % 512 == 0 ? 1 : 0;
+}
+void launch_trickle(const GemmP& p, hipStream_t s, int ppk) {
+  const uint32_t ntiles = (uint32_t)p.mt * p.nt;
+  uint32_t nblocks = (256u / (uint32_t)p.nt) * (uint32_t)p.nt;            // a workgroup keeps its column tile: bias / columns fixed per launch
+  if (nblocks > ntiles) nblocks = ntiles;
+#define DL_TRK(E)                                                                                            \
+  do {                                                                                                       \
+    if (ppk == 2) hipLaunchKernelGGL((gemm_trickle_kernel<E, 2>), dim3(nblocks), dim3(512), 0, s, p);      \
+    else hipLaunchKernelGGL((gemm_trickle_kernel<E, 1>), dim3(nblocks), dim3(512), 0, s, p);               \
+  } while (0)
+  switch (pick_epi(p, false)) {
+    case 0: DL_TRK(0); break;
+    case 2: DL_TRK(2); break;
+    case 3: DL_TRK(3); break;
+    default: DL_TRK(4); break;
+  }
+#undef DL_TRK
+}
+#else
+static inline int trickle_ppk(const dl_gemm_args*, const GemmP&, int) { return 0; }
+static inline void launch_trickle(const GemmP&, hipStream_t, int) {}
+#endif
 // Few-tile ("latency") form of the same kernel: a 128x128 tile per 4-wave workgroup with a DEEP stage ring.  When the
 // whole output is at most a round or two of tiles (strong-scaling batches: M = 8192 ... 32768 rows) every workgroup walks
 // its k-steps alone on its CU, and gemm_kernel's two-buffer ring pays one full memory round trip per k-step; three
@@ -978,6 +1021,9 @@ int gemm_run(const dl_gemm_args* a, const dl_gemm_args* b, dl_stream stream) {
     const int64_t ksteps = (a->K + 63) / 64;
     p.k_per_split = (int)(((ksteps + sp - 1) / sp) * 64);
     launch_big_tt(p, s, tt_bm);
+  } else if (const int ppk = trickle_ppk(a, p, sp)) {
+    p.mt = (int)((a->M + 255) / 256); p.nt = (int)(a->N / 128);
+    launch_trickle(p, s, ppk);
   } else if (big_eligible(a, p, sp)) {
     p.mt = (int)((a->M + 255) / 256); p.nt = (int)((a->N + (big_cfg() == 1 ? 127 : 255)) / (big_cfg() == 1 ? 128 : 256));
     launch_big(p, s);

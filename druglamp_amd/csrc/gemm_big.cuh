@@ -24,6 +24,7 @@ template <int EPI>
 __device__ __forceinline__ void big_epilogue8(const GemmP& p, uint64_t seed_eff, int m, int n, f32x4 a0, f32x4 a1, f32x4 b0, f32x4 b1, u32x4 ext) {
   typedef bf16_t T;
   if constexpr (EPI != 4) { a0 += b0; a1 += b1; }
+  if constexpr (EPI == 2 || EPI == 3 || EPI == 4) { a0 = dl_round_store<T>(a0); a1 = dl_round_store<T>(a1); }   // (common.cuh: as gemm_trickle_kernel)
   if constexpr (EPI == 2) {
     T* pd = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
     u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};

@@ -55,12 +55,15 @@ def test_fill_pool_matches_reference_formulation(dtype, odt, site_len, S, F):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(49152, 512, 256), (49000, 520, 192), (8192, 512, 2048), (8100, 264, 1024), (16384, 256, 512)])
+@pytest.mark.parametrize("M,N,K", [(49152, 512, 256), (49000, 520, 192), (8192, 512, 2048), (8100, 264, 1024), (16384, 256, 512),
+                                   (65536, 1024, 256), (49152, 1536, 512), (33024, 640, 512), (57344, 512, 1024)])
 def test_large_tile_gemm_is_bitwise_equal_to_the_128_tile_path(M, N, K):
-    """The 256x256 persistent kernel (gemm_big.cuh), its few-tile 128x128 deep-ring form (the last three shapes: at most
+    """The 256x256 persistent kernel (gemm_big.cuh), its few-tile 128x128 deep-ring form (shapes 3-5: at most
     256 tiles, K >= 512 — the strong-scaling batches) and gemm_kernel accumulate every output element in the same
     k order and share epilogue math and dropout counters: outputs must be identical bit for bit, for every
-    specialised epilogue, including ragged M / N edges."""
+    specialised epilogue, including ragged M / N edges.  (Shapes 6-9 were added with round 6's trickle kernel — study library
+    only, tools/trickle_bench.py checks it bit for bit there — and stay as further large-tile cases: N = 1024 / 1536 / 640, a
+    partial last round of tiles.)"""
     from druglamp_amd import ops
     g = torch.Generator().manual_seed(11)
     dt = torch.bfloat16
