@@ -1049,6 +1049,7 @@ __global__ __launch_bounds__(ATT_THREADS, 1) void attn_bwd_dkv_ring_kernel(const
 // O tiles and their LSE rows stream through a FOUR-stage LDS ring by LDS-DMA, issued three blocks ahead and counted with
 // vmcnt (in-order), so HBM sees an even demand; Delta = sum_d dO * O of a tile is formed from the ring by all threads one
 // block before it is used; the partner's K / V images are fetched a whole pass early into their own LDS regions.
+__device__ __forceinline__ int ds_swz(int key) { return (((key >> 2) & 1) << 1) | ((key >> 3) & 1); }
 template <typename T, int HD>
 __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(const AttnP p) {
   static_assert(sizeof(T) == 2 && HD == 64, "bf16, head_dim 64");
@@ -1234,13 +1235,17 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(const AttnP p) {
           sb[kt][2 * qt + 1] = pack_bf16x2(dp[kt][2], dp[kt][3]);
         }
       }
-      // dS^T[key][q] image: row = key (64 bytes = 32 q), the 32-byte half of q tile qt sits at half qt ^ ((key >> 2) & 1);
+      // dS^T[key][q] image: row = key (64 bytes = 32 q = four 16-byte chunks: chunk 2 qt + (g >> 1) holds rows 4g .. 4g+3 of q
+      // tile qt); the chunk index is XORed with ds_swz(key) = bit 2 of the key -> bit 1, bit 3 -> bit 0.  Keys il, il + 4, il + 8,
+      // il + 12 of one 8-byte write (and rows r, r + 4 of one transposing read below) start on the same bank; the four of a
+      // write get the four chunk positions, the two of a read different 32-byte halves.  (Rounds 4-5 toggled the half with bit 2
+      // only: keys il and il + 8 collided — 25 % of the kernel's LDS-active cycles were bank conflicts, r4_attn_paired_sq_counters.)
       // words 0-1 of the packed fragment are rows 4g .. 4g+3 of q tile 0 at this lane's key, words 2-3 the same of q tile 1
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
-        const int key = kw0 + kt * 16 + il, sw = (key >> 2) & 1;
-        *reinterpret_cast<u32x2*>(dSb + key * 64 + ((0 ^ sw) << 5) + 8 * g) = u32x2{sb[kt][0], sb[kt][1]};
-        *reinterpret_cast<u32x2*>(dSb + key * 64 + ((1 ^ sw) << 5) + 8 * g) = u32x2{sb[kt][2], sb[kt][3]};
+        const int key = kw0 + kt * 16 + il, sw = ds_swz(key);
+        *reinterpret_cast<u32x2*>(dSb + key * 64 + (((0 + (g >> 1)) ^ sw) << 4) + 8 * (g & 1)) = u32x2{sb[kt][0], sb[kt][1]};
+        *reinterpret_cast<u32x2*>(dSb + key * 64 + (((2 + (g >> 1)) ^ sw) << 4) + 8 * (g & 1)) = u32x2{sb[kt][2], sb[kt][3]};
       }
       // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
@@ -1266,8 +1271,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused_kernel(const AttnP p) {
       f32x4 dq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int cki = 0; cki < 8; ++cki) {
-        const int r0 = cki * 32 + 4 * g + (il >> 2), sw = (r0 >> 2) & 1;     // (r0 + 16) >> 2 has the same parity
-        const uint32_t off = (uint32_t)(r0 * 64 + ((qt_o ^ sw) << 5) + (il & 3) * 8);
+        const int r0 = cki * 32 + 4 * g + (il >> 2), sw = ds_swz(r0);        // (row r0 + 16 has the same swizzle)
+        const uint32_t off = (uint32_t)(r0 * 64 + (((2 * qt_o + ((il & 3) >> 1)) ^ sw) << 4) + (il & 1) * 8);
         const u32x2 lo = lds_read_tr16(dSb, off);
         const u32x2 hi = lds_read_tr16(dSb, off + 16 * 64);
         dq = Mma<T>::mma(ktr[cki], u32x4{lo[0], lo[1], hi[0], hi[1]}, dq);

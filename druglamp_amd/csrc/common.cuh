@@ -290,39 +290,39 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
-// Packed-math erf for the bf16 pipelines: odd rational minimax on [-4, 4] (|err| <= 4.5e-7 absolute, two
-// orders below bf16 rounding), evaluated two lanes at a time with v_pk_fma_f32; ~1/3 of libm erff's
-// instruction count, which otherwise dominates the fused GELU epilogues of the small-K GEMMs.
+// packed fp32 helpers (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth per instruction)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 bc2(float v) { return f32x2{v, v}; }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 erf_fast2(f32x2 x) {
-  x = __builtin_elementwise_max(__builtin_elementwise_min(x, bc2(4.f)), bc2(-4.f));
-  const f32x2 x2 = x * x;
-  f32x2 p = fma2(bc2(-2.72614225801306e-10f), x2, bc2(2.77068142495902e-08f));
-  p = fma2(p, x2, bc2(-2.10102402082508e-06f));
-  p = fma2(p, x2, bc2(-5.69250639462346e-05f));
-  p = fma2(p, x2, bc2(-7.34990630326855e-04f));
-  p = fma2(p, x2, bc2(-2.95459980854025e-03f));
-  p = fma2(p, x2, bc2(-1.60960333262415e-02f));
-  f32x2 q = fma2(bc2(-1.45660718464996e-05f), x2, bc2(-2.13374055278905e-04f));
-  q = fma2(q, x2, bc2(-1.68282697438203e-03f));
-  q = fma2(q, x2, bc2(-7.37332916720468e-03f));
-  q = fma2(q, x2, bc2(-1.42647390514189e-02f));
-  const f32x2 r = {__builtin_amdgcn_rcpf(q[0]), __builtin_amdgcn_rcpf(q[1])};
-  return x * p * r;
+// GELU of the bf16 pipelines (round 6): gelu(x) = x Phi(x), Phi(x) - 1/2 = x R(x^2) with R a degree-8 minimax polynomial on |x| <=
+// 4.3 (linear program over 3000 points, weighted for the error of the PRODUCT x Phi), x clamped to the interval: |error| <= 3.8e-5 on
+// |x| <= 4.3 and <= 7.1e-5 on |x| <= 12 (beyond the interval it grows by 6e-6 per unit: x (1 - Phi(4.3))) — below half a bf16 ulp of
+// every output above 0.02 in magnitude.  13 VALU slots per PAIR (2 v_med3, 11 packed) against 28 for the rational erf above
+// (whose two v_rcp_f32 are quarter rate): the GELU + pre-activation epilogue of the fc1 products is VALU-bound (27 -> 19 slots per
+// output element with the address arithmetic of gemm_big.cuh), 65536x2048x512: see DESIGN section 7.  (Rounds 1-5: an odd rational
+// minimax erf, |err| <= 4.5e-7 — two orders below what a bf16 output can show.)
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+  const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -4.3f, 4.3f), __builtin_amdgcn_fmed3f(x[1], -4.3f, 4.3f)};
+  const f32x2 u = xc * xc;
+  f32x2 r = fma2(bc2(4.198948828e-11f), u, bc2(-4.250320984e-09f));
+  r = fma2(r, u, bc2(1.902729281e-07f));
+  r = fma2(r, u, bc2(-5.007155778e-06f));
+  r = fma2(r, u, bc2(8.712943963e-05f));
+  r = fma2(r, u, bc2(-1.071470790e-03f));
+  r = fma2(r, u, bc2(9.695499204e-03f));
+  r = fma2(r, u, bc2(-6.615635008e-02f));
+  r = fma2(r, u, bc2(3.988027275e-01f));
+  return x * fma2(xc, r, bc2(0.5f));
 }
 // 4-wide GELU / GELU' keyed on the pipeline's storage type: fp32 pipelines keep libm erff (parity runs),
-// bf16 pipelines take the packed rational form.
+// bf16 pipelines take the packed polynomial form.
 template <typename T> __device__ __forceinline__ f32x4 gelu4(f32x4 v) {
   if constexpr (sizeof(T) == 4) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
     return v;
   } else {
-    const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
-    const f32x2 ga = bc2(0.5f) * a * (bc2(1.f) + erf_fast2(a * bc2(0.70710678118654752440f)));
-    const f32x2 gb = bc2(0.5f) * b * (bc2(1.f) + erf_fast2(b * bc2(0.70710678118654752440f)));
+    const f32x2 ga = gelu_fast2(f32x2{v[0], v[1]}), gb = gelu_fast2(f32x2{v[2], v[3]});
     return f32x4{ga[0], ga[1], gb[0], gb[1]};
   }
 }
@@ -330,7 +330,7 @@ template <typename T> __device__ __forceinline__ f32x4 gelu4(f32x4 v) {
 // (least-squares fit, checked in fp32 arithmetic over [-9, 9]) — a factor 40 below the bf16 rounding of the product it
 // feeds.  One reciprocal and 8 packed FMAs per pair instead of erf + exp (the gelu' data-gradient epilogue is VALU-bound).
 __device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
-  x = __builtin_elementwise_max(__builtin_elementwise_min(x, bc2(5.5f)), bc2(-5.5f));
+  x = f32x2{__builtin_amdgcn_fmed3f(x[0], -5.5f, 5.5f), __builtin_amdgcn_fmed3f(x[1], -5.5f, 5.5f)};   // (v_med3_f32: one slot per element; min + max: two)
   const f32x2 x2 = x * x;
   f32x2 p = fma2(bc2(1.6454146817e-04f), x2, bc2(1.4818409354e-02f));
   p = fma2(p, x2, bc2(-2.9252399590e-02f));
@@ -381,6 +381,18 @@ __device__ __forceinline__ uint64_t dl_eff_seed(uint64_t seed, const uint64_t* _
 __device__ __forceinline__ f32x4 dl_dropout4(f32x4 v, uint64_t seed, uint64_t row, uint64_t col,
                                              uint64_t ncols, uint32_t thr16, float inv_keep) {
   const uint64_t bits = dl_splitmix(seed, (row * ncols + col) >> 2);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t b = (uint32_t)(bits >> (16 * j)) & 0xffffu;
+    v[j] = (b >= thr16) ? v[j] * inv_keep : 0.0f;
+  }
+  return v;
+}
+
+// the same draw keyed by the GROUP index ((row * ncols + col) >> 2) directly: callers that walk rows in constant steps keep a running
+// index instead of a 64-bit multiply per quad (gemm_big.cuh)
+__device__ __forceinline__ f32x4 dl_dropout4_idx(f32x4 v, uint64_t seed, uint64_t group, uint32_t thr16, float inv_keep) {
+  const uint64_t bits = dl_splitmix(seed, group);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const uint32_t b = (uint32_t)(bits >> (16 * j)) & 0xffffu;

@@ -20,13 +20,20 @@
 // One 8-column piece of an output row.  b0/b1: the lane's bias values (the column is fixed per lane, loaded once per
 // tile); ext: the residual (EPI 3) or the saved pre-activation (EPI 4) for this piece, requested several pieces
 // ahead by the caller so that its HBM latency is not paid once per piece.
+// Addresses (round 6): a piece's row is row_s + (lane >> 3) with row_s WAVE-UNIFORM (tile row + the wave's offset + a compile-time
+// constant per piece), so every pointer is a scalar base (row_s * ld + the wave's first column: scalar unit) plus ONE 32-bit lane
+// offset per tensor that is the same for every piece and tile (lo_c / lo_p: output, pre-activation copy), and the dropout group
+// index is a scalar plus the lane's constant.  Rounds 1-5 multiplied row * ld (and row * N for the dropout key) per piece in
+// 64-bit vector arithmetic: five quarter-rate integer multiplies = 4 of the ~27 VALU slots per output element of the GELU +
+// dropout epilogue, which is VALU-bound (tools/trickle_parts.py).
 template <int EPI>
-__device__ __forceinline__ void big_epilogue8(const GemmP& p, uint64_t seed_eff, int m, int n, f32x4 a0, f32x4 a1, f32x4 b0, f32x4 b1, u32x4 ext) {
+__device__ __forceinline__ void big_epilogue8(const GemmP& p, uint64_t seed_eff, int row_s, int n0_s, uint32_t lo_c, uint32_t lo_p, uint32_t lo_g,
+                                              f32x4 a0, f32x4 a1, f32x4 b0, f32x4 b1, u32x4 ext) {
   typedef bf16_t T;
   if constexpr (EPI != 4) { a0 += b0; a1 += b1; }
-  if constexpr (EPI == 2 || EPI == 3 || EPI == 4) { a0 = dl_round_store<T>(a0); a1 = dl_round_store<T>(a1); }   // (common.cuh: as gemm_trickle_kernel)
+  if constexpr (EPI == 2 || EPI == 3 || EPI == 4) { a0 = dl_round_store<T>(a0); a1 = dl_round_store<T>(a1); }   // (study builds only: common.cuh)
   if constexpr (EPI == 2) {
-    T* pd = reinterpret_cast<T*>(p.pre_out) + (int64_t)m * p.ldp + n;
+    char* pd = p.pre_out + ((int64_t)row_s * p.ldp + n0_s) * 2 + lo_p;
     u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
     if (p.nt_pre) store16_nt(pd, o, p.nt_pre);
     else *reinterpret_cast<u32x4*>(pd) = o;
@@ -39,15 +46,16 @@ __device__ __forceinline__ void big_epilogue8(const GemmP& p, uint64_t seed_eff,
     a1 *= gelu_grad4<T>(f32x4{bf16lo(ext[2]), bf16hi(ext[2]), bf16lo(ext[3]), bf16hi(ext[3])});
   }
   if (EPI != 5 && EPI != 0 && p.drop_thr16) {
-    a0 = dl_dropout4(a0, seed_eff, (uint64_t)m, (uint64_t)n, (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
-    a1 = dl_dropout4(a1, seed_eff, (uint64_t)m, (uint64_t)(n + 4), (uint64_t)p.N, p.drop_thr16, p.drop_inv_keep);
+    const uint64_t grp = (((uint64_t)row_s * (uint64_t)p.N + (uint64_t)n0_s) >> 2) + lo_g;   // = (row * N + col) >> 2: N % 8 == 0, col % 8 == 0
+    a0 = dl_dropout4_idx(a0, seed_eff, grp, p.drop_thr16, p.drop_inv_keep);
+    a1 = dl_dropout4_idx(a1, seed_eff, grp + 1, p.drop_thr16, p.drop_inv_keep);
   }
   if constexpr (EPI == 3) {
     a0 += f32x4{bf16lo(ext[0]), bf16hi(ext[0]), bf16lo(ext[1]), bf16hi(ext[1])};
     a1 += f32x4{bf16lo(ext[2]), bf16hi(ext[2]), bf16lo(ext[3]), bf16hi(ext[3])};
   }
   u32x4 o = {pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
-  T* dstp = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n;
+  char* dstp = p.C + ((int64_t)row_s * p.ldc + n0_s) * 2 + lo_c;
   if (p.nt_c) store16_nt(dstp, o, p.nt_c);
   else *reinterpret_cast<u32x4*>(dstp) = o;
 }
@@ -239,7 +247,16 @@ void gemm_big_kernel(const GemmP p) {
     constexpr int HPI = 16 / SR, HH = SR / 8, NITEM = XF * HPI * HH, PF = 4;
     const int n_lane = cn0 + wn * 16 * WF + (lane & 7) * 8;
     const bool n_ok = n_lane < p.N;
-    auto m_of = [&](int item) { return cm0 + wm * 16 * XF + (item / (HPI * HH)) * 16 + ((item / HH) % HPI) * SR + (lane >> 3) + 8 * (item % HH); };
+    // rows of this lane's pieces: row_s(item) + (lane >> 3), row_s wave-uniform (ro_of: a compile-time constant per unrolled item)
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int row0_s = cm0 + (wave_s / NWN) * 16 * XF, n0_s = cn0 + (wave_s % NWN) * 16 * WF;
+    auto ro_of = [](int item) { return (item / (HPI * HH)) * 16 + ((item / HH) % HPI) * SR + 8 * (item % HH); };
+    const int lr = lane >> 3, lc = (lane & 7) * 8;
+    const uint32_t lo_c = (uint32_t)((lr * (int)p.ldc + lc) * 2);                         // byte offsets of (row lr, column lc) of a piece
+    const uint32_t lo_p = EPI == 2 ? (uint32_t)((lr * (int)p.ldp + lc) * 2) : 0u;
+    const int64_t lde = EPI == 3 ? p.ldr : p.lddp;
+    const uint32_t lo_e = (EPI == 3 || EPI == 4) ? (uint32_t)((lr * (int)lde + lc) * 2) : 0u;
+    const uint32_t lo_g = (uint32_t)((lr * p.N + lc) >> 2);                              // dropout group offset
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
     if (EPI != 4 && p.bias && n_ok) {
       b0 = *reinterpret_cast<const f32x4*>(p.bias + n_lane);
@@ -248,10 +265,9 @@ void gemm_big_kernel(const GemmP p) {
     auto fetch = [&](int item) -> u32x4 {
       u32x4 v = {0u, 0u, 0u, 0u};
       if constexpr (EPI == 3 || EPI == 4) {
-        const int m = m_of(item);
-        if (m < p.M && n_ok) {
-          const T* src = EPI == 3 ? reinterpret_cast<const T*>(p.res) + (int64_t)m * p.ldr + n_lane
-                                  : reinterpret_cast<const T*>(p.dact_pre) + (int64_t)m * p.lddp + n_lane;
+        const int row_s = row0_s + ro_of(item);
+        if (row_s + lr < p.M && n_ok) {
+          const char* src = (EPI == 3 ? p.res : p.dact_pre) + ((int64_t)row_s * lde + n0_s) * 2 + lo_e;
           v = p.nt_ext ? load16_nt(src) : *reinterpret_cast<const u32x4*>(src);
         }
       }
@@ -278,8 +294,9 @@ void gemm_big_kernel(const GemmP p) {
           const int r = (lane >> 3) + 8 * h, c8 = lane & 7;
           const f32x4 a0 = __builtin_bit_cast(f32x4, lds_read16(st, r * 256 + (((2 * c8) ^ r) << 4)));
           const f32x4 a1 = __builtin_bit_cast(f32x4, lds_read16(st, r * 256 + (((2 * c8 + 1) ^ r) << 4)));
-          const int m = m_of(item);
-          if (m < p.M && n_ok && !(DL_DBG(p) & 1)) big_epilogue8<EPI>(p, seed_eff, m, n_lane, a0, a1, b0, b1, ext[item]);
+          const int row_s = row0_s + ro_of(item);
+          if (row_s + lr < p.M && n_ok && !(DL_DBG(p) & 1))
+            big_epilogue8<EPI>(p, seed_eff, row_s, n0_s, lo_c, lo_p, lo_g, a0, a1, b0, b1, ext[item]);
         }
         wave_sync();
       }

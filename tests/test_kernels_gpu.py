@@ -772,3 +772,31 @@ def test_bn_stats_finalize_is_bit_identical_to_the_three_launch_form(dt, R, C, w
     for a, b, what in ((ma, mb, "mean"), (va, vb, "var"), (ra, rb, "rstd"), (rm_a, rm_b, "running mean"), (rv_a, rv_b, "running var")):
         assert torch.equal(a, b), what
     assert not torch.equal(rm_a, rm0)
+
+
+@pytest.mark.gpu
+def test_gelu_epilogue_of_the_bf16_pipeline_is_within_half_a_bf16_ulp_of_erf_gelu():
+    """Round 6: the bf16 GEMM epilogues evaluate GELU as x (1/2 + x R(x^2)) with a degree-8 minimax R on |x| <= 4.3 (13 VALU slots per
+    pair instead of the rational erf's 28; common.cuh::gelu_fast2).  Here the pre-activations are EXACT: x rows are one-hot, so
+    acc = one weight value, bias 0 — a grid over [-12, 12] plus the region around 0 and the minimum of GELU.  Output against
+    bf16(erf-GELU(pre)) in fp64: the error may not exceed half a bf16 ulp of the exact value + 8e-5 (the stated bound of the
+    approximation); the pre-activation copy is the exact value."""
+    from druglamp_amd import ops
+    dt = torch.bfloat16
+    M, N, K = 4096, 256, 64
+    grid = torch.cat((torch.linspace(-12, 12, 8192), torch.linspace(-1.5, 1.5, 4096), torch.linspace(-4.5, -3.5, 2048),
+                      torch.linspace(3.5, 4.5, 2048)))[:N * K].to(dt)
+    w = grid.reshape(N, K).contiguous().cuda()                      # w[n][k]
+    x = torch.zeros(M, K, dtype=dt)
+    x[torch.arange(M), torch.arange(M) % K] = 1.0                   # row m selects column k = m % 64
+    x = x.cuda()
+    for algo in (1, 0):
+        pre = torch.empty(M, N, device="cuda", dtype=dt)
+        h = ops.gemm(x, w, M=M, N=N, K=K, act=1, pre_out=pre, bias=torch.zeros(N, device="cuda"), algo=algo)
+        want_pre = w.t()[torch.arange(M, device="cuda") % K]          # (M, N): pre[m][n] = w[n][m % K]
+        assert torch.equal(pre, want_pre)
+        p64 = pre.double()
+        ref = 0.5 * p64 * (1.0 + torch.erf(p64 / 2 ** 0.5))
+        err = (h.double() - ref).abs()
+        bound = 0.5 * ref.abs() * 2.0 ** -7 + 8e-5                    # half a bf16 ulp (<= 2^-8 relative to the binade's top: 2^-7 x value / 2) + the bound
+        assert bool((err <= bound).all()), (algo, float((err - bound).max()), float(p64.flatten()[(err - bound).argmax()]))

@@ -1,5 +1,9 @@
 """Bitwise repeatability of kernels while a second process hammers the same GPU (races on counted waits / LDS rings show up
-as rare mismatching launches only under contention).  usage: contention_repeat.py [reps]"""
+as rare mismatching launches only under contention).  usage: contention_repeat.py [reps]
+CR_LOAD=process (default): the load is a second PROCESS (its queues are time-sliced against ours: waves are saved / restored);
+CR_LOAD=thread: the same load from a second thread of THIS process on its own stream (kernels of one process share the chip
+without queue time-slicing); CR_LOAD=none: idle GPU.  Round 6 uses the three to ask what the round-3 LayerNorm-backward fault
+(stale lanes 48-63 with the SLP-vectorised build, only under load) depends on."""
 import os, sys, time, subprocess, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ROLE = os.environ.get("CR_ROLE", "main")
@@ -88,7 +92,8 @@ def rows_pool(B):
         return (pd.buf.clone(), ops.cnn_sitepool_rows_fwd(z, pd.row_of, B, 2304, 9), ops.cnn_sitepool_rows_bwd(g, pd.rep, pd.row_of, 2304, 9),
                 ops.rows_gather(z, pd.row_of), ops.cast(x32, dt))
     return run
-cases = {"BatchNorm stats+finalize / apply / bwd reduce / bwd apply 300000x128 (wide kernels)": bn(300000, 128, False),
+def make_cases():
+  return {"BatchNorm stats+finalize / apply / bwd reduce / bwd apply 300000x128 (wide kernels)": bn(300000, 128, False),
          "BatchNorm with row weights 165888x128": bn(165888, 128, True), "BatchNorm 70000x96 (generic kernels)": bn(70000, 96, False),
          "row tables built on the device, site pooling through the row map fwd / bwd, rows_gather, cast": rows_pool(128),
          "attention backward one-pass, paired 384 x 4 x 256^2 (LDS-DMA ring, counted waits)": attn_bwd(384, 4, 2, 256, 3),
@@ -99,6 +104,7 @@ cases = {"BatchNorm stats+finalize / apply / bwd reduce / bwd apply 300000x128 (
          "nn bias+dropout+residual 65536x512x2048": nn_res(65536, 512, 2048), "nn gelu 128-tile 65536x128x648": nn_gelu(65536, 128, 648),
          "fill_pool + dropout_apply": misc(), "ntxent bf16 n=8192": ntx(8192, 128, dt), "ntxent f32 n=2048": ntx(2048, 128, torch.float32),
          "ln 65536x256": ln(65536, 256), "ln 65536x512": ln(65536, 512), "ln 65536x384 (8-byte kernels)": ln(65536, 384)}
+cases = make_cases()
 if only_ln and ROLE == "main":
     cases = {k: v for k, v in cases.items() if k.startswith("ln")}
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
@@ -109,9 +115,27 @@ if ROLE == "load":
         for f in fs: f()
         torch.cuda.synchronize()
     sys.exit(0)
-env = dict(os.environ, CR_ROLE="load", CR_SECONDS="90")
-p = subprocess.Popen([sys.executable, os.path.abspath(__file__)], env=env)
-time.sleep(8)
+LOAD = os.environ.get("CR_LOAD", "process")
+p = None
+stop = [False]
+if LOAD == "process":
+    env = dict(os.environ, CR_ROLE="load", CR_SECONDS="90")
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__)], env=env)
+    time.sleep(8)
+elif LOAD == "thread":
+    import threading
+    lcases = list(make_cases().values())           # the loader's own tensors
+    side = torch.cuda.Stream()
+    def loader():
+        with torch.cuda.stream(side):
+            while not stop[0]:
+                for f in lcases:
+                    if stop[0]: break
+                    f()
+                side.synchronize()
+    th = threading.Thread(target=loader, daemon=True); th.start()
+    time.sleep(3)
+print("load:", LOAD, flush=True)
 for name, f in cases.items():
     ref = [t.clone() for t in f()]; torch.cuda.synchronize()
     bad = 0
@@ -131,4 +155,6 @@ for name, f in cases.items():
                     else:
                         print("      columns:", (d > 0).nonzero().flatten().tolist(), flush=True)
     print("%-32s mismatching launches %d / %d" % (name, bad, reps), flush=True)
-p.terminate(); p.wait()
+stop[0] = True
+if p is not None:
+    p.terminate(); p.wait()
