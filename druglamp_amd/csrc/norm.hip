@@ -189,7 +189,12 @@ template <int LPR> __device__ __forceinline__ float seg_sum(float v) {      // s
 }
 __device__ __forceinline__ void unpack8(u32x4 w, float (&f)[8]) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { f[2 * e] = bf16lo(w[e]); f[2 * e + 1] = bf16hi(w[e]); }
+  for (int e = 0; e < 4; ++e) {
+    f[2 * e] = bf16lo(w[e]); f[2 * e + 1] = bf16hi(w[e]);
+#ifdef DL_UNPACK_NOP   // (round 6 hazard experiment, tools/_run7.sh: a wait state between the unpacking shift and whatever consumes it)
+    asm volatile("s_nop 1" : "+v"(f[2 * e]));
+#endif
+  }
 }
 __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
   return u32x4{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
