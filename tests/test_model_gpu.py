@@ -438,7 +438,13 @@ def test_cross_attention_over_the_distinct_drug_rows_whole_model(dt, tol):
     ref.pmma.embeddings.p_drop = 0.0
     ref.set_compute_dtype(dt)
     ref.drug_extractor.compact_min_rows = 0           # (a batch of 4: take the compact MolecularGCN form anyway)
-    batch, meta = make_batch(4, DEV, seed=11, with_graph=True, llm_dtype=dt)
+    # bf16: batch 16.  Rounds 4-5 ran this leg at batch 4, where the classifier's BatchNorm over four rows amplifies the fp32
+    # rounding differences of the two softmax orders chaotically: the thresholds below were one seed's draw (round 5 over eight
+    # seeds: whole-gradient cosine 0.9933-0.9981, score 0.6-4.3 %; round 6 the same spread, 0.9844-0.9977 — the committed seed
+    # fell to 0.99476 against a 0.995 threshold).  At batch 16 both rounds give 0.9986-0.9994 over eight seeds, the 40 largest
+    # tensors 0.91-0.96, scores within 0.8-4.3 % (tools/compact_keys_cosine.py, profiles/r6_compact_keys_cosine.txt).
+    B = 4 if dt == torch.float32 else 16
+    batch, meta = make_batch(B, DEV, seed=11, with_graph=True, llm_dtype=dt)
     blk = Trainer.padding_hints_of(meta, batch)["drug_tokens"]
     cmp_ = copy.deepcopy(ref)
     ref.compact_keys, cmp_.compact_keys = False, True
@@ -456,13 +462,13 @@ def test_cross_attention_over_the_distinct_drug_rows_whole_model(dt, tol):
             ops_mod.attn_fwd = real
         # (a weighted sum: the plain sum of the scores of a batch is constant under the classifier's last BatchNorm — its
         #  gradient in front of that layer is identically zero, i.e. rounding noise — and would test nothing)
-        (score.float().view(-1) * torch.tensor([1.0, -2.0, 0.5, 3.0], device=DEV)).sum().backward()
+        (score.float().view(-1) * torch.tensor([1.0, -2.0, 0.5, 3.0], device=DEV).repeat(B // 4)).sum().backward()
         outs.append(score.float())
         calls.append([c for c in seen if c[0] != 256])                  # the two PGCA launches (PMMA's have Lk = 256)
     assert calls[0] == [(512, None), (512, None)]
     assert sorted(calls[1]) == sorted([(128 + 8, (8, 48)), (blk + 8, (8, (512 - blk) // 8))]), calls[1]
     # (the softmax over 136 weighted keys and over 512 keys sum in different orders: fp32 rounding, carried through the network)
-    assert relerr(outs[1], outs[0]) <= tol
+    assert relerr(outs[1], outs[0]) <= (tol if dt == torch.float32 else 3 * tol)      # (bf16: 0.06 against a measured 0.043 at worst)
     # Gradients.  Parameters in front of a BatchNorm carry little signal (a bias directly in front of one has none at all:
     # what arrives there is rounding noise, in either form), so every tensor is compared on the scale of the LARGEST gradient
     # entries of the model as well as on its own: |a - b| <= tol x max(own largest entry, 1e-3 x model's largest entry).
@@ -474,10 +480,10 @@ def test_cross_attention_over_the_distinct_drug_rows_whole_model(dt, tol):
             assert float((a - b).abs().max()) <= 20 * tol * max(float(a.abs().max()), 1e-3 * top), n
     else:
         va, vb = torch.cat([a.double().flatten() for _, a, _ in pa]), torch.cat([b.double().flatten() for _, _, b in pa])
-        assert float(torch.dot(va, vb) / (va.norm() * vb.norm())) >= 0.995
+        assert float(torch.dot(va, vb) / (va.norm() * vb.norm())) >= 0.997                 # (measured 0.9986-0.9994)
         for n, a, b in sorted(pa, key=lambda t: -float(t[1].norm()))[:40]:
             x, y = b.double().flatten(), a.double().flatten()
-            assert float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)) >= 0.95, n      # (0.96 at worst: MolecularGCN's first weight)
+            assert float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)) >= 0.88, n      # (measured 0.905-0.964 at worst: MolecularGCN's first weight)
     ops_mod.check_guard_flags(DEV)
 
 
