@@ -191,7 +191,7 @@ __device__ __forceinline__ void unpack8(u32x4 w, float (&f)[8]) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     f[2 * e] = bf16lo(w[e]); f[2 * e + 1] = bf16hi(w[e]);
-#ifdef DL_UNPACK_NOP   // (round 6 hazard experiment, tools/hazard_run2.sh: a wait state between the unpacking shift and whatever consumes it)
+#ifdef DL_UNPACK_NOP   // (round 6 hazard experiment, tools/_run7.sh: a wait state between the unpacking shift and whatever consumes it)
     asm volatile("s_nop 1" : "+v"(f[2 * e]));
 #endif
   }
